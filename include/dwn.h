@@ -1,0 +1,267 @@
+/* libdwiseneuro_hip.so — C-ABI of the MI355X-native DwiseNeuro hot path.
+ *
+ * The reference (lRomul/sensorium) has no native code and no FFI: its hot path is
+ * `DwiseNeuro.forward` (src/models/dwiseneuro.py:397-405) + `MicePoissonLoss` (src/losses.py:10-21) driven
+ * by `MouseModel.train_step` (src/argus_models.py:43-71), all delegated to torch/cuDNN ops.  This header is
+ * the boundary a maintainer binds instead (ctypes stub: INTEGRATION.md): one entry point per fused kernel
+ * family plus block-level composites, each citing the reference lines it replaces.
+ *
+ * Conventions
+ *  - plain `extern "C"`, raw device pointers + sizes; no torch types.  The caller (PyTorch) owns and
+ *    allocates every buffer, including workspaces; the library never allocates device memory, keeps no
+ *    mutable global state, never synchronises, and enqueues only on the passed `stream`
+ *    (hipGraph-capturable).  Every call takes an explicit `device` because autograd calls backward from a
+ *    worker thread whose current device is not the caller's.
+ *  - return value: 0 ok; < 0 argument / unsupported-configuration error; > 0 a hipError_t.
+ *    `dwn_last_error()` returns a thread-local message.
+ *  - activations are channels-last matrices [rows = (b,t,h,w)][C] in `dtype` storage
+ *    (DWN_F32 = fp32 parity mode, DWN_BF16 = bf16 storage / fp32 accumulate).  Parameters, BN
+ *    coefficients, statistics and gradients of parameters are always fp32.
+ *  - channel counts must be multiples of 8 (one 16-byte bf16 vector).
+ */
+#ifndef DWN_H_
+#define DWN_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DWN_ABI_VERSION 1
+#define DWN_F32 0
+#define DWN_BF16 1
+#define DWN_NREP 32 /* replicas of every cross-workgroup statistics buffer: double[DWN_NREP][2][C] */
+
+/* operand loader kinds (how a kernel reads one 16-byte channel vector of an operand) */
+#define DWN_LD_PLAIN 0   /* p                                                     */
+#define DWN_LD_PE 1      /* p + pe_t[t] + pe_h[h] + pe_w[w]      (dwiseneuro.py:184-192) */
+#define DWN_LD_BNACT 2   /* act(v1*p + v2) * gate[b]             (dwiseneuro.py:16-22, 38-43) */
+#define DWN_LD_AFFINE2 3 /* v1*p + v2*q + v3                     (BatchNorm backward) */
+#define DWN_LD_DY3 4     /* v1*((p*gate[b]+gate2[b])*silu'(v4*q+v5)) + v2*q + v3 (SE + BN3 backward) */
+
+typedef struct dwn_load_desc {
+    const void* p;
+    const void* q;
+    long long ld;
+    const float* v1;
+    const float* v2;
+    const float* v3;
+    const float* v4;
+    const float* v5;
+    const float* gate;
+    const float* gate2;
+    int gate_ld;
+    int rows_per_sample;
+    int act;
+    const float* pe_t;
+    const float* pe_h;
+    const float* pe_w;
+    int pT, pH, pW;
+    int pe_ld;
+} dwn_load_desc;
+
+#define DWN_EPI_STORE 0
+#define DWN_EPI_READOUT 1
+#define DWN_EPI_DG 2
+
+/* C[M][N] = load(A)[M][K] . B[N][K]^T  (+ BN statistics / readout / SE-grad epilogues).
+ * Replaces nn.Conv3d 1x1x1 (dwiseneuro.py:91,118) and grouped nn.Conv1d k=1 (:207,276). */
+typedef struct dwn_gemm_nn_args {
+    dwn_load_desc a;
+    int a_kind;
+    const void* b; long long ldb;
+    void* c; long long ldc;
+    int M, N, K;
+    int groups;
+    double* stats; int stat_rep_stride_unused; int stat_nchan;
+    int epi;
+    const float* bias; float sp_beta; float* out_nct; int Tn; int n_valid;
+    const void* y3; long long ldy3; const float* s3; const float* t3; float* dg; int dg_ld; int rows_per_sample;
+} dwn_gemm_nn_args;
+
+/* dW[R][Cc] += sum_m load(P)[m][r] * load(Q)[m][c]   (fp32 atomics; dW must be zeroed by the caller) */
+typedef struct dwn_gemm_tn_args {
+    dwn_load_desc p; int p_kind;
+    dwn_load_desc q; int q_kind;
+    int M, R, Cc;
+    float* dw; long long lddw;
+    int groups;
+    int rows_per_split; int nsplit;       /* nsplit <= 0: chosen by the library */
+    int R_load;                           /* P columns per group incl. zero padding (>= R; 0 -> R) */
+} dwn_gemm_tn_args;
+
+/* depth-wise (1,k,k) conv, stride (1,s,s), pad k/2 — dwiseneuro.py:96-100 */
+typedef struct dwn_dw_spatial_fwd_args {
+    dwn_load_desc in;   /* DWN_LD_BNACT over raw y1 */
+    const float* w;     /* [k*k][C] fp32 tap-major */
+    void* out;
+    int planes, Hin, Win, Hout, Wout, C, stride, ks;
+    double* stats;
+    int rows_band;      /* <= 0: chosen by the library */
+} dwn_dw_spatial_fwd_args;
+
+typedef struct dwn_dw_spatial_bwd_args {
+    dwn_load_desc dy;   /* DWN_LD_AFFINE2 over (dh2, y2) */
+    dwn_load_desc y1;   /* p = raw y1; v1..v4 = bn1 scale, shift, mean, invstd */
+    const float* w;
+    void* dh1;
+    float* dw;          /* [C][k*k] fp32, accumulated */
+    int planes, Hin, Win, Hout, Wout, C, stride, ks;
+    double* stats;
+    int rows_band;
+} dwn_dw_spatial_bwd_args;
+
+/* depth-wise (k,1,1) conv along T, pad k/2 — dwiseneuro.py:105-109 */
+typedef struct dwn_dw_temporal_fwd_args {
+    dwn_load_desc in;
+    const float* w;     /* [k][C] */
+    void* out;
+    int B, T, HW, C, kt;
+    double* stats;
+} dwn_dw_temporal_fwd_args;
+
+typedef struct dwn_dw_temporal_bwd_args {
+    dwn_load_desc dy; int dy_kind;   /* DWN_LD_DY3 or DWN_LD_AFFINE2 */
+    dwn_load_desc y2;                /* p = raw y2; v1..v4 = bn2 scale, shift, mean, invstd */
+    const float* w;
+    void* dh2;
+    float* dw;                       /* [C][k] */
+    int B, T, HW, C, kt;
+    double* stats;
+} dwn_dw_temporal_bwd_args;
+
+/* BatchNorm parameter bundle (BatchNormAct, dwiseneuro.py:9-22) */
+typedef struct dwn_bn {
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var; long long* num_batches_tracked;
+    float* coef;    /* [4][C]: scale, shift, mean, invstd — written by forward, read by backward */
+    float* dgamma; float* dbeta;   /* backward outputs (may be null in forward) */
+} dwn_bn;
+
+/* stem: Conv3d(C_in->C0, 1x1x1) + BN on the NCDHW fp32 input — dwiseneuro.py:306-309 */
+typedef struct dwn_stem_args {
+    int dtype, training, B, Cin, C0; long long S;   /* S = T*H*W */
+    float eps, momentum;
+    const float* x;      /* [B][Cin][S] fp32 */
+    const float* w;      /* [C0][Cin] */
+    dwn_bn bn;
+    void* y0;            /* raw conv output [B*S][C0] (saved) */
+    void* out;           /* BN output [B*S][C0] */
+    const void* dout;    /* backward: grad wrt out */
+    float* dw;           /* backward: [C0][Cin], zeroed by caller */
+    void* ws; size_t ws_bytes;
+} dwn_stem_args;
+
+/* one InvertedResidual3d preceded by its PositionalEncoding3d — dwiseneuro.py:136-144, 184-192 */
+typedef struct dwn_block_args {
+    int dtype, training;
+    int B, T, Hin, Win, Hout, Wout, Cin, Cmid, Cout, stride, ks, kt, se_r;
+    float eps, momentum;
+    const void* x; void* out;
+    void *y1, *y2, *y3, *y4;
+    const float *pe_t, *pe_h, *pe_w;
+    const float *w_pw, *w_dws, *w_dwt, *w_pwl, *se_wr, *se_br, *se_we, *se_be;
+    dwn_bn bn1, bn2, bn3, bn4, bnsc;
+    const float* drop_scale;                 /* [B] DropPath factor mask/keep (dwiseneuro.py:46-54) or null */
+    const int *hsrc, *wsrc, *hinv, *winv;    /* nearest-interpolation index maps (device int32) */
+    float *se_pmean, *se_hidpre, *se_gate;   /* saved SE activations [B][Cmid], [B][se_r], [B][Cmid] */
+    /* backward only */
+    const void* dout; void* dx;
+    void *buf_a, *buf_b;                     /* scratch [max(M_in,M_out)][Cmid], [M_out][Cmid] */
+    void *dy4, *da0;                         /* scratch [M_out][Cout], [M_in][Cin] */
+    float *dw_pw, *dw_dws, *dw_dwt, *dw_pwl, *dse_wr, *dse_br, *dse_we, *dse_be;   /* zeroed by caller */
+    void* ws; size_t ws_bytes;
+} dwn_block_args;
+
+/* AdaptiveAvgPool3d((None,1,1)) — dwiseneuro.py:374,400 */
+typedef struct dwn_pool_args {
+    int dtype; long long BT; int HW, C;
+    const void* x; void* out; const void* dout; void* dx;
+} dwn_pool_args;
+
+/* ShuffleLayer — dwiseneuro.py:228-234 */
+typedef struct dwn_cortex_args {
+    int dtype, training, B, T, Cin, C, groups;
+    float eps, momentum;
+    const void* x; void* out; void* y;      /* y: raw conv output [B*T][C] (saved) */
+    const float* w;                         /* [C][Cin/groups] */
+    dwn_bn bn, bnsc;
+    const float* drop_scale;
+    const void* dout; void* dx; float* dw;  /* backward */
+    const float* dout_mask; int dout_mask_ld; /* optional [B][C] multiplier on dout (readout Dropout1d backward) */
+    void* ws; size_t ws_bytes;
+} dwn_cortex_args;
+
+/* Readout — dwiseneuro.py:283-287 */
+typedef struct dwn_readout_args {
+    int dtype, B, T, Cin, groups, n_out;    /* n_out = N (valid neurons); weight has ceil(N/g)*g rows */
+    float softplus_beta;
+    const void* x;                          /* [B*T][Cin] */
+    const float* w; const float* bias;      /* [Npad][Cin/groups], [Npad] */
+    const float* drop_mask;                 /* [B][Cin] Dropout1d factor or null */
+    float* out;                             /* [B][N][T] fp32 */
+    const float* dout; void* dx; float* dw; float* dbias;   /* backward (dw, dbias zeroed by caller) */
+    void* ws; size_t ws_bytes;
+} dwn_readout_args;
+
+typedef struct dwn_tensor_entry {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq; float* ema;
+    long long numel; int is_int64; int pad_;
+} dwn_tensor_entry;
+
+int dwn_abi_version(void);
+int dwn_sizeof(const char* struct_name);   /* sizeof of a struct of this header, -1 if unknown (binding self-check) */
+const char* dwn_last_error(void);
+
+/* kernel families */
+int dwn_gemm_nn(const dwn_gemm_nn_args* a, int dtype, int device, void* stream);
+int dwn_gemm_tn(const dwn_gemm_tn_args* a, int dtype, int device, void* stream);
+int dwn_dw_spatial_fwd(const dwn_dw_spatial_fwd_args* a, int dtype, int device, void* stream);
+int dwn_dw_spatial_bwd(const dwn_dw_spatial_bwd_args* a, int dtype, int device, void* stream);
+int dwn_dw_temporal_fwd(const dwn_dw_temporal_fwd_args* a, int dtype, int device, void* stream);
+int dwn_dw_temporal_bwd(const dwn_dw_temporal_bwd_args* a, int dtype, int device, void* stream);
+int dwn_bn_finalize(const double* stats, int stat_c, double count, const dwn_bn* bn, int C, int training,
+                    float momentum, float eps, int device, void* stream);
+int dwn_bn_bwd_finalize(const double* stats, double count, const dwn_bn* bn, float* abc, int C, int device,
+                        void* stream);
+int dwn_pack_weight(const float* src, void* dst, int groups, int R, int C, int transpose, int Rd, int Cd,
+                    int dtype, int device, void* stream);
+
+/* composites (forward / backward of one reference module each) */
+size_t dwn_stem_workspace_bytes(const dwn_stem_args* a);
+int dwn_stem_forward(const dwn_stem_args* a, int device, void* stream);
+int dwn_stem_backward(const dwn_stem_args* a, int device, void* stream);
+size_t dwn_block_workspace_bytes(const dwn_block_args* a, int backward);
+int dwn_block_forward(const dwn_block_args* a, int device, void* stream);
+int dwn_block_backward(const dwn_block_args* a, int device, void* stream);
+int dwn_pool_forward(const dwn_pool_args* a, int device, void* stream);
+int dwn_pool_backward(const dwn_pool_args* a, int device, void* stream);
+size_t dwn_cortex_workspace_bytes(const dwn_cortex_args* a, int backward);
+int dwn_cortex_forward(const dwn_cortex_args* a, int device, void* stream);
+int dwn_cortex_backward(const dwn_cortex_args* a, int device, void* stream);
+size_t dwn_readout_workspace_bytes(const dwn_readout_args* a, int backward);
+int dwn_readout_forward(const dwn_readout_args* a, int device, void* stream);
+int dwn_readout_backward(const dwn_readout_args* a, int device, void* stream);
+
+/* MicePoissonLoss — losses.py:10-21.  w = mice_weights[:, m] / sum(mice_weights) (normalised by caller).
+ * forward accumulates into *loss_acc (double, zeroed by caller); backward writes dpred. */
+int dwn_poisson_loss_forward(const float* pred, const float* target, const float* w, long long per_sample,
+                             long long total, float eps, double* loss_acc, int device, void* stream);
+int dwn_poisson_loss_backward(const float* pred, const float* target, const float* w, const float* gscale,
+                              long long per_sample, long long total, float eps, float* dpred, int device,
+                              void* stream);
+int dwn_f64_to_f32(const double* src, float* dst, int n, int device, void* stream);
+
+/* fused multi-tensor AdamW (+EMA) — torch.optim.AdamW (true_batch_001.py:45-48) + ModelEma.update (ema.py:47-55).
+ * `list` is a DEVICE array of ntensors entries.  step >= 1. */
+int dwn_adamw_ema_multi(const dwn_tensor_entry* list, int ntensors, int max_blocks, double lr, double beta1,
+                        double beta2, double eps, double weight_decay, long long step, double ema_decay,
+                        double grad_scale, int device, void* stream);
+int dwn_ema_lerp_multi(const dwn_tensor_entry* list, int ntensors, int max_blocks, double decay, int device,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DWN_H_ */

@@ -1,0 +1,197 @@
+"""ctypes binding of libdwiseneuro_hip.so (C-ABI: include/dwn.h).
+
+The product path has no fallback: if the shared library is missing or its ABI does not match, importing
+this module raises.  Structures mirror include/dwn.h field by field; ``dwn_sizeof`` cross-checks the layout.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "csrc" / "libdwiseneuro_hip.so"
+
+c_p = C.c_void_p
+c_i = C.c_int
+c_ll = C.c_longlong
+c_f = C.c_float
+c_d = C.c_double
+c_sz = C.c_size_t
+
+DWN_F32, DWN_BF16 = 0, 1
+DWN_NREP = 32
+LD_PLAIN, LD_PE, LD_BNACT, LD_AFFINE2, LD_DY3 = 0, 1, 2, 3, 4
+EPI_STORE, EPI_READOUT, EPI_DG = 0, 1, 2
+
+
+class LoadDesc(C.Structure):
+    _fields_ = [("p", c_p), ("q", c_p), ("ld", c_ll), ("v1", c_p), ("v2", c_p), ("v3", c_p), ("v4", c_p),
+                ("v5", c_p), ("gate", c_p), ("gate2", c_p), ("gate_ld", c_i), ("rows_per_sample", c_i),
+                ("act", c_i), ("pe_t", c_p), ("pe_h", c_p), ("pe_w", c_p), ("pT", c_i), ("pH", c_i),
+                ("pW", c_i), ("pe_ld", c_i)]
+
+
+class GemmNNArgs(C.Structure):
+    _fields_ = [("a", LoadDesc), ("a_kind", c_i), ("b", c_p), ("ldb", c_ll), ("c", c_p), ("ldc", c_ll),
+                ("M", c_i), ("N", c_i), ("K", c_i), ("groups", c_i), ("stats", c_p),
+                ("stat_rep_stride_unused", c_i), ("stat_nchan", c_i), ("epi", c_i), ("bias", c_p),
+                ("sp_beta", c_f), ("out_nct", c_p), ("Tn", c_i), ("n_valid", c_i), ("y3", c_p), ("ldy3", c_ll),
+                ("s3", c_p), ("t3", c_p), ("dg", c_p), ("dg_ld", c_i), ("rows_per_sample", c_i)]
+
+
+class GemmTNArgs(C.Structure):
+    _fields_ = [("p", LoadDesc), ("p_kind", c_i), ("q", LoadDesc), ("q_kind", c_i), ("M", c_i), ("R", c_i),
+                ("Cc", c_i), ("dw", c_p), ("lddw", c_ll), ("groups", c_i), ("rows_per_split", c_i),
+                ("nsplit", c_i), ("R_load", c_i)]
+
+
+class DwSpatialFwdArgs(C.Structure):
+    _fields_ = [("inp", LoadDesc), ("w", c_p), ("out", c_p), ("planes", c_i), ("Hin", c_i), ("Win", c_i),
+                ("Hout", c_i), ("Wout", c_i), ("C", c_i), ("stride", c_i), ("ks", c_i), ("stats", c_p),
+                ("rows_band", c_i)]
+
+
+class DwSpatialBwdArgs(C.Structure):
+    _fields_ = [("dy", LoadDesc), ("y1", LoadDesc), ("w", c_p), ("dh1", c_p), ("dw", c_p), ("planes", c_i),
+                ("Hin", c_i), ("Win", c_i), ("Hout", c_i), ("Wout", c_i), ("C", c_i), ("stride", c_i),
+                ("ks", c_i), ("stats", c_p), ("rows_band", c_i)]
+
+
+class DwTemporalFwdArgs(C.Structure):
+    _fields_ = [("inp", LoadDesc), ("w", c_p), ("out", c_p), ("B", c_i), ("T", c_i), ("HW", c_i), ("C", c_i),
+                ("kt", c_i), ("stats", c_p)]
+
+
+class DwTemporalBwdArgs(C.Structure):
+    _fields_ = [("dy", LoadDesc), ("dy_kind", c_i), ("y2", LoadDesc), ("w", c_p), ("dh2", c_p), ("dw", c_p),
+                ("B", c_i), ("T", c_i), ("HW", c_i), ("C", c_i), ("kt", c_i), ("stats", c_p)]
+
+
+class BN(C.Structure):
+    _fields_ = [("gamma", c_p), ("beta", c_p), ("running_mean", c_p), ("running_var", c_p),
+                ("num_batches_tracked", c_p), ("coef", c_p), ("dgamma", c_p), ("dbeta", c_p)]
+
+
+class StemArgs(C.Structure):
+    _fields_ = [("dtype", c_i), ("training", c_i), ("B", c_i), ("Cin", c_i), ("C0", c_i), ("S", c_ll),
+                ("eps", c_f), ("momentum", c_f), ("x", c_p), ("w", c_p), ("bn", BN), ("y0", c_p), ("out", c_p),
+                ("dout", c_p), ("dw", c_p), ("ws", c_p), ("ws_bytes", c_sz)]
+
+
+class BlockArgs(C.Structure):
+    _fields_ = [("dtype", c_i), ("training", c_i),
+                ("B", c_i), ("T", c_i), ("Hin", c_i), ("Win", c_i), ("Hout", c_i), ("Wout", c_i), ("Cin", c_i),
+                ("Cmid", c_i), ("Cout", c_i), ("stride", c_i), ("ks", c_i), ("kt", c_i), ("se_r", c_i),
+                ("eps", c_f), ("momentum", c_f),
+                ("x", c_p), ("out", c_p), ("y1", c_p), ("y2", c_p), ("y3", c_p), ("y4", c_p),
+                ("pe_t", c_p), ("pe_h", c_p), ("pe_w", c_p),
+                ("w_pw", c_p), ("w_dws", c_p), ("w_dwt", c_p), ("w_pwl", c_p), ("se_wr", c_p), ("se_br", c_p),
+                ("se_we", c_p), ("se_be", c_p),
+                ("bn1", BN), ("bn2", BN), ("bn3", BN), ("bn4", BN), ("bnsc", BN),
+                ("drop_scale", c_p), ("hsrc", c_p), ("wsrc", c_p), ("hinv", c_p), ("winv", c_p),
+                ("se_pmean", c_p), ("se_hidpre", c_p), ("se_gate", c_p),
+                ("dout", c_p), ("dx", c_p), ("buf_a", c_p), ("buf_b", c_p), ("dy4", c_p), ("da0", c_p),
+                ("dw_pw", c_p), ("dw_dws", c_p), ("dw_dwt", c_p), ("dw_pwl", c_p), ("dse_wr", c_p),
+                ("dse_br", c_p), ("dse_we", c_p), ("dse_be", c_p),
+                ("ws", c_p), ("ws_bytes", c_sz)]
+
+
+class PoolArgs(C.Structure):
+    _fields_ = [("dtype", c_i), ("BT", c_ll), ("HW", c_i), ("C", c_i), ("x", c_p), ("out", c_p), ("dout", c_p),
+                ("dx", c_p)]
+
+
+class CortexArgs(C.Structure):
+    _fields_ = [("dtype", c_i), ("training", c_i), ("B", c_i), ("T", c_i), ("Cin", c_i), ("C", c_i),
+                ("groups", c_i), ("eps", c_f), ("momentum", c_f), ("x", c_p), ("out", c_p), ("y", c_p),
+                ("w", c_p), ("bn", BN), ("bnsc", BN), ("drop_scale", c_p), ("dout", c_p), ("dx", c_p),
+                ("dw", c_p), ("dout_mask", c_p), ("dout_mask_ld", c_i), ("ws", c_p), ("ws_bytes", c_sz)]
+
+
+class ReadoutArgs(C.Structure):
+    _fields_ = [("dtype", c_i), ("B", c_i), ("T", c_i), ("Cin", c_i), ("groups", c_i), ("n_out", c_i),
+                ("softplus_beta", c_f), ("x", c_p), ("w", c_p), ("bias", c_p), ("drop_mask", c_p), ("out", c_p),
+                ("dout", c_p), ("dx", c_p), ("dw", c_p), ("dbias", c_p), ("ws", c_p), ("ws_bytes", c_sz)]
+
+
+class TensorEntry(C.Structure):
+    _fields_ = [("param", c_p), ("grad", c_p), ("exp_avg", c_p), ("exp_avg_sq", c_p), ("ema", c_p),
+                ("numel", c_ll), ("is_int64", c_i), ("pad_", c_i)]
+
+
+_STRUCTS = {
+    "dwn_load_desc": LoadDesc, "dwn_gemm_nn_args": GemmNNArgs, "dwn_gemm_tn_args": GemmTNArgs,
+    "dwn_dw_spatial_fwd_args": DwSpatialFwdArgs, "dwn_dw_spatial_bwd_args": DwSpatialBwdArgs,
+    "dwn_dw_temporal_fwd_args": DwTemporalFwdArgs, "dwn_dw_temporal_bwd_args": DwTemporalBwdArgs,
+    "dwn_bn": BN, "dwn_stem_args": StemArgs, "dwn_block_args": BlockArgs, "dwn_pool_args": PoolArgs,
+    "dwn_cortex_args": CortexArgs, "dwn_readout_args": ReadoutArgs, "dwn_tensor_entry": TensorEntry,
+}
+
+# every symbol include/dwn.h declares: (restype, argtypes)
+_P = C.POINTER
+SYMBOLS = {
+    "dwn_abi_version": (c_i, []),
+    "dwn_sizeof": (c_i, [C.c_char_p]),
+    "dwn_last_error": (C.c_char_p, []),
+    "dwn_gemm_nn": (c_i, [_P(GemmNNArgs), c_i, c_i, c_p]),
+    "dwn_gemm_tn": (c_i, [_P(GemmTNArgs), c_i, c_i, c_p]),
+    "dwn_dw_spatial_fwd": (c_i, [_P(DwSpatialFwdArgs), c_i, c_i, c_p]),
+    "dwn_dw_spatial_bwd": (c_i, [_P(DwSpatialBwdArgs), c_i, c_i, c_p]),
+    "dwn_dw_temporal_fwd": (c_i, [_P(DwTemporalFwdArgs), c_i, c_i, c_p]),
+    "dwn_dw_temporal_bwd": (c_i, [_P(DwTemporalBwdArgs), c_i, c_i, c_p]),
+    "dwn_bn_finalize": (c_i, [c_p, c_i, c_d, _P(BN), c_i, c_i, c_f, c_f, c_i, c_p]),
+    "dwn_bn_bwd_finalize": (c_i, [c_p, c_d, _P(BN), c_p, c_i, c_i, c_p]),
+    "dwn_pack_weight": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dwn_stem_workspace_bytes": (c_sz, [_P(StemArgs)]),
+    "dwn_stem_forward": (c_i, [_P(StemArgs), c_i, c_p]),
+    "dwn_stem_backward": (c_i, [_P(StemArgs), c_i, c_p]),
+    "dwn_block_workspace_bytes": (c_sz, [_P(BlockArgs), c_i]),
+    "dwn_block_forward": (c_i, [_P(BlockArgs), c_i, c_p]),
+    "dwn_block_backward": (c_i, [_P(BlockArgs), c_i, c_p]),
+    "dwn_pool_forward": (c_i, [_P(PoolArgs), c_i, c_p]),
+    "dwn_pool_backward": (c_i, [_P(PoolArgs), c_i, c_p]),
+    "dwn_cortex_workspace_bytes": (c_sz, [_P(CortexArgs), c_i]),
+    "dwn_cortex_forward": (c_i, [_P(CortexArgs), c_i, c_p]),
+    "dwn_cortex_backward": (c_i, [_P(CortexArgs), c_i, c_p]),
+    "dwn_readout_workspace_bytes": (c_sz, [_P(ReadoutArgs), c_i]),
+    "dwn_readout_forward": (c_i, [_P(ReadoutArgs), c_i, c_p]),
+    "dwn_readout_backward": (c_i, [_P(ReadoutArgs), c_i, c_p]),
+    "dwn_poisson_loss_forward": (c_i, [c_p, c_p, c_p, c_ll, c_ll, c_f, c_p, c_i, c_p]),
+    "dwn_poisson_loss_backward": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_ll, c_f, c_p, c_i, c_p]),
+    "dwn_f64_to_f32": (c_i, [c_p, c_p, c_i, c_i, c_p]),
+    "dwn_adamw_ema_multi": (c_i, [c_p, c_i, c_i, c_d, c_d, c_d, c_d, c_d, c_ll, c_d, c_d, c_i, c_p]),
+    "dwn_ema_lerp_multi": (c_i, [c_p, c_i, c_i, c_d, c_i, c_p]),
+}
+
+
+class DwnError(RuntimeError):
+    pass
+
+
+def _load():
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C {LIB_PATH.parent}`).  sensorium_amd has no fallback path.")
+    lib = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.dwn_abi_version() != 1:
+        raise ImportError("libdwiseneuro_hip.so ABI version mismatch")
+    for cname, struct in _STRUCTS.items():
+        n = lib.dwn_sizeof(cname.encode())
+        if n != C.sizeof(struct):
+            raise ImportError(f"struct layout mismatch for {cname}: C {n} bytes vs ctypes {C.sizeof(struct)}")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib.dwn_last_error()
+        raise DwnError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

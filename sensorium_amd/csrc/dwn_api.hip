@@ -1,0 +1,582 @@
+// C-ABI layer of libdwiseneuro_hip.so (declarations and contracts: include/dwn.h).
+// Composites chain the fused kernels of one reference module; they enqueue on the caller's stream only,
+// never allocate, never synchronise (hipGraph-capturable), and carve all scratch from the caller's workspace.
+#include "dwn_internal.h"
+#include "dwn_kernels.h"
+#include <string.h>
+#include <math.h>
+
+static thread_local char g_err[512] = "";
+
+int dwn_set_error(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "dwn error %d: %s", code, msg ? msg : "");
+    return code;
+}
+
+#define TRY(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
+#define HIP_TRY(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return dwn_set_error((int)e__, hipGetErrorString(e__)); } while (0)
+#define ENTER(device) do { g_err[0] = 0; HIP_TRY(hipSetDevice(device)); } while (0)
+
+namespace {
+
+struct Carver {
+    char* base; size_t off; size_t cap;
+    explicit Carver(void* b, size_t c) : base((char*)b), off(0), cap(c) {}
+    template <class U> U* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        U* p = base ? (U*)(base + off) : (U*)nullptr;
+        off += n * sizeof(U);
+        return p;
+    }
+    bool ok() const { return base == nullptr || off <= cap; }
+};
+
+inline size_t tsize(int dtype) { return dtype == DWN_BF16 ? 2 : 4; }
+inline size_t nstat(int C) { return (size_t)DWN_NREP * 2 * C; }
+
+LoadDesc ld_plain(const void* p, i64 ld) {
+    LoadDesc d; memset(&d, 0, sizeof(d));
+    d.p = p; d.ld = ld;
+    return d;
+}
+LoadDesc ld_bnact(const void* p, i64 ld, const float* coef, int C, int act, const float* gate, int gate_ld,
+                  int rows_per_sample) {
+    LoadDesc d = ld_plain(p, ld);
+    d.v1 = coef; d.v2 = coef + C; d.act = act; d.gate = gate; d.gate_ld = gate_ld;
+    d.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
+    return d;
+}
+LoadDesc ld_affine2(const void* p, const void* q, i64 ld, const float* abc, int C) {
+    LoadDesc d = ld_plain(p, ld);
+    d.q = q; d.v1 = abc; d.v2 = abc + C; d.v3 = abc + 2 * C;
+    return d;
+}
+LoadDesc ld_pe(const void* p, i64 ld, const float* pe_t, const float* pe_h, const float* pe_w, int T, int H, int W) {
+    LoadDesc d = ld_plain(p, ld);
+    d.pe_t = pe_t; d.pe_h = pe_h; d.pe_w = pe_w; d.pT = T; d.pH = H; d.pW = W; d.pe_ld = (int)ld;
+    return d;
+}
+// p = raw y; v1..v4 = scale, shift, mean, invstd (used by the dw backward kernels)
+LoadDesc ld_ycoef(const void* y, i64 ld, const float* coef, int C) {
+    LoadDesc d = ld_plain(y, ld);
+    d.v1 = coef; d.v2 = coef + C; d.v3 = coef + 2 * C; d.v4 = coef + 3 * C;
+    return d;
+}
+
+int bn_finalize(const double* stats, int stat_c, double count, const dwn_bn& bn, int C, int training, float momentum,
+                float eps, hipStream_t s) {
+    if (training)
+        return k_bn_finalize_train(stats, stat_c, count, bn.gamma, bn.beta, bn.running_mean, bn.running_var,
+                                   bn.num_batches_tracked, momentum, eps, bn.coef, C, s);
+    return k_bn_finalize_eval(bn.gamma, bn.beta, bn.running_mean, bn.running_var, eps, bn.coef, C, s);
+}
+
+GemmNN nn_base(const LoadDesc& a, int a_kind, const void* b, i64 ldb, void* c, i64 ldc, int M, int N, int K, int groups) {
+    GemmNN g; memset(&g, 0, sizeof(g));
+    g.a = a; g.a_kind = a_kind; g.b = b; g.ldb = ldb; g.c = c; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.groups = groups; g.epi = EPI_STORE;
+    return g;
+}
+GemmTN tn_base(const LoadDesc& p, int pk, const LoadDesc& q, int qk, int M, int R, int Cc, float* dw, i64 lddw, int groups) {
+    GemmTN g; memset(&g, 0, sizeof(g));
+    g.p = p; g.p_kind = pk; g.q = q; g.q_kind = qk; g.M = M; g.R = R; g.Cc = Cc; g.dw = dw; g.lddw = lddw;
+    g.groups = groups; g.nsplit = 0;
+    return g;
+}
+
+// ---------------------------------------------------------------- block workspace layout
+struct BlockWs {
+    void *wpw, *wpwl;            // forward: W1 [Cmid][Cin], W2 [Cout][Cmid] in T; backward: W1^T [Cin][Cmid], W2^T [Cmid][Cout]
+    float *wdws, *wdwt;          // tap-major depth-wise weights
+    double *st1, *st2, *st3, *st4, *stsc;
+    float* pooled;               // forward: SE pooled sums; backward: dg
+    float *abc1, *abc2, *abc3, *abc4, *abcsc, *ident3;
+    float *dgp, *dhp, *dps;
+    char* zero_beg; char* zero_end;
+    size_t bytes;
+};
+BlockWs carve_block(const dwn_block_args& a, int backward, void* base, size_t cap) {
+    BlockWs w; memset(&w, 0, sizeof(w));
+    Carver c(base, cap);
+    const size_t ts = tsize(a.dtype);
+    w.wpw = c.take<char>((size_t)a.Cmid * a.Cin * ts);
+    w.wpwl = c.take<char>((size_t)a.Cout * a.Cmid * ts);
+    w.wdws = c.take<float>((size_t)a.ks * a.ks * a.Cmid);
+    w.wdwt = c.take<float>((size_t)a.kt * a.Cmid);
+    c.take<char>(0);
+    size_t z0 = (c.off + 255) & ~(size_t)255;
+    w.st1 = c.take<double>(nstat(a.Cmid));
+    w.st2 = c.take<double>(nstat(a.Cmid));
+    w.st3 = c.take<double>(nstat(a.Cmid));
+    w.st4 = c.take<double>(nstat(a.Cout));
+    w.stsc = c.take<double>(nstat(backward ? a.Cout : a.Cin));
+    w.pooled = c.take<float>((size_t)a.B * a.Cmid);
+    size_t z1 = c.off;
+    if (backward) {
+        w.abc1 = c.take<float>(3 * (size_t)a.Cmid);
+        w.abc2 = c.take<float>(3 * (size_t)a.Cmid);
+        w.abc3 = c.take<float>(3 * (size_t)a.Cmid);
+        w.abc4 = c.take<float>(3 * (size_t)a.Cout);
+        w.abcsc = c.take<float>(3 * (size_t)a.Cout);
+        w.ident3 = c.take<float>(3 * (size_t)a.Cmid);
+        w.dgp = c.take<float>((size_t)a.B * a.Cmid);
+        w.dhp = c.take<float>((size_t)a.B * a.se_r);
+        w.dps = c.take<float>((size_t)a.B * a.Cmid);
+    }
+    w.bytes = c.off + 256;
+    if (base) { w.zero_beg = (char*)base + z0; w.zero_end = (char*)base + z1; }
+    return w;
+}
+
+ResGeom geom_of(const dwn_block_args& a) {
+    ResGeom gm;
+    gm.BT = a.B * a.T; gm.T = a.T; gm.Hin = a.Hin; gm.Win = a.Win; gm.Hout = a.Hout; gm.Wout = a.Wout;
+    gm.Cin = a.Cin; gm.Cout = a.Cout; gm.hsrc = a.hsrc; gm.wsrc = a.wsrc; gm.hinv = a.hinv; gm.winv = a.winv;
+    return gm;
+}
+
+int check_block(const dwn_block_args& a) {
+    if (a.Cin % 8 || a.Cmid % 8 || a.Cout % 8) return dwn_set_error(-2, "block: channel counts must be multiples of 8");
+    if (a.ks != 3) return dwn_set_error(-4, "block: spatial_kernel must be 3");
+    if (a.kt != 3 && a.kt != 5) return dwn_set_error(-4, "block: temporal_kernel must be 3 or 5");
+    if (a.Hout != (a.Hin - 1) / a.stride + 1 || a.Wout != (a.Win - 1) / a.stride + 1)
+        return dwn_set_error(-2, "block: Hout/Wout inconsistent with stride");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dwn_abi_version(void) { return DWN_ABI_VERSION; }
+int dwn_sizeof(const char* name) {
+#define SZ(T) if (strcmp(name, #T) == 0) return (int)sizeof(T)
+    SZ(dwn_load_desc); SZ(dwn_gemm_nn_args); SZ(dwn_gemm_tn_args); SZ(dwn_dw_spatial_fwd_args);
+    SZ(dwn_dw_spatial_bwd_args); SZ(dwn_dw_temporal_fwd_args); SZ(dwn_dw_temporal_bwd_args); SZ(dwn_bn);
+    SZ(dwn_stem_args); SZ(dwn_block_args); SZ(dwn_pool_args); SZ(dwn_cortex_args); SZ(dwn_readout_args);
+    SZ(dwn_tensor_entry);
+#undef SZ
+    return -1;
+}
+const char* dwn_last_error(void) { return g_err; }
+
+int dwn_gemm_nn(const dwn_gemm_nn_args* a, int dtype, int device, void* stream) {
+    ENTER(device);
+    return launch_gemm_nn(*a, dtype, (hipStream_t)stream);
+}
+int dwn_gemm_tn(const dwn_gemm_tn_args* a, int dtype, int device, void* stream) {
+    ENTER(device);
+    return launch_gemm_tn(*a, dtype, (hipStream_t)stream);
+}
+int dwn_dw_spatial_fwd(const dwn_dw_spatial_fwd_args* a, int dtype, int device, void* stream) {
+    ENTER(device);
+    return launch_dw_spatial_fwd(*a, dtype, (hipStream_t)stream);
+}
+int dwn_dw_spatial_bwd(const dwn_dw_spatial_bwd_args* a, int dtype, int device, void* stream) {
+    ENTER(device);
+    return launch_dw_spatial_bwd(*a, dtype, (hipStream_t)stream);
+}
+int dwn_dw_temporal_fwd(const dwn_dw_temporal_fwd_args* a, int dtype, int device, void* stream) {
+    ENTER(device);
+    return launch_dw_temporal_fwd(*a, dtype, (hipStream_t)stream);
+}
+int dwn_dw_temporal_bwd(const dwn_dw_temporal_bwd_args* a, int dtype, int device, void* stream) {
+    ENTER(device);
+    return launch_dw_temporal_bwd(*a, dtype, (hipStream_t)stream);
+}
+int dwn_bn_finalize(const double* stats, int stat_c, double count, const dwn_bn* bn, int C, int training,
+                    float momentum, float eps, int device, void* stream) {
+    ENTER(device);
+    return bn_finalize(stats, stat_c, count, *bn, C, training, momentum, eps, (hipStream_t)stream);
+}
+int dwn_bn_bwd_finalize(const double* stats, double count, const dwn_bn* bn, float* abc, int C, int device,
+                        void* stream) {
+    ENTER(device);
+    return k_bn_bwd_finalize(stats, count, bn->coef, bn->dgamma, bn->dbeta, abc, C, (hipStream_t)stream);
+}
+int dwn_pack_weight(const float* src, void* dst, int groups, int R, int C, int transpose, int Rd, int Cd, int dtype,
+                    int device, void* stream) {
+    ENTER(device);
+    return k_pack_weight(src, dst, groups, R, C, transpose, Rd, Cd, dtype, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ stem
+size_t dwn_stem_workspace_bytes(const dwn_stem_args* a) {
+    return (nstat(a->C0) * sizeof(double) + 3 * (size_t)a->C0 * sizeof(float) + 1024);
+}
+int dwn_stem_forward(const dwn_stem_args* a, int device, void* stream) {
+    ENTER(device);
+    hipStream_t s = (hipStream_t)stream;
+    if (a->C0 % 8) return dwn_set_error(-2, "stem: C0 must be a multiple of 8");
+    Carver c(a->ws, a->ws_bytes);
+    double* st = c.take<double>(nstat(a->C0));
+    if (!c.ok()) return dwn_set_error(-6, "stem: workspace too small");
+    const i64 M = (i64)a->B * a->S;
+    if (a->training) HIP_TRY(hipMemsetAsync(st, 0, nstat(a->C0) * sizeof(double), s));
+    TRY(k_stem_fwd(a->x, a->w, a->y0, a->B, a->Cin, a->S, a->C0, a->training ? st : nullptr, a->dtype, s));
+    TRY(bn_finalize(st, a->C0, (double)M, a->bn, a->C0, a->training, a->momentum, a->eps, s));
+    LoadDesc d = ld_bnact(a->y0, a->C0, a->bn.coef, a->C0, 0, nullptr, 0, 1);
+    return k_ew_apply(d, LD_BNACT, a->out, a->C0, M, a->C0, a->dtype, s);
+}
+int dwn_stem_backward(const dwn_stem_args* a, int device, void* stream) {
+    ENTER(device);
+    hipStream_t s = (hipStream_t)stream;
+    Carver c(a->ws, a->ws_bytes);
+    double* st = c.take<double>(nstat(a->C0));
+    float* abc = c.take<float>(3 * (size_t)a->C0);
+    if (!c.ok()) return dwn_set_error(-6, "stem: workspace too small");
+    const i64 M = (i64)a->B * a->S;
+    HIP_TRY(hipMemsetAsync(st, 0, nstat(a->C0) * sizeof(double), s));
+    TRY(k_bn_bwd_reduce_plain(a->dout, a->y0, a->bn.coef, M, a->C0, st, a->dtype, s));
+    TRY(k_bn_bwd_finalize(st, (double)M, a->bn.coef, a->bn.dgamma, a->bn.dbeta, abc, a->C0, s));
+    LoadDesc dy = ld_affine2(a->dout, a->y0, a->C0, abc, a->C0);
+    return k_stem_bwd(dy, a->x, a->dw, a->B, a->Cin, a->S, a->C0, a->dtype, s);
+}
+
+// ------------------------------------------------------------------------------------------------ block
+size_t dwn_block_workspace_bytes(const dwn_block_args* a, int backward) {
+    return carve_block(*a, backward, nullptr, 0).bytes;
+}
+
+int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
+    ENTER(device);
+    const dwn_block_args& a = *ap;
+    hipStream_t s = (hipStream_t)stream;
+    TRY(check_block(a));
+    BlockWs w = carve_block(a, 0, a.ws, a.ws_bytes);
+    if (w.bytes > a.ws_bytes) return dwn_set_error(-6, "block_forward: workspace too small");
+    const int dt = a.dtype, tr = a.training;
+    const i64 Min = (i64)a.B * a.T * a.Hin * a.Win, Mout = (i64)a.B * a.T * a.Hout * a.Wout;
+    const int S_out = a.T * a.Hout * a.Wout;
+    HIP_TRY(hipMemsetAsync(w.zero_beg, 0, (size_t)(w.zero_end - w.zero_beg), s));
+    TRY(k_pack_weight(a.w_pw, w.wpw, 1, a.Cmid, a.Cin, 0, a.Cmid, a.Cin, dt, s));
+    TRY(k_pack_weight(a.w_pwl, w.wpwl, 1, a.Cout, a.Cmid, 0, a.Cout, a.Cmid, dt, s));
+    TRY(k_pack_dw(a.w_dws, w.wdws, a.Cmid, a.ks * a.ks, s));
+    TRY(k_pack_dw(a.w_dwt, w.wdwt, a.Cmid, a.kt, s));
+
+    // conv_pw (dwiseneuro.py:90-93): y1 = (x + PE) @ W1^T, Σ/Σ² for bn1
+    LoadDesc xin = ld_pe(a.x, a.Cin, a.pe_t, a.pe_h, a.pe_w, a.T, a.Hin, a.Win);
+    {
+        GemmNN g = nn_base(xin, LD_PE, w.wpw, a.Cin, a.y1, a.Cmid, (int)Min, a.Cmid, a.Cin, 1);
+        g.stats = tr ? w.st1 : nullptr; g.stat_nchan = a.Cmid;
+        TRY(launch_gemm_nn(g, dt, s));
+    }
+    TRY(bn_finalize(w.st1, a.Cmid, (double)Min, a.bn1, a.Cmid, tr, a.momentum, a.eps, s));
+    // spat_covn_dw (:96-102)
+    {
+        DwSpatialFwd d; memset(&d, 0, sizeof(d));
+        d.in = ld_bnact(a.y1, a.Cmid, a.bn1.coef, a.Cmid, 1, nullptr, 0, 1);
+        d.w = w.wdws; d.out = a.y2; d.planes = a.B * a.T; d.Hin = a.Hin; d.Win = a.Win; d.Hout = a.Hout;
+        d.Wout = a.Wout; d.C = a.Cmid; d.stride = a.stride; d.ks = a.ks; d.stats = tr ? w.st2 : nullptr;
+        TRY(launch_dw_spatial_fwd(d, dt, s));
+    }
+    TRY(bn_finalize(w.st2, a.Cmid, (double)Mout, a.bn2, a.Cmid, tr, a.momentum, a.eps, s));
+    // temp_covn_dw (:105-111)
+    {
+        DwTemporalFwd d; memset(&d, 0, sizeof(d));
+        d.in = ld_bnact(a.y2, a.Cmid, a.bn2.coef, a.Cmid, 1, nullptr, 0, 1);
+        d.w = w.wdwt; d.out = a.y3; d.B = a.B; d.T = a.T; d.HW = a.Hout * a.Wout; d.C = a.Cmid; d.kt = a.kt;
+        d.stats = tr ? w.st3 : nullptr;
+        TRY(launch_dw_temporal_fwd(d, dt, s));
+    }
+    TRY(bn_finalize(w.st3, a.Cmid, (double)Mout, a.bn3, a.Cmid, tr, a.momentum, a.eps, s));
+    // se (:38-43)
+    LoadDesc z3 = ld_bnact(a.y3, a.Cmid, a.bn3.coef, a.Cmid, 1, nullptr, 0, S_out);
+    TRY(k_se_pool(z3, a.B, a.Cmid, S_out, w.pooled, dt, s));
+    TRY(k_se_mlp_fwd(w.pooled, 1.0f / (float)S_out, a.se_wr, a.se_br, a.se_we, a.se_be, a.B, a.Cmid, a.se_r,
+                     a.se_pmean, a.se_hidpre, a.se_gate, s));
+    // conv_pwl (:117-120): y4 = (silu(bn3(y3)) * gate) @ W2^T
+    {
+        LoadDesc u = ld_bnact(a.y3, a.Cmid, a.bn3.coef, a.Cmid, 1, a.se_gate, a.Cmid, S_out);
+        GemmNN g = nn_base(u, LD_BNACT, w.wpwl, a.Cmid, a.y4, a.Cout, (int)Mout, a.Cout, a.Cmid, 1);
+        g.stats = tr ? w.st4 : nullptr; g.stat_nchan = a.Cout;
+        TRY(launch_gemm_nn(g, dt, s));
+    }
+    TRY(bn_finalize(w.st4, a.Cout, (double)Mout, a.bn4, a.Cout, tr, a.momentum, a.eps, s));
+    // shortcut (:125-134) + residual (:143)
+    ResGeom gm = geom_of(a);
+    if (tr) TRY(k_shortcut_stats(xin, gm, w.stsc, dt, s));
+    TRY(bn_finalize(w.stsc, a.Cin, (double)Mout, a.bnsc, a.Cout, tr, a.momentum, a.eps, s));
+    return k_residual_fwd(xin, a.y4, a.bn4.coef, a.bnsc.coef, a.drop_scale, gm, a.out, dt, s);
+}
+
+int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
+    ENTER(device);
+    const dwn_block_args& a = *ap;
+    hipStream_t s = (hipStream_t)stream;
+    TRY(check_block(a));
+    if (!a.training) return dwn_set_error(-7, "block_backward: only training-mode (batch-statistics) backward is built");
+    BlockWs w = carve_block(a, 1, a.ws, a.ws_bytes);
+    if (w.bytes > a.ws_bytes) return dwn_set_error(-6, "block_backward: workspace too small");
+    const int dt = a.dtype;
+    const i64 Min = (i64)a.B * a.T * a.Hin * a.Win, Mout = (i64)a.B * a.T * a.Hout * a.Wout;
+    const int S_out = a.T * a.Hout * a.Wout;
+    float* dg = w.pooled;
+    HIP_TRY(hipMemsetAsync(w.zero_beg, 0, (size_t)(w.zero_end - w.zero_beg), s));
+    TRY(k_pack_weight(a.w_pw, w.wpw, 1, a.Cmid, a.Cin, 1, a.Cin, a.Cmid, dt, s));      // W1^T [Cin][Cmid]
+    TRY(k_pack_weight(a.w_pwl, w.wpwl, 1, a.Cout, a.Cmid, 1, a.Cmid, a.Cout, dt, s));  // W2^T [Cmid][Cout]
+    TRY(k_pack_dw(a.w_dws, w.wdws, a.Cmid, a.ks * a.ks, s));
+    TRY(k_pack_dw(a.w_dwt, w.wdwt, a.Cmid, a.kt, s));
+    TRY(k_fill_f32(w.ident3, 1.0f, a.Cmid, s));
+    HIP_TRY(hipMemsetAsync(w.ident3 + a.Cmid, 0, 2 * (size_t)a.Cmid * sizeof(float), s));
+
+    LoadDesc xin = ld_pe(a.x, a.Cin, a.pe_t, a.pe_h, a.pe_w, a.T, a.Hin, a.Win);
+    ResGeom gm = geom_of(a);
+    // residual + the two linear BNs (bn4 = conv_pwl.1.bn, bnsc = bn_sc.bn)
+    TRY(k_residual_bwd_reduce(xin, a.y4, a.dout, a.bn4.coef, a.bnsc.coef, a.drop_scale, gm, w.st4, w.stsc, dt, s));
+    TRY(k_bn_bwd_finalize(w.st4, (double)Mout, a.bn4.coef, a.bn4.dgamma, a.bn4.dbeta, w.abc4, a.Cout, s));
+    TRY(k_bn_bwd_finalize(w.stsc, (double)Mout, a.bnsc.coef, a.bnsc.dgamma, a.bnsc.dbeta, w.abcsc, a.Cout, s));
+    TRY(k_residual_bwd_dy4(a.y4, a.dout, w.abc4, a.drop_scale, gm, a.dy4, dt, s));
+    // conv_pwl backward: du = dy4 @ W2 (+ SE gate gradient), dW2 = dy4^T @ u
+    void* du = a.buf_a;
+    {
+        GemmNN g = nn_base(ld_plain(a.dy4, a.Cout), LD_PLAIN, w.wpwl, a.Cout, du, a.Cmid, (int)Mout, a.Cmid, a.Cout, 1);
+        g.epi = EPI_DG; g.y3 = a.y3; g.ldy3 = a.Cmid; g.s3 = a.bn3.coef; g.t3 = a.bn3.coef + a.Cmid; g.dg = dg;
+        g.dg_ld = a.Cmid; g.rows_per_sample = S_out;
+        TRY(launch_gemm_nn(g, dt, s));
+    }
+    {
+        LoadDesc u = ld_bnact(a.y3, a.Cmid, a.bn3.coef, a.Cmid, 1, a.se_gate, a.Cmid, S_out);
+        GemmTN g = tn_base(ld_plain(a.dy4, a.Cout), LD_PLAIN, u, LD_BNACT, (int)Mout, a.Cout, a.Cmid, a.dw_pwl, a.Cmid, 1);
+        TRY(launch_gemm_tn(g, dt, s));
+    }
+    // SE backward
+    TRY(k_se_mlp_bwd(dg, a.se_gate, a.se_hidpre, a.se_pmean, a.se_wr, a.se_we, a.B, a.Cmid, a.se_r,
+                     1.0f / (float)S_out, w.dgp, w.dhp, w.dps, a.dse_wr, a.dse_br, a.dse_we, a.dse_be, s));
+    // bn3 backward sums over dh3 = (du*gate + dpS) * silu'(h3)
+    LoadDesc d3; memset(&d3, 0, sizeof(d3));
+    d3.p = du; d3.q = a.y3; d3.ld = a.Cmid; d3.v1 = w.ident3; d3.v2 = w.ident3 + a.Cmid; d3.v3 = w.ident3 + 2 * a.Cmid;
+    d3.v4 = a.bn3.coef; d3.v5 = a.bn3.coef + a.Cmid; d3.gate = a.se_gate; d3.gate2 = w.dps; d3.gate_ld = a.Cmid;
+    d3.rows_per_sample = S_out;
+    TRY(k_bn3_bwd_reduce(d3, a.bn3.coef, Mout, a.Cmid, w.st3, dt, s));
+    TRY(k_bn_bwd_finalize(w.st3, (double)Mout, a.bn3.coef, a.bn3.dgamma, a.bn3.dbeta, w.abc3, a.Cmid, s));
+    // temporal dw backward
+    {
+        DwTemporalBwd d; memset(&d, 0, sizeof(d));
+        d.dy = d3; d.dy.v1 = w.abc3; d.dy.v2 = w.abc3 + a.Cmid; d.dy.v3 = w.abc3 + 2 * a.Cmid; d.dy_kind = LD_DY3;
+        d.y2 = ld_ycoef(a.y2, a.Cmid, a.bn2.coef, a.Cmid);
+        d.w = w.wdwt; d.dh2 = a.buf_b; d.dw = a.dw_dwt; d.B = a.B; d.T = a.T; d.HW = a.Hout * a.Wout; d.C = a.Cmid;
+        d.kt = a.kt; d.stats = w.st2;
+        TRY(launch_dw_temporal_bwd(d, dt, s));
+    }
+    TRY(k_bn_bwd_finalize(w.st2, (double)Mout, a.bn2.coef, a.bn2.dgamma, a.bn2.dbeta, w.abc2, a.Cmid, s));
+    // spatial dw backward (du is dead: reuse buf_a for dh1)
+    void* dh1 = a.buf_a;
+    {
+        DwSpatialBwd d; memset(&d, 0, sizeof(d));
+        d.dy = ld_affine2(a.buf_b, a.y2, a.Cmid, w.abc2, a.Cmid);
+        d.y1 = ld_ycoef(a.y1, a.Cmid, a.bn1.coef, a.Cmid);
+        d.w = w.wdws; d.dh1 = dh1; d.dw = a.dw_dws; d.planes = a.B * a.T; d.Hin = a.Hin; d.Win = a.Win;
+        d.Hout = a.Hout; d.Wout = a.Wout; d.C = a.Cmid; d.stride = a.stride; d.ks = a.ks; d.stats = w.st1;
+        TRY(launch_dw_spatial_bwd(d, dt, s));
+    }
+    TRY(k_bn_bwd_finalize(w.st1, (double)Min, a.bn1.coef, a.bn1.dgamma, a.bn1.dbeta, w.abc1, a.Cmid, s));
+    // conv_pw backward
+    LoadDesc dy1 = ld_affine2(dh1, a.y1, a.Cmid, w.abc1, a.Cmid);
+    {
+        GemmNN g = nn_base(dy1, LD_AFFINE2, w.wpw, a.Cmid, a.da0, a.Cin, (int)Min, a.Cin, a.Cmid, 1);
+        TRY(launch_gemm_nn(g, dt, s));
+    }
+    {
+        GemmTN g = tn_base(dy1, LD_AFFINE2, xin, LD_PE, (int)Min, a.Cmid, a.Cin, a.dw_pw, a.Cin, 1);
+        TRY(launch_gemm_tn(g, dt, s));
+    }
+    return k_residual_bwd_dx(xin, a.da0, a.dout, w.abcsc, gm, a.dx, dt, s);
+}
+
+// ------------------------------------------------------------------------------------------------ pool
+int dwn_pool_forward(const dwn_pool_args* a, int device, void* stream) {
+    ENTER(device);
+    if (a->C % 8) return dwn_set_error(-2, "pool: C must be a multiple of 8");
+    return k_pool_fwd(a->x, a->out, a->BT, a->HW, a->C, a->dtype, (hipStream_t)stream);
+}
+int dwn_pool_backward(const dwn_pool_args* a, int device, void* stream) {
+    ENTER(device);
+    return k_pool_bwd(a->dout, a->dx, a->BT, a->HW, a->C, a->dtype, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ cortex
+namespace {
+struct CortexWs { void* wp; double *st, *stsc; float *abc, *abcsc; void *dy, *dxmain; char *zb, *ze; size_t bytes; };
+CortexWs carve_cortex(const dwn_cortex_args& a, int backward, void* base, size_t cap) {
+    CortexWs w; memset(&w, 0, sizeof(w));
+    Carver c(base, cap);
+    const size_t ts = tsize(a.dtype);
+    const i64 M = (i64)a.B * a.T;
+    w.wp = c.take<char>((size_t)a.C * (a.Cin / a.groups) * ts);
+    c.take<char>(0);
+    size_t z0 = (c.off + 255) & ~(size_t)255;
+    w.st = c.take<double>(nstat(a.C));
+    w.stsc = c.take<double>(nstat(backward ? a.C : a.Cin));
+    size_t z1 = c.off;
+    if (backward) {
+        w.abc = c.take<float>(3 * (size_t)a.C);
+        w.abcsc = c.take<float>(3 * (size_t)a.C);
+        w.dy = c.take<char>((size_t)M * a.C * ts);
+        w.dxmain = c.take<char>((size_t)M * a.Cin * ts);
+    }
+    w.bytes = c.off + 256;
+    if (base) { w.zb = (char*)base + z0; w.ze = (char*)base + z1; }
+    return w;
+}
+}  // namespace
+
+size_t dwn_cortex_workspace_bytes(const dwn_cortex_args* a, int backward) {
+    return carve_cortex(*a, backward, nullptr, 0).bytes;
+}
+int dwn_cortex_forward(const dwn_cortex_args* ap, int device, void* stream) {
+    ENTER(device);
+    const dwn_cortex_args& a = *ap;
+    hipStream_t s = (hipStream_t)stream;
+    if (a.Cin % (8 * a.groups) || a.C % (8 * a.groups)) return dwn_set_error(-2, "cortex: channels per group must be multiples of 8");
+    CortexWs w = carve_cortex(a, 0, a.ws, a.ws_bytes);
+    if (w.bytes > a.ws_bytes) return dwn_set_error(-6, "cortex_forward: workspace too small");
+    const int M = a.B * a.T, Kg = a.Cin / a.groups, Ng = a.C / a.groups, dt = a.dtype, tr = a.training;
+    HIP_TRY(hipMemsetAsync(w.zb, 0, (size_t)(w.ze - w.zb), s));
+    TRY(k_pack_weight(a.w, w.wp, 1, a.C, Kg, 0, a.C, Kg, dt, s));
+    GemmNN g = nn_base(ld_plain(a.x, a.Cin), LD_PLAIN, w.wp, Kg, a.y, a.C, M, Ng, Kg, a.groups);
+    g.stats = tr ? w.st : nullptr; g.stat_nchan = a.C;
+    TRY(launch_gemm_nn(g, dt, s));
+    TRY(bn_finalize(w.st, a.C, (double)M, a.bn, a.C, tr, a.momentum, a.eps, s));
+    if (tr) TRY(k_colstats(ld_plain(a.x, a.Cin), LD_PLAIN, M, a.Cin, w.stsc, dt, s));
+    TRY(bn_finalize(w.stsc, a.Cin, (double)M, a.bnsc, a.C, tr, a.momentum, a.eps, s));
+    return k_cortex_residual_fwd(a.y, a.x, a.bn.coef, a.bnsc.coef, a.drop_scale, M, a.T, a.Cin, a.C, a.groups, a.out,
+                                 dt, s);
+}
+int dwn_cortex_backward(const dwn_cortex_args* ap, int device, void* stream) {
+    ENTER(device);
+    const dwn_cortex_args& a = *ap;
+    hipStream_t s = (hipStream_t)stream;
+    if (!a.training) return dwn_set_error(-7, "cortex_backward: only training-mode backward is built");
+    CortexWs w = carve_cortex(a, 1, a.ws, a.ws_bytes);
+    if (w.bytes > a.ws_bytes) return dwn_set_error(-6, "cortex_backward: workspace too small");
+    const int M = a.B * a.T, Kg = a.Cin / a.groups, Ng = a.C / a.groups, dt = a.dtype;
+    HIP_TRY(hipMemsetAsync(w.zb, 0, (size_t)(w.ze - w.zb), s));
+    TRY(k_pack_weight(a.w, w.wp, a.groups, Ng, Kg, 1, Kg, Ng, dt, s));     // per group W^T [Kg][Ng]
+    TRY(k_cortex_bwd_reduce(a.y, a.x, a.dout, a.dout_mask, a.dout_mask_ld, a.bn.coef, a.bnsc.coef, a.drop_scale, M, a.T,
+                            a.Cin, a.C, a.groups, w.st, w.stsc, dt, s));
+    TRY(k_bn_bwd_finalize(w.st, (double)M, a.bn.coef, a.bn.dgamma, a.bn.dbeta, w.abc, a.C, s));
+    TRY(k_bn_bwd_finalize(w.stsc, (double)M, a.bnsc.coef, a.bnsc.dgamma, a.bnsc.dbeta, w.abcsc, a.C, s));
+    TRY(k_cortex_bwd_dy(a.y, a.dout, a.dout_mask, a.dout_mask_ld, a.bn.coef, w.abc, a.drop_scale, M, a.T, a.C, a.groups,
+                        w.dy, dt, s));
+    {
+        GemmNN g = nn_base(ld_plain(w.dy, a.C), LD_PLAIN, w.wp, Ng, w.dxmain, a.Cin, M, Kg, Ng, a.groups);
+        TRY(launch_gemm_nn(g, dt, s));
+    }
+    {
+        GemmTN g = tn_base(ld_plain(w.dy, a.C), LD_PLAIN, ld_plain(a.x, a.Cin), LD_PLAIN, M, Ng, Kg, a.dw, Kg, a.groups);
+        TRY(launch_gemm_tn(g, dt, s));
+    }
+    return k_cortex_bwd_dx(w.dxmain, a.x, a.dout, a.dout_mask, a.dout_mask_ld, w.abcsc, M, a.T, a.Cin, a.C, a.dx, dt, s);
+}
+
+// ------------------------------------------------------------------------------------------------ readout
+namespace {
+struct ReadoutWs { void* wp; float* ones; float* zeros; void* dz; size_t bytes; int Npad, Rg, Rp; };
+ReadoutWs carve_readout(const dwn_readout_args& a, int backward, void* base, size_t cap) {
+    ReadoutWs w; memset(&w, 0, sizeof(w));
+    Carver c(base, cap);
+    const size_t ts = tsize(a.dtype);
+    const i64 M = (i64)a.B * a.T;
+    w.Npad = (a.n_out + a.groups - 1) / a.groups * a.groups;
+    w.Rg = w.Npad / a.groups;
+    w.Rp = (w.Rg + 7) / 8 * 8;
+    const int Kg = a.Cin / a.groups;
+    w.wp = c.take<char>(backward ? (size_t)a.groups * Kg * w.Rp * ts : (size_t)w.Npad * Kg * ts);
+    w.ones = c.take<float>(a.Cin);
+    w.zeros = c.take<float>(a.Cin);
+    if (backward) w.dz = c.take<char>((size_t)M * a.groups * w.Rp * ts);
+    w.bytes = c.off + 256;
+    return w;
+}
+}  // namespace
+
+size_t dwn_readout_workspace_bytes(const dwn_readout_args* a, int backward) {
+    return carve_readout(*a, backward, nullptr, 0).bytes;
+}
+int dwn_readout_forward(const dwn_readout_args* ap, int device, void* stream) {
+    ENTER(device);
+    const dwn_readout_args& a = *ap;
+    hipStream_t s = (hipStream_t)stream;
+    if (a.Cin % (8 * a.groups)) return dwn_set_error(-2, "readout: in-channels per group must be a multiple of 8");
+    ReadoutWs w = carve_readout(a, 0, a.ws, a.ws_bytes);
+    if (w.bytes > a.ws_bytes) return dwn_set_error(-6, "readout_forward: workspace too small");
+    const int M = a.B * a.T, Kg = a.Cin / a.groups, dt = a.dtype;
+    TRY(k_pack_weight(a.w, w.wp, 1, w.Npad, Kg, 0, w.Npad, Kg, dt, s));
+    LoadDesc x = ld_plain(a.x, a.Cin);
+    int kind = LD_PLAIN;
+    if (a.drop_mask) {
+        TRY(k_fill_f32(w.ones, 1.0f, a.Cin, s));
+        HIP_TRY(hipMemsetAsync(w.zeros, 0, (size_t)a.Cin * sizeof(float), s));
+        x.v1 = w.ones; x.v2 = w.zeros; x.act = 0; x.gate = a.drop_mask; x.gate_ld = a.Cin; x.rows_per_sample = a.T;
+        kind = LD_BNACT;
+    }
+    GemmNN g = nn_base(x, kind, w.wp, Kg, nullptr, 0, M, w.Rg, Kg, a.groups);
+    g.epi = EPI_READOUT; g.bias = a.bias; g.sp_beta = a.softplus_beta; g.out_nct = a.out; g.Tn = a.T; g.n_valid = a.n_out;
+    return launch_gemm_nn(g, dt, s);
+}
+int dwn_readout_backward(const dwn_readout_args* ap, int device, void* stream) {
+    ENTER(device);
+    const dwn_readout_args& a = *ap;
+    hipStream_t s = (hipStream_t)stream;
+    ReadoutWs w = carve_readout(a, 1, a.ws, a.ws_bytes);
+    if (w.bytes > a.ws_bytes) return dwn_set_error(-6, "readout_backward: workspace too small");
+    const int M = a.B * a.T, Kg = a.Cin / a.groups, dt = a.dtype;
+    TRY(k_pack_weight(a.w, w.wp, a.groups, w.Rg, Kg, 1, Kg, w.Rp, dt, s));   // per group W^T [Kg][Rp], zero padded
+    TRY(k_readout_dz(a.dout, a.out, a.softplus_beta, a.B, a.T, a.n_out, w.Rg, w.Rp, a.groups, w.dz, a.dbias, dt, s));
+    LoadDesc dz = ld_plain(w.dz, (i64)a.groups * w.Rp);
+    {
+        GemmNN g = nn_base(dz, LD_PLAIN, w.wp, w.Rp, a.dx, a.Cin, M, Kg, w.Rp, a.groups);
+        TRY(launch_gemm_nn(g, dt, s));
+    }
+    LoadDesc x = ld_plain(a.x, a.Cin);
+    int kind = LD_PLAIN;
+    if (a.drop_mask) {
+        TRY(k_fill_f32(w.ones, 1.0f, a.Cin, s));
+        HIP_TRY(hipMemsetAsync(w.zeros, 0, (size_t)a.Cin * sizeof(float), s));
+        x.v1 = w.ones; x.v2 = w.zeros; x.act = 0; x.gate = a.drop_mask; x.gate_ld = a.Cin; x.rows_per_sample = a.T;
+        kind = LD_BNACT;
+        // grad wrt the un-dropped input: dx *= mask (in place)
+        LoadDesc dxm = ld_plain(a.dx, a.Cin);
+        dxm.v1 = w.ones; dxm.v2 = w.zeros; dxm.act = 0; dxm.gate = a.drop_mask; dxm.gate_ld = a.Cin; dxm.rows_per_sample = a.T;
+        TRY(k_ew_apply(dxm, LD_BNACT, a.dx, a.Cin, M, a.Cin, dt, s));
+    }
+    GemmTN g = tn_base(dz, LD_PLAIN, x, kind, M, w.Rg, Kg, a.dw, Kg, a.groups);
+    g.R_load = w.Rp;
+    return launch_gemm_tn(g, dt, s);
+}
+
+// ------------------------------------------------------------------------------------------------ loss / optimizer
+int dwn_poisson_loss_forward(const float* pred, const float* target, const float* w, long long per_sample,
+                             long long total, float eps, double* loss_acc, int device, void* stream) {
+    ENTER(device);
+    return k_poisson_fwd(pred, target, w, per_sample, total, eps, loss_acc, (hipStream_t)stream);
+}
+int dwn_poisson_loss_backward(const float* pred, const float* target, const float* w, const float* gscale,
+                              long long per_sample, long long total, float eps, float* dpred, int device,
+                              void* stream) {
+    ENTER(device);
+    return k_poisson_bwd(pred, target, w, gscale, per_sample, total, eps, dpred, (hipStream_t)stream);
+}
+int dwn_f64_to_f32(const double* src, float* dst, int n, int device, void* stream) {
+    ENTER(device);
+    return k_f64_to_f32(src, dst, n, (hipStream_t)stream);
+}
+int dwn_adamw_ema_multi(const dwn_tensor_entry* list, int ntensors, int max_blocks, double lr, double beta1,
+                        double beta2, double eps, double weight_decay, long long step, double ema_decay,
+                        double grad_scale, int device, void* stream) {
+    ENTER(device);
+    if (step < 1) return dwn_set_error(-2, "adamw: step must be >= 1");
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    return k_adamw_ema(list, ntensors, max_blocks, (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)sqrt(bc2), (float)ema_decay,
+                       (float)(1.0 - ema_decay), (float)grad_scale, (hipStream_t)stream);
+}
+int dwn_ema_lerp_multi(const dwn_tensor_entry* list, int ntensors, int max_blocks, double decay, int device,
+                       void* stream) {
+    ENTER(device);
+    return k_ema_lerp(list, ntensors, max_blocks, (float)decay, (float)(1.0 - decay), (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,1137 @@
+// Memory-bound glue kernels: BatchNorm finalisation (forward / eval / backward coefficients), stem conv
+// (K = 5 is too thin for MFMA), shortcut gather + residual add (+DropPath), H×W pooling, Squeeze-Excite
+// pooling and MLP, cortex shuffle/residual, readout glue, Poisson loss, fused AdamW + EMA.
+// Reference call sites are cited per kernel (paths relative to lRomul/sensorium).
+#include "dwn_internal.h"
+#include "dwn_kernels.h"
+
+#define NCV 8
+
+// every "sliced" kernel: thread -> (cv = tid % 8, pl = tid / 8), channel slice = blockIdx.y
+#define SLICE_SETUP(Cval)                                   \
+    constexpr int KC = TT<T>::KC;                           \
+    const int tid = threadIdx.x;                            \
+    const int cv = tid % NCV, pl = tid / NCV;               \
+    const int c0 = blockIdx.y * NCV * KC;                   \
+    const int chan = c0 + cv * KC;                          \
+    const bool chan_ok = chan < (Cval);                     \
+    (void)pl; (void)chan_ok;
+
+template <int KC>
+__device__ __forceinline__ void slice_stats_flush(float* lstat, const float* s0, const float* s1, int cv,
+                                                 int c0, int C, double* stats, int rep) {
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+        atomicAdd(&lstat[cv * KC + i], s0[i]);
+        atomicAdd(&lstat[NCV * KC + cv * KC + i], s1[i]);
+    }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < 2 * NCV * KC) {
+        int which = tid / (NCV * KC), c = c0 + tid % (NCV * KC);
+        if (c < C) stat_add(stats, rep, C, which, c, lstat[tid]);
+    }
+}
+
+static inline dim3 slice_grid(i64 rows, int C, int KC, int cap = 2048) {
+    int slices = (C + NCV * KC - 1) / (NCV * KC);
+    i64 bx = (rows + 31) / 32;
+    int capx = (cap + slices - 1) / slices;
+    if (bx > capx) bx = capx;
+    if (bx < 1) bx = 1;
+    return dim3((unsigned)bx, (unsigned)slices);
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm finalisation (BatchNormAct, dwiseneuro.py:9-22; torch BatchNorm semantics)
+// coef layout: [4][C] = scale, shift, mean, invstd
+// ------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_train_kernel(const double* stats, int stat_c, double count, const float* gamma,
+                                         const float* beta, float* running_mean, float* running_var,
+                                         long long* nbt, float momentum, float eps, float* coef, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    int sc = c % stat_c;                     // shortcut BN: out channel c uses the stats of in channel c % C_in
+    double s = 0, ss = 0;
+    for (int r = 0; r < DWN_NREP; ++r) {
+        s += stats[((i64)r * 2 + 0) * stat_c + sc];
+        ss += stats[((i64)r * 2 + 1) * stat_c + sc];
+    }
+    double mean = s / count;
+    double var = ss / count - mean * mean;
+    if (var < 0) var = 0;
+    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    float scale = gamma[c] * invstd;
+    coef[c] = scale;
+    coef[C + c] = beta[c] - (float)mean * scale;
+    coef[2 * C + c] = (float)mean;
+    coef[3 * C + c] = invstd;
+    if (running_mean) {
+        double unbiased = count > 1 ? var * count / (count - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_finalize_eval_kernel(const float* gamma, const float* beta, const float* running_mean,
+                                        const float* running_var, float eps, float* coef, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float invstd = 1.0f / sqrtf(running_var[c] + eps);
+    float scale = gamma[c] * invstd;
+    coef[c] = scale;
+    coef[C + c] = beta[c] - running_mean[c] * scale;
+    coef[2 * C + c] = running_mean[c];
+    coef[3 * C + c] = invstd;
+}
+
+// backward: stats = [NREP][2][C] with Σdh and Σdh·ŷ.  dy = A1*dh + A2*y + A3 (y raw), dgamma = Σdh·ŷ, dbeta = Σdh
+__global__ void bn_bwd_finalize_kernel(const double* stats, double count, const float* coef, float* dgamma,
+                                       float* dbeta, float* abc, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0, s2 = 0;
+    for (int r = 0; r < DWN_NREP; ++r) {
+        s1 += stats[((i64)r * 2 + 0) * C + c];
+        s2 += stats[((i64)r * 2 + 1) * C + c];
+    }
+    float scale = coef[c], mean = coef[2 * C + c], invstd = coef[3 * C + c];
+    if (dgamma) dgamma[c] = (float)s2;
+    if (dbeta) dbeta[c] = (float)s1;
+    double m1 = s1 / count, m2 = s2 / count;
+    abc[c] = scale;
+    abc[C + c] = (float)(-(double)scale * invstd * m2);
+    abc[2 * C + c] = (float)((double)scale * (-m1 + (double)mean * invstd * m2));
+}
+
+int k_bn_finalize_train(const double* stats, int stat_c, double count, const float* gamma, const float* beta,
+                        float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef, int C,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, stat_c, count,
+                       gamma, beta, rm, rv, nbt, momentum, eps, coef, C);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_bn_finalize_eval(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                       float* coef, int C, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, s, gamma, beta, rm, rv, eps,
+                       coef, C);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_bn_bwd_finalize(const double* stats, double count, const float* coef, float* dgamma, float* dbeta,
+                      float* abc, int C, hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, count, coef, dgamma,
+                       dbeta, abc, C);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic "materialise a loader" and per-channel statistics of a loader
+// ------------------------------------------------------------------------------------------------
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void ew_apply_kernel(LoadDesc d, T* out, i64 ldo, i64 rows, int C) {
+    SLICE_SETUP(C)
+    if (!chan_ok) return;
+    for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
+        float v[KC];
+        load_op<KIND, T>(d, row, chan, v);
+        st_vec<T>(out + row * ldo + chan, v);
+    }
+}
+
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void colstats_kernel(LoadDesc d, i64 rows, int C, double* stats) {
+    SLICE_SETUP(C)
+    __shared__ float lstat[2 * NCV * KC];
+    if (tid < 2 * NCV * KC) lstat[tid] = 0.f;
+    __syncthreads();
+    float s0[KC], s1[KC];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+    if (chan_ok)
+        for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
+            float v[KC];
+            load_op<KIND, T>(d, row, chan, v);
+#pragma unroll
+            for (int i = 0; i < KC; ++i) { s0[i] += v[i]; s1[i] += v[i] * v[i]; }
+        }
+    slice_stats_flush<KC>(lstat, s0, s1, cv, c0, C, stats, blockIdx.x % DWN_NREP);
+}
+
+template <typename T>
+static int ew_apply_t(const LoadDesc& d, int kind, void* out, i64 ldo, i64 rows, int C, hipStream_t s) {
+    dim3 grid = slice_grid(rows, C, TT<T>::KC);
+    T* o = reinterpret_cast<T*>(out);
+    switch (kind) {
+        case LD_PLAIN: hipLaunchKernelGGL((ew_apply_kernel<T, LD_PLAIN>), grid, dim3(256), 0, s, d, o, ldo, rows, C); break;
+        case LD_PE: hipLaunchKernelGGL((ew_apply_kernel<T, LD_PE>), grid, dim3(256), 0, s, d, o, ldo, rows, C); break;
+        case LD_BNACT: hipLaunchKernelGGL((ew_apply_kernel<T, LD_BNACT>), grid, dim3(256), 0, s, d, o, ldo, rows, C); break;
+        case LD_AFFINE2: hipLaunchKernelGGL((ew_apply_kernel<T, LD_AFFINE2>), grid, dim3(256), 0, s, d, o, ldo, rows, C); break;
+        case LD_DY3: hipLaunchKernelGGL((ew_apply_kernel<T, LD_DY3>), grid, dim3(256), 0, s, d, o, ldo, rows, C); break;
+        default: return dwn_set_error(-3, "ew_apply: bad loader kind");
+    }
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_ew_apply(const LoadDesc& d, int kind, void* out, i64 ldo, i64 rows, int C, int dtype, hipStream_t s) {
+    return dtype == DWN_BF16 ? ew_apply_t<bf16_t>(d, kind, out, ldo, rows, C, s)
+                             : ew_apply_t<float>(d, kind, out, ldo, rows, C, s);
+}
+template <typename T>
+static int colstats_t(const LoadDesc& d, int kind, i64 rows, int C, double* stats, hipStream_t s) {
+    dim3 grid = slice_grid(rows, C, TT<T>::KC, 1024);
+    switch (kind) {
+        case LD_PLAIN: hipLaunchKernelGGL((colstats_kernel<T, LD_PLAIN>), grid, dim3(256), 0, s, d, rows, C, stats); break;
+        case LD_PE: hipLaunchKernelGGL((colstats_kernel<T, LD_PE>), grid, dim3(256), 0, s, d, rows, C, stats); break;
+        case LD_BNACT: hipLaunchKernelGGL((colstats_kernel<T, LD_BNACT>), grid, dim3(256), 0, s, d, rows, C, stats); break;
+        default: return dwn_set_error(-3, "colstats: bad loader kind");
+    }
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_colstats(const LoadDesc& d, int kind, i64 rows, int C, double* stats, int dtype, hipStream_t s) {
+    return dtype == DWN_BF16 ? colstats_t<bf16_t>(d, kind, rows, C, stats, s) : colstats_t<float>(d, kind, rows, C, stats, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stem: Conv3d(C_in -> C0, 1x1x1, no bias) on the NCDHW fp32 input (dwiseneuro.py:306), raw output + Σ/Σ²
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const float* w, T* y, int B, int Cin, i64 S,
+                                                       int C0, double* stats) {
+    SLICE_SETUP(C0)
+    __shared__ float lstat[2 * NCV * KC];
+    if (tid < 2 * NCV * KC) lstat[tid] = 0.f;
+    __syncthreads();
+    float s0[KC], s1[KC];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+    const i64 rows = (i64)B * S;
+    if (chan_ok)
+        for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
+            i64 b = row / S, sp = row % S;
+            float acc[KC];
+#pragma unroll
+            for (int i = 0; i < KC; ++i) acc[i] = 0.f;
+            for (int c = 0; c < Cin; ++c) {
+                float xv = x[(b * Cin + c) * S + sp];
+#pragma unroll
+                for (int i = 0; i < KC; ++i) acc[i] = fmaf(w[(chan + i) * Cin + c], xv, acc[i]);
+            }
+            st_vec<T>(y + row * C0 + chan, acc);
+#pragma unroll
+            for (int i = 0; i < KC; ++i) {
+                float r = round_t<T>(acc[i]);
+                s0[i] += r;
+                s1[i] += r * r;
+            }
+        }
+    if (stats) slice_stats_flush<KC>(lstat, s0, s1, cv, c0, C0, stats, blockIdx.x % DWN_NREP);
+}
+
+// stem backward: dW[o][c] = sum_rows dy0[row][o] * x[b][c][sp], dy0 through LD_AFFINE2(dx0, y0)
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bwd_kernel(LoadDesc dy, const float* x, float* dw, int B, int Cin, i64 S,
+                                                       int C0) {
+    SLICE_SETUP(C0)
+    constexpr int MAXCIN = 8;
+    __shared__ float lacc[MAXCIN * NCV * KC];
+    for (int i = tid; i < MAXCIN * NCV * KC; i += 256) lacc[i] = 0.f;
+    __syncthreads();
+    float acc[MAXCIN][KC];
+#pragma unroll
+    for (int c = 0; c < MAXCIN; ++c)
+#pragma unroll
+        for (int i = 0; i < KC; ++i) acc[c][i] = 0.f;
+    const i64 rows = (i64)B * S;
+    if (chan_ok)
+        for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
+            i64 b = row / S, sp = row % S;
+            float g[KC];
+            load_op<LD_AFFINE2, T>(dy, row, chan, g);
+#pragma unroll
+            for (int c = 0; c < MAXCIN; ++c) {
+                if (c < Cin) {
+                    float xv = x[(b * Cin + c) * S + sp];
+#pragma unroll
+                    for (int i = 0; i < KC; ++i) acc[c][i] = fmaf(g[i], xv, acc[c][i]);
+                }
+            }
+        }
+#pragma unroll
+    for (int c = 0; c < MAXCIN; ++c)
+#pragma unroll
+        for (int i = 0; i < KC; ++i) atomicAdd(&lacc[c * NCV * KC + cv * KC + i], acc[c][i]);
+    __syncthreads();
+    for (int i = tid; i < MAXCIN * NCV * KC; i += 256) {
+        int c = i / (NCV * KC), o = c0 + i % (NCV * KC);
+        if (c < Cin && o < C0) atomicAdd(dw + (i64)o * Cin + c, lacc[i]);
+    }
+}
+
+int k_stem_fwd(const float* x, const float* w, void* y, int B, int Cin, i64 S, int C0, double* stats, int dtype,
+               hipStream_t s) {
+    if (dtype == DWN_BF16) {
+        dim3 grid = slice_grid((i64)B * S, C0, 8);
+        hipLaunchKernelGGL((stem_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, x, w, (bf16_t*)y, B, Cin, S, C0, stats);
+    } else {
+        dim3 grid = slice_grid((i64)B * S, C0, 4);
+        hipLaunchKernelGGL((stem_fwd_kernel<float>), grid, dim3(256), 0, s, x, w, (float*)y, B, Cin, S, C0, stats);
+    }
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_stem_bwd(const LoadDesc& dy, const float* x, float* dw, int B, int Cin, i64 S, int C0, int dtype, hipStream_t s) {
+    if (Cin > 8) return dwn_set_error(-4, "stem: in_channels > 8 not built");
+    if (dtype == DWN_BF16) {
+        dim3 grid = slice_grid((i64)B * S, C0, 8, 1024);
+        hipLaunchKernelGGL((stem_bwd_kernel<bf16_t>), grid, dim3(256), 0, s, dy, x, dw, B, Cin, S, C0);
+    } else {
+        dim3 grid = slice_grid((i64)B * S, C0, 4, 1024);
+        hipLaunchKernelGGL((stem_bwd_kernel<float>), grid, dim3(256), 0, s, dy, x, dw, B, Cin, S, C0);
+    }
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// shortcut (interpolate_shortcut, dwiseneuro.py:125-134) + residual (:143)
+// geometry of one block's shortcut gather
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void shortcut_stats_kernel(LoadDesc xin, ResGeom gm, double* stats) {
+    // Σ, Σ² of (x + PE) at the gathered (nearest) positions, per *input* channel
+    SLICE_SETUP(gm.Cin)
+    __shared__ float lstat[2 * NCV * KC];
+    if (tid < 2 * NCV * KC) lstat[tid] = 0.f;
+    __syncthreads();
+    float s0[KC], s1[KC];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+    const i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
+    if (chan_ok)
+        for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
+            int wo = (int)(row % gm.Wout);
+            i64 r2 = row / gm.Wout;
+            int ho = (int)(r2 % gm.Hout);
+            i64 bt = r2 / gm.Hout;
+            i64 rin = (bt * gm.Hin + gm.hsrc[ho]) * gm.Win + gm.wsrc[wo];
+            float v[KC];
+            load_op<LD_PE, T>(xin, rin, chan, v);
+#pragma unroll
+            for (int i = 0; i < KC; ++i) { float r = round_t<T>(v[i]); s0[i] += r; s1[i] += r * r; }
+        }
+    slice_stats_flush<KC>(lstat, s0, s1, cv, c0, gm.Cin, stats, blockIdx.x % DWN_NREP);
+}
+
+// out[m_out][c'] = d[b] * (s4*y4 + t4) + ssc*s + tsc,  s = (x+PE)[m_in][c' % Cin]
+template <typename T>
+__global__ __launch_bounds__(256) void residual_fwd_kernel(LoadDesc xin, const T* y4, const float* coef4,
+                                                           const float* coefsc, const float* dscale, ResGeom gm,
+                                                           T* out) {
+    SLICE_SETUP(gm.Cout)
+    if (!chan_ok) return;
+    float s4[KC], t4[KC], ss[KC], ts[KC];
+    ld_coef<KC>(coef4 + chan, s4); ld_coef<KC>(coef4 + gm.Cout + chan, t4);
+    ld_coef<KC>(coefsc + chan, ss); ld_coef<KC>(coefsc + gm.Cout + chan, ts);
+    const int csrc = chan % gm.Cin;
+    const i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
+    const i64 rows_per_b = (i64)gm.T * gm.Hout * gm.Wout;
+    for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
+        int wo = (int)(row % gm.Wout);
+        i64 r2 = row / gm.Wout;
+        int ho = (int)(r2 % gm.Hout);
+        i64 bt = r2 / gm.Hout;
+        i64 rin = (bt * gm.Hin + gm.hsrc[ho]) * gm.Win + gm.wsrc[wo];
+        float sv[KC], yv[KC], o[KC];
+        load_op<LD_PE, T>(xin, rin, csrc, sv);
+        ld_vec<T>(y4 + row * gm.Cout + chan, yv);
+        float d = dscale ? dscale[row / rows_per_b] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < KC; ++i)
+            o[i] = d * fmaf(yv[i], s4[i], t4[i]) + fmaf(round_t<T>(sv[i]), ss[i], ts[i]);
+        st_vec<T>(out + row * gm.Cout + chan, o);
+    }
+}
+
+// Σ d·dout, Σ d·dout·ŷ4 -> stats4 ; Σ dout, Σ dout·ŝ -> statssc   (per out channel)
+template <typename T>
+__global__ __launch_bounds__(256) void residual_bwd_reduce_kernel(LoadDesc xin, const T* y4, const T* dout,
+                                                                  const float* coef4, const float* coefsc,
+                                                                  const float* dscale, ResGeom gm, double* stats4,
+                                                                  double* statssc) {
+    SLICE_SETUP(gm.Cout)
+    __shared__ float lstat[2 * NCV * KC];
+    __shared__ float lstat2[2 * NCV * KC];
+    if (tid < 2 * NCV * KC) { lstat[tid] = 0.f; lstat2[tid] = 0.f; }
+    __syncthreads();
+    float a0[KC], a1[KC], b0[KC], b1[KC];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) { a0[i] = a1[i] = b0[i] = b1[i] = 0.f; }
+    if (chan_ok) {
+        float m4[KC], i4[KC], ms[KC], is[KC];
+        ld_coef<KC>(coef4 + 2 * gm.Cout + chan, m4); ld_coef<KC>(coef4 + 3 * gm.Cout + chan, i4);
+        ld_coef<KC>(coefsc + 2 * gm.Cout + chan, ms); ld_coef<KC>(coefsc + 3 * gm.Cout + chan, is);
+        const int csrc = chan % gm.Cin;
+        const i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
+        const i64 rows_per_b = (i64)gm.T * gm.Hout * gm.Wout;
+        for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
+            int wo = (int)(row % gm.Wout);
+            i64 r2 = row / gm.Wout;
+            int ho = (int)(r2 % gm.Hout);
+            i64 bt = r2 / gm.Hout;
+            i64 rin = (bt * gm.Hin + gm.hsrc[ho]) * gm.Win + gm.wsrc[wo];
+            float sv[KC], yv[KC], g[KC];
+            load_op<LD_PE, T>(xin, rin, csrc, sv);
+            ld_vec<T>(y4 + row * gm.Cout + chan, yv);
+            ld_vec<T>(dout + row * gm.Cout + chan, g);
+            float d = dscale ? dscale[row / rows_per_b] : 1.0f;
+#pragma unroll
+            for (int i = 0; i < KC; ++i) {
+                float gd = g[i] * d;
+                a0[i] += gd;
+                a1[i] += gd * (yv[i] - m4[i]) * i4[i];
+                b0[i] += g[i];
+                b1[i] += g[i] * (round_t<T>(sv[i]) - ms[i]) * is[i];
+            }
+        }
+    }
+    slice_stats_flush<KC>(lstat, a0, a1, cv, c0, gm.Cout, stats4, blockIdx.x % DWN_NREP);
+    __syncthreads();
+    slice_stats_flush<KC>(lstat2, b0, b1, cv, c0, gm.Cout, statssc, blockIdx.x % DWN_NREP);
+}
+
+// dy4[m][c'] = A1*(d*dout) + A2*y4 + A3
+template <typename T>
+__global__ __launch_bounds__(256) void residual_bwd_dy4_kernel(const T* y4, const T* dout, const float* abc4,
+                                                               const float* dscale, ResGeom gm, T* dy4) {
+    SLICE_SETUP(gm.Cout)
+    if (!chan_ok) return;
+    float a1[KC], a2[KC], a3[KC];
+    ld_coef<KC>(abc4 + chan, a1); ld_coef<KC>(abc4 + gm.Cout + chan, a2); ld_coef<KC>(abc4 + 2 * gm.Cout + chan, a3);
+    const i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
+    const i64 rows_per_b = (i64)gm.T * gm.Hout * gm.Wout;
+    for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
+        float yv[KC], g[KC], o[KC];
+        ld_vec<T>(y4 + row * gm.Cout + chan, yv);
+        ld_vec<T>(dout + row * gm.Cout + chan, g);
+        float d = dscale ? dscale[row / rows_per_b] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < KC; ++i) o[i] = fmaf(a1[i], g[i] * d, fmaf(a2[i], yv[i], a3[i]));
+        st_vec<T>(dy4 + row * gm.Cout + chan, o);
+    }
+}
+
+// dx[m_in][c] = da0[m_in][c] + [m_in gathered] sum_{c' = c + j*Cin < Cout} (A1sc*dout[m_out][c'] + A2sc*s + A3sc)
+template <typename T>
+__global__ __launch_bounds__(256) void residual_bwd_dx_kernel(LoadDesc xin, const T* da0, const T* dout,
+                                                              const float* abcsc, ResGeom gm, T* dx) {
+    SLICE_SETUP(gm.Cin)
+    if (!chan_ok) return;
+    const i64 rows = (i64)gm.BT * gm.Hin * gm.Win;
+    for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
+        int wi = (int)(row % gm.Win);
+        i64 r2 = row / gm.Win;
+        int hi = (int)(r2 % gm.Hin);
+        i64 bt = r2 / gm.Hin;
+        float o[KC];
+        ld_vec<T>(da0 + row * gm.Cin + chan, o);
+        int ho = gm.hinv[hi], wo = gm.winv[wi];
+        if (ho >= 0 && wo >= 0) {
+            i64 rout = (bt * gm.Hout + ho) * gm.Wout + wo;
+            float sv[KC];
+            load_op<LD_PE, T>(xin, row, chan, sv);
+            for (int cc = chan; cc < gm.Cout; cc += gm.Cin) {
+                float g[KC], a1[KC], a2[KC], a3[KC];
+                ld_vec<T>(dout + rout * gm.Cout + cc, g);
+                ld_coef<KC>(abcsc + cc, a1); ld_coef<KC>(abcsc + gm.Cout + cc, a2);
+                ld_coef<KC>(abcsc + 2 * gm.Cout + cc, a3);
+#pragma unroll
+                for (int i = 0; i < KC; ++i) o[i] += fmaf(a1[i], g[i], fmaf(a2[i], round_t<T>(sv[i]), a3[i]));
+            }
+        }
+        st_vec<T>(dx + row * gm.Cin + chan, o);
+    }
+}
+
+#define DISPATCH_T(dtype, CALL_BF, CALL_F) do { if ((dtype) == DWN_BF16) { CALL_BF; } else { CALL_F; } } while (0)
+
+int k_shortcut_stats(const LoadDesc& xin, const ResGeom& gm, double* stats, int dtype, hipStream_t s) {
+    i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((shortcut_stats_kernel<bf16_t>), slice_grid(rows, gm.Cin, 8, 1024), dim3(256), 0, s, xin, gm, stats),
+        hipLaunchKernelGGL((shortcut_stats_kernel<float>), slice_grid(rows, gm.Cin, 4, 1024), dim3(256), 0, s, xin, gm, stats));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_residual_fwd(const LoadDesc& xin, const void* y4, const float* coef4, const float* coefsc, const float* dscale,
+                   const ResGeom& gm, void* out, int dtype, hipStream_t s) {
+    i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((residual_fwd_kernel<bf16_t>), slice_grid(rows, gm.Cout, 8), dim3(256), 0, s, xin, (const bf16_t*)y4, coef4, coefsc, dscale, gm, (bf16_t*)out),
+        hipLaunchKernelGGL((residual_fwd_kernel<float>), slice_grid(rows, gm.Cout, 4), dim3(256), 0, s, xin, (const float*)y4, coef4, coefsc, dscale, gm, (float*)out));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_residual_bwd_reduce(const LoadDesc& xin, const void* y4, const void* dout, const float* coef4,
+                          const float* coefsc, const float* dscale, const ResGeom& gm, double* stats4,
+                          double* statssc, int dtype, hipStream_t s) {
+    i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((residual_bwd_reduce_kernel<bf16_t>), slice_grid(rows, gm.Cout, 8, 1024), dim3(256), 0, s, xin, (const bf16_t*)y4, (const bf16_t*)dout, coef4, coefsc, dscale, gm, stats4, statssc),
+        hipLaunchKernelGGL((residual_bwd_reduce_kernel<float>), slice_grid(rows, gm.Cout, 4, 1024), dim3(256), 0, s, xin, (const float*)y4, (const float*)dout, coef4, coefsc, dscale, gm, stats4, statssc));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_residual_bwd_dy4(const void* y4, const void* dout, const float* abc4, const float* dscale, const ResGeom& gm,
+                       void* dy4, int dtype, hipStream_t s) {
+    i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((residual_bwd_dy4_kernel<bf16_t>), slice_grid(rows, gm.Cout, 8), dim3(256), 0, s, (const bf16_t*)y4, (const bf16_t*)dout, abc4, dscale, gm, (bf16_t*)dy4),
+        hipLaunchKernelGGL((residual_bwd_dy4_kernel<float>), slice_grid(rows, gm.Cout, 4), dim3(256), 0, s, (const float*)y4, (const float*)dout, abc4, dscale, gm, (float*)dy4));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_residual_bwd_dx(const LoadDesc& xin, const void* da0, const void* dout, const float* abcsc, const ResGeom& gm,
+                      void* dx, int dtype, hipStream_t s) {
+    i64 rows = (i64)gm.BT * gm.Hin * gm.Win;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((residual_bwd_dx_kernel<bf16_t>), slice_grid(rows, gm.Cin, 8), dim3(256), 0, s, xin, (const bf16_t*)da0, (const bf16_t*)dout, abcsc, gm, (bf16_t*)dx),
+        hipLaunchKernelGGL((residual_bwd_dx_kernel<float>), slice_grid(rows, gm.Cin, 4), dim3(256), 0, s, xin, (const float*)da0, (const float*)dout, abcsc, gm, (float*)dx));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Squeeze-Excite (SqueezeExcite3d, dwiseneuro.py:38-43)
+// ------------------------------------------------------------------------------------------------
+// pooled[b][c] += sum over a chunk of the sample's rows of silu(bn3(y3))
+template <typename T>
+__global__ __launch_bounds__(256) void se_pool_kernel(LoadDesc z3, int C, int rows_per_sample, int chunks,
+                                                      float* pooled) {
+    SLICE_SETUP(C)
+    __shared__ float lacc[NCV * KC];
+    if (tid < NCV * KC) lacc[tid] = 0.f;
+    __syncthreads();
+    const int b = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const int per = (rows_per_sample + chunks - 1) / chunks;
+    const int r_beg = chunk * per;
+    const int r_end = (r_beg + per < rows_per_sample) ? r_beg + per : rows_per_sample;
+    float acc[KC];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) acc[i] = 0.f;
+    if (chan_ok)
+        for (int r = r_beg + pl; r < r_end; r += 32) {
+            float v[KC];
+            load_op<LD_BNACT, T>(z3, (i64)b * rows_per_sample + r, chan, v);
+#pragma unroll
+            for (int i = 0; i < KC; ++i) acc[i] += v[i];
+        }
+#pragma unroll
+    for (int i = 0; i < KC; ++i) atomicAdd(&lacc[cv * KC + i], acc[i]);
+    __syncthreads();
+    if (tid < NCV * KC && c0 + tid < C) atomicAdd(pooled + (i64)b * C + c0 + tid, lacc[tid]);
+}
+
+int k_se_pool(const LoadDesc& z3, int B, int C, int rows_per_sample, float* pooled, int dtype, hipStream_t s) {
+    int KCv = dtype == DWN_BF16 ? 8 : 4;
+    int slices = (C + NCV * KCv - 1) / (NCV * KCv);
+    int chunks = (rows_per_sample + 255) / 256;
+    int maxchunks = (2048 + B * slices - 1) / (B * slices);
+    if (chunks > maxchunks) chunks = maxchunks;
+    if (chunks < 1) chunks = 1;
+    dim3 grid(B * chunks, slices);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((se_pool_kernel<bf16_t>), grid, dim3(256), 0, s, z3, C, rows_per_sample, chunks, pooled),
+        hipLaunchKernelGGL((se_pool_kernel<float>), grid, dim3(256), 0, s, z3, C, rows_per_sample, chunks, pooled));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+// one workgroup per sample: p = pooled/S; hid_pre = Wr p + br; hid = silu; gate = sigmoid(We hid + be)
+__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* pooled_sum, float inv_s, const float* wr,
+                                                         const float* br, const float* we, const float* be, int C,
+                                                         int R, float* pmean, float* hid_pre, float* gate) {
+    extern __shared__ float sh[];          // [C] mean + [R] hid
+    float* pm = sh;
+    float* hid = sh + C;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) {
+        float v = pooled_sum[(i64)b * C + c] * inv_s;
+        pm[c] = v;
+        pmean[(i64)b * C + c] = v;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int r = wave; r < R; r += 4) {
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc = fmaf(wr[(i64)r * C + c], pm[c], acc);
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) {
+            float h = acc + br[r];
+            hid_pre[(i64)b * R + r] = h;
+            hid[r] = siluf_(h);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float acc = be[c];
+        for (int r = 0; r < R; ++r) acc = fmaf(we[(i64)c * R + r], hid[r], acc);
+        gate[(i64)b * C + c] = sigmoidf_(acc);
+    }
+}
+
+// per sample: dgp = dg*g*(1-g); dhid = We^T dgp; dhp = dhid*silu'(hid_pre); dpS = (Wr^T dhp)/S
+__global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* dg, const float* gate, const float* hid_pre,
+                                                         const float* wr, const float* we, int C, int R, float inv_s,
+                                                         float* dgp_out, float* dhp_out, float* dps) {
+    extern __shared__ float sh[];          // [C] dgp + [R] dhp
+    float* dgp = sh;
+    float* dhp = sh + C;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) {
+        float g = gate[(i64)b * C + c];
+        float v = dg[(i64)b * C + c] * g * (1.f - g);
+        dgp[c] = v;
+        dgp_out[(i64)b * C + c] = v;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int r = wave; r < R; r += 4) {
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc = fmaf(we[(i64)c * R + r], dgp[c], acc);
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) {
+            float v = acc * silu_gradf_(hid_pre[(i64)b * R + r]);
+            dhp[r] = v;
+            dhp_out[(i64)b * R + r] = v;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc = fmaf(wr[(i64)r * C + c], dhp[r], acc);
+        dps[(i64)b * C + c] = acc * inv_s;
+    }
+}
+
+// parameter grads of the SE MLP: one thread per channel c
+__global__ void se_mlp_wgrad_kernel(const float* dgp, const float* dhp, const float* pmean, const float* hid_pre,
+                                    int B, int C, int R, float* dwr, float* dbr, float* dwe, float* dbe) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        float sb = 0.f;
+        for (int b = 0; b < B; ++b) sb += dgp[(i64)b * C + c];
+        dbe[c] = sb;
+        for (int r = 0; r < R; ++r) {
+            float a = 0.f, a2 = 0.f;
+            for (int b = 0; b < B; ++b) {
+                a = fmaf(dgp[(i64)b * C + c], siluf_(hid_pre[(i64)b * R + r]), a);
+                a2 = fmaf(dhp[(i64)b * R + r], pmean[(i64)b * C + c], a2);
+            }
+            dwe[(i64)c * R + r] = a;
+            dwr[(i64)r * C + c] = a2;
+        }
+    }
+    if (c < R) {
+        float sb = 0.f;
+        for (int b = 0; b < B; ++b) sb += dhp[(i64)b * R + c];
+        dbr[c] = sb;
+    }
+}
+
+int k_se_mlp_fwd(const float* pooled_sum, float inv_s, const float* wr, const float* br, const float* we,
+                 const float* be, int B, int C, int R, float* pmean, float* hid_pre, float* gate, hipStream_t s) {
+    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), s, pooled_sum, inv_s, wr, br, we,
+                       be, C, R, pmean, hid_pre, gate);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_se_mlp_bwd(const float* dg, const float* gate, const float* hid_pre, const float* pmean, const float* wr,
+                 const float* we, int B, int C, int R, float inv_s, float* dgp, float* dhp, float* dps, float* dwr,
+                 float* dbr, float* dwe, float* dbe, hipStream_t s) {
+    hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), s, dg, gate, hid_pre, wr, we, C,
+                       R, inv_s, dgp, dhp, dps);
+    DWN_CHECK_LAUNCH();
+    int n = C > R ? C : R;
+    hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((n + 127) / 128), dim3(128), 0, s, dgp, dhp, pmean, hid_pre, B, C, R,
+                       dwr, dbr, dwe, dbe);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+// Σdh3, Σdh3·ŷ3 where dh3 = (du*gate + dpS) * silu'(bn3(y3))   (LD_DY3 with A1=1, A2=A3=0 gives dh3)
+template <typename T>
+__global__ __launch_bounds__(256) void bn3_bwd_reduce_kernel(LoadDesc d, const float* coef3, i64 rows, int C,
+                                                             double* stats) {
+    SLICE_SETUP(C)
+    __shared__ float lstat[2 * NCV * KC];
+    if (tid < 2 * NCV * KC) lstat[tid] = 0.f;
+    __syncthreads();
+    float s0[KC], s1[KC];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+    if (chan_ok) {
+        float m3[KC], i3[KC];
+        ld_coef<KC>(coef3 + 2 * C + chan, m3);
+        ld_coef<KC>(coef3 + 3 * C + chan, i3);
+        const T* yp = reinterpret_cast<const T*>(d.q);
+        for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
+            float dh[KC], y[KC];
+            load_op<LD_DY3, T>(d, row, chan, dh);
+            ld_vec<T>(yp + row * d.ld + chan, y);
+#pragma unroll
+            for (int i = 0; i < KC; ++i) { s0[i] += dh[i]; s1[i] += dh[i] * (y[i] - m3[i]) * i3[i]; }
+        }
+    }
+    slice_stats_flush<KC>(lstat, s0, s1, cv, c0, C, stats, blockIdx.x % DWN_NREP);
+}
+int k_bn3_bwd_reduce(const LoadDesc& d, const float* coef3, i64 rows, int C, double* stats, int dtype, hipStream_t s) {
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((bn3_bwd_reduce_kernel<bf16_t>), slice_grid(rows, C, 8, 2048), dim3(256), 0, s, d, coef3, rows, C, stats),
+        hipLaunchKernelGGL((bn3_bwd_reduce_kernel<float>), slice_grid(rows, C, 4, 2048), dim3(256), 0, s, d, coef3, rows, C, stats));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// H×W average pool (AdaptiveAvgPool3d((None,1,1)), dwiseneuro.py:374,400) and its backward
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const T* x, T* out, i64 BT, int HW, int C) {
+    SLICE_SETUP(C)
+    if (!chan_ok) return;
+    const float inv = 1.0f / HW;
+    for (i64 bt = (i64)blockIdx.x * 32 + pl; bt < BT; bt += (i64)gridDim.x * 32) {
+        float acc[KC];
+#pragma unroll
+        for (int i = 0; i < KC; ++i) acc[i] = 0.f;
+        for (int p = 0; p < HW; ++p) {
+            float v[KC];
+            ld_vec<T>(x + (bt * HW + p) * C + chan, v);
+#pragma unroll
+            for (int i = 0; i < KC; ++i) acc[i] += v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < KC; ++i) acc[i] *= inv;
+        st_vec<T>(out + bt * C + chan, acc);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const T* dpool, T* dx, i64 BT, int HW, int C) {
+    SLICE_SETUP(C)
+    if (!chan_ok) return;
+    const float inv = 1.0f / HW;
+    const i64 rows = BT * HW;
+    for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
+        float v[KC];
+        ld_vec<T>(dpool + (row / HW) * C + chan, v);
+#pragma unroll
+        for (int i = 0; i < KC; ++i) v[i] *= inv;
+        st_vec<T>(dx + row * C + chan, v);
+    }
+}
+int k_pool_fwd(const void* x, void* out, i64 BT, int HW, int C, int dtype, hipStream_t s) {
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((pool_fwd_kernel<bf16_t>), slice_grid(BT, C, 8), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, BT, HW, C),
+        hipLaunchKernelGGL((pool_fwd_kernel<float>), slice_grid(BT, C, 4), dim3(256), 0, s, (const float*)x, (float*)out, BT, HW, C));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_pool_bwd(const void* dpool, void* dx, i64 BT, int HW, int C, int dtype, hipStream_t s) {
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((pool_bwd_kernel<bf16_t>), slice_grid(BT * HW, C, 8), dim3(256), 0, s, (const bf16_t*)dpool, (bf16_t*)dx, BT, HW, C),
+        hipLaunchKernelGGL((pool_bwd_kernel<float>), slice_grid(BT * HW, C, 4), dim3(256), 0, s, (const float*)dpool, (float*)dx, BT, HW, C));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cortex ShuffleLayer glue (dwiseneuro.py:212-234).  Tiny tensors ([B*T][<=4096]): scalar kernels.
+//   out[m][j] = d[b]*silu(s[o]*y[m][o]+t[o]) + ssc[j]*x[m][j % Cin] + tsc[j],  o = (j % g)*(C/g) + j / g
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void cortex_residual_fwd_kernel(const T* y, const T* x, const float* coef, const float* coefsc,
+                                           const float* dscale, int M, int Tn, int Cin, int C, int groups, T* out) {
+    i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (i64)M * C) return;
+    int j = (int)(idx % C);
+    i64 m = idx / C;
+    int o = (j % groups) * (C / groups) + j / groups;
+    float h = fmaf(to_f<T>(y[m * C + o]), coef[o], coef[C + o]);
+    float z = siluf_(h);
+    float d = dscale ? dscale[m / Tn] : 1.0f;
+    float sc = fmaf(to_f<T>(x[m * Cin + j % Cin]), coefsc[j], coefsc[C + j]);
+    out[idx] = from_f<T>(d * z + sc);
+}
+
+// per-channel backward sums: main BN (indexed by o): Σdh, Σdh·ŷ ; shortcut BN (indexed by j): Σdout, Σdout·ŝ
+// one thread per channel, looping over rows (M = B*T is ~1k)
+template <typename T>
+__global__ void cortex_bwd_reduce_kernel(const T* y, const T* x, const T* dout, const float* gmask, int gmask_ld,
+                                         const float* coef, const float* coefsc, const float* dscale, int M, int Tn,
+                                         int Cin, int C, int groups, int rows_per_chunk, double* stats,
+                                         double* statssc) {
+    int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= C) return;
+    int m_beg = blockIdx.y * rows_per_chunk;
+    int m_end = m_beg + rows_per_chunk < M ? m_beg + rows_per_chunk : M;
+    // main path for o = ch : shuffled position j(o) = (o % (C/g))*g + o / (C/g)
+    int o = ch;
+    int j = (o % (C / groups)) * groups + o / (C / groups);
+    float s = coef[o], t = coef[C + o], mean = coef[2 * C + o], invstd = coef[3 * C + o];
+    float a0 = 0.f, a1 = 0.f;
+    for (int m = m_beg; m < m_end; ++m) {
+        float yv = to_f<T>(y[(i64)m * C + o]);
+        float g = to_f<T>(dout[(i64)m * C + j]);
+        if (gmask) g *= gmask[(i64)(m / Tn) * gmask_ld + j];
+        float d = dscale ? dscale[m / Tn] : 1.0f;
+        float dh = g * d * silu_gradf_(fmaf(yv, s, t));
+        a0 += dh;
+        a1 += dh * (yv - mean) * invstd;
+    }
+    int rep = blockIdx.y % DWN_NREP;
+    stat_add(stats, rep, C, 0, o, a0);
+    stat_add(stats, rep, C, 1, o, a1);
+    // shortcut path for j = ch
+    j = ch;
+    float ms = coefsc[2 * C + j], is = coefsc[3 * C + j];
+    float b0 = 0.f, b1 = 0.f;
+    for (int m = m_beg; m < m_end; ++m) {
+        float g = to_f<T>(dout[(i64)m * C + j]);
+        if (gmask) g *= gmask[(i64)(m / Tn) * gmask_ld + j];
+        float xv = to_f<T>(x[(i64)m * Cin + j % Cin]);
+        b0 += g;
+        b1 += g * (xv - ms) * is;
+    }
+    stat_add(statssc, rep, C, 0, j, b0);
+    stat_add(statssc, rep, C, 1, j, b1);
+}
+
+// dy[m][o] = A1*dh + A2*y + A3 (main path, materialised for the GEMMs)
+template <typename T>
+__global__ void cortex_bwd_dy_kernel(const T* y, const T* dout, const float* gmask, int gmask_ld, const float* coef,
+                                     const float* abc, const float* dscale, int M, int Tn, int C, int groups, T* dy) {
+    i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (i64)M * C) return;
+    int o = (int)(idx % C);
+    i64 m = idx / C;
+    int j = (o % (C / groups)) * groups + o / (C / groups);
+    float yv = to_f<T>(y[idx]);
+    float g = to_f<T>(dout[m * C + j]);
+    if (gmask) g *= gmask[(m / Tn) * gmask_ld + j];
+    float d = dscale ? dscale[m / Tn] : 1.0f;
+    float dh = g * d * silu_gradf_(fmaf(yv, coef[o], coef[C + o]));
+    dy[idx] = from_f<T>(fmaf(abc[o], dh, fmaf(abc[C + o], yv, abc[2 * C + o])));
+}
+
+// dx[m][c] = dxmain[m][c] + sum_{j = c + k*Cin < C} (A1sc[j]*dout[m][j] + A2sc[j]*x[m][c] + A3sc[j])
+template <typename T>
+__global__ void cortex_bwd_dx_kernel(const T* dxmain, const T* x, const T* dout, const float* gmask, int gmask_ld,
+                                     const float* abcsc, int M, int Tn, int Cin, int C, T* dx) {
+    i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (i64)M * Cin) return;
+    int c = (int)(idx % Cin);
+    i64 m = idx / Cin;
+    float acc = to_f<T>(dxmain[idx]);
+    float xv = to_f<T>(x[idx]);
+    for (int j = c; j < C; j += Cin) {
+        float g = to_f<T>(dout[m * C + j]);
+        if (gmask) g *= gmask[(m / Tn) * gmask_ld + j];
+        acc += fmaf(abcsc[j], g, fmaf(abcsc[C + j], xv, abcsc[2 * C + j]));
+    }
+    dx[idx] = from_f<T>(acc);
+}
+
+int k_cortex_residual_fwd(const void* y, const void* x, const float* coef, const float* coefsc, const float* dscale,
+                          int M, int Tn, int Cin, int C, int groups, void* out, int dtype, hipStream_t s) {
+    i64 n = (i64)M * C;
+    dim3 grid((unsigned)((n + 255) / 256));
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((cortex_residual_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)y, (const bf16_t*)x, coef, coefsc, dscale, M, Tn, Cin, C, groups, (bf16_t*)out),
+        hipLaunchKernelGGL((cortex_residual_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)y, (const float*)x, coef, coefsc, dscale, M, Tn, Cin, C, groups, (float*)out));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_cortex_bwd_reduce(const void* y, const void* x, const void* dout, const float* gmask, int gmask_ld,
+                        const float* coef, const float* coefsc, const float* dscale, int M, int Tn, int Cin, int C,
+                        int groups, double* stats, double* statssc, int dtype, hipStream_t s) {
+    int rows_per_chunk = 64;
+    dim3 grid((C + 127) / 128, (M + rows_per_chunk - 1) / rows_per_chunk);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((cortex_bwd_reduce_kernel<bf16_t>), grid, dim3(128), 0, s, (const bf16_t*)y, (const bf16_t*)x, (const bf16_t*)dout, gmask, gmask_ld, coef, coefsc, dscale, M, Tn, Cin, C, groups, rows_per_chunk, stats, statssc),
+        hipLaunchKernelGGL((cortex_bwd_reduce_kernel<float>), grid, dim3(128), 0, s, (const float*)y, (const float*)x, (const float*)dout, gmask, gmask_ld, coef, coefsc, dscale, M, Tn, Cin, C, groups, rows_per_chunk, stats, statssc));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_cortex_bwd_dy(const void* y, const void* dout, const float* gmask, int gmask_ld, const float* coef,
+                    const float* abc, const float* dscale, int M, int Tn, int C, int groups, void* dy, int dtype,
+                    hipStream_t s) {
+    i64 n = (i64)M * C;
+    dim3 grid((unsigned)((n + 255) / 256));
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((cortex_bwd_dy_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)y, (const bf16_t*)dout, gmask, gmask_ld, coef, abc, dscale, M, Tn, C, groups, (bf16_t*)dy),
+        hipLaunchKernelGGL((cortex_bwd_dy_kernel<float>), grid, dim3(256), 0, s, (const float*)y, (const float*)dout, gmask, gmask_ld, coef, abc, dscale, M, Tn, C, groups, (float*)dy));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_cortex_bwd_dx(const void* dxmain, const void* x, const void* dout, const float* gmask, int gmask_ld,
+                    const float* abcsc, int M, int Tn, int Cin, int C, void* dx, int dtype, hipStream_t s) {
+    i64 n = (i64)M * Cin;
+    dim3 grid((unsigned)((n + 255) / 256));
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((cortex_bwd_dx_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dxmain, (const bf16_t*)x, (const bf16_t*)dout, gmask, gmask_ld, abcsc, M, Tn, Cin, C, (bf16_t*)dx),
+        hipLaunchKernelGGL((cortex_bwd_dx_kernel<float>), grid, dim3(256), 0, s, (const float*)dxmain, (const float*)x, (const float*)dout, gmask, gmask_ld, abcsc, M, Tn, Cin, C, (float*)dx));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: fp32 parameter -> T, optionally transposed and zero padded
+// dst[g][r][c] (rows R_dst, cols C_dst per group) = src[g][..] ; transpose: dst[g][c][r] = src[g][r][c]
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weight_kernel(const float* src, T* dst, int groups, int R, int C, int transpose, int Rd, int Cd) {
+    i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    i64 per = (i64)Rd * Cd;
+    if (idx >= per * groups) return;
+    int g = (int)(idx / per);
+    i64 rem = idx % per;
+    int rd = (int)(rem / Cd), cd = (int)(rem % Cd);
+    float v = 0.f;
+    if (!transpose) { if (rd < R && cd < C) v = src[((i64)g * R + rd) * C + cd]; }
+    else { if (cd < R && rd < C) v = src[((i64)g * R + cd) * C + rd]; }
+    dst[idx] = from_f<T>(v);
+}
+int k_pack_weight(const float* src, void* dst, int groups, int R, int C, int transpose, int Rd, int Cd, int dtype,
+                  hipStream_t s) {
+    i64 n = (i64)groups * Rd * Cd;
+    dim3 grid((unsigned)((n + 255) / 256));
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((pack_weight_kernel<bf16_t>), grid, dim3(256), 0, s, src, (bf16_t*)dst, groups, R, C, transpose, Rd, Cd),
+        hipLaunchKernelGGL((pack_weight_kernel<float>), grid, dim3(256), 0, s, src, (float*)dst, groups, R, C, transpose, Rd, Cd));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+// depth-wise weights: reference layout [C][taps] -> tap-major [taps][C] fp32
+__global__ void pack_dw_kernel(const float* src, float* dst, int C, int taps) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C * taps) return;
+    int k = idx / C, c = idx % C;
+    dst[idx] = src[c * taps + k];
+}
+int k_pack_dw(const float* src, float* dst, int C, int taps, hipStream_t s) {
+    hipLaunchKernelGGL(pack_dw_kernel, dim3((C * taps + 255) / 256), dim3(256), 0, s, src, dst, C, taps);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// readout glue (Readout, dwiseneuro.py:283-287) + Poisson loss (losses.py:10-21)
+// ------------------------------------------------------------------------------------------------
+// dz[m][g*Rp + r] = dout[b][n][t] * (1 - exp(-beta*out[b][n][t])),  n = g*Rg + r  (zero in the padding),
+// db[n] += sum_m dz.  One workgroup per (b, 64-neuron tile): LDS transpose (t-contiguous -> n-contiguous).
+template <typename T>
+__global__ __launch_bounds__(256) void readout_dz_kernel(const float* dout, const float* out, float beta, int Tn,
+                                                         int n_valid, int Rg, int Rp, int groups, T* dz, float* db) {
+    extern __shared__ float tile[];        // [64][Tn+1]
+    const int b = blockIdx.y, n0 = blockIdx.x * 64, tid = threadIdx.x;
+    const int npad_total = groups * Rp;
+    for (int i = tid; i < 64 * Tn; i += 256) {
+        int nl = i / Tn, t = i % Tn;
+        int np = n0 + nl;                  // index in the padded [groups][Rp] space
+        int g = np / Rp, r = np % Rp;
+        int n = g * Rg + r;
+        float v = 0.f;
+        if (np < npad_total && r < Rg && n < n_valid) {
+            i64 off = ((i64)b * n_valid + n) * Tn + t;
+            v = dout[off] * (1.0f - __expf(-beta * out[off]));
+        }
+        tile[nl * (Tn + 1) + t] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * Tn; i += 256) {
+        int t = i / 64, nl = i % 64;
+        int np = n0 + nl;
+        if (np < npad_total) dz[((i64)b * Tn + t) * npad_total + np] = from_f<T>(tile[nl * (Tn + 1) + t]);
+    }
+    if (tid < 64) {
+        int np = n0 + tid;
+        int g = np / Rp, r = np % Rp;
+        int n = g * Rg + r;
+        if (np < npad_total && r < Rg && n < groups * Rg) {
+            float sum = 0.f;
+            for (int t = 0; t < Tn; ++t) sum += round_t<T>(tile[tid * (Tn + 1) + t]);
+            atomicAdd(db + n, sum);
+        }
+    }
+}
+int k_readout_dz(const float* dout, const float* out, float beta, int B, int Tn, int n_valid, int Rg, int Rp,
+                 int groups, void* dz, float* db, int dtype, hipStream_t s) {
+    dim3 grid((groups * Rp + 63) / 64, B);
+    size_t lds = (size_t)64 * (Tn + 1) * sizeof(float);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((readout_dz_kernel<bf16_t>), grid, dim3(256), lds, s, dout, out, beta, Tn, n_valid, Rg, Rp, groups, (bf16_t*)dz, db),
+        hipLaunchKernelGGL((readout_dz_kernel<float>), grid, dim3(256), lds, s, dout, out, beta, Tn, n_valid, Rg, Rp, groups, (float*)dz, db));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+// loss += sum_{b,n,t} w[b] * (x - y*log(x + eps));  dpred = gscale * w[b] * (1 - y/(x+eps))
+__global__ __launch_bounds__(256) void poisson_fwd_kernel(const float* pred, const float* target, const float* w,
+                                                          i64 per_sample, i64 total, float eps, double* loss) {
+    double acc = 0.0;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < total; i += (i64)gridDim.x * 256) {
+        float wb = w[i / per_sample];
+        if (wb != 0.f) {
+            float x = pred[i], y = target[i];
+            acc += (double)(wb * (x - y * __logf(x + eps)));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, part[0] + part[1] + part[2] + part[3]);
+}
+__global__ __launch_bounds__(256) void poisson_bwd_kernel(const float* pred, const float* target, const float* w,
+                                                          const float* gscale, i64 per_sample, i64 total, float eps,
+                                                          float* dpred) {
+    const float gs = gscale ? *gscale : 1.0f;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < total; i += (i64)gridDim.x * 256) {
+        float wb = w[i / per_sample];
+        dpred[i] = wb != 0.f ? gs * wb * (1.0f - target[i] / (pred[i] + eps)) : 0.f;
+    }
+}
+__global__ void f64_to_f32_kernel(const double* src, float* dst, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+int k_poisson_fwd(const float* pred, const float* target, const float* w, i64 per_sample, i64 total, float eps,
+                  double* loss, hipStream_t s) {
+    i64 blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(poisson_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pred, target, w, per_sample, total, eps, loss);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_poisson_bwd(const float* pred, const float* target, const float* w, const float* gscale, i64 per_sample,
+                  i64 total, float eps, float* dpred, hipStream_t s) {
+    i64 blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(poisson_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pred, target, w, gscale, per_sample, total, eps, dpred);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_f64_to_f32(const double* src, float* dst, int n, hipStream_t s) {
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3((n + 63) / 64), dim3(64), 0, s, src, dst, n);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout conversion at the API boundary: T channels-last [B*T][C] <-> fp32 NCT [B][C][T]  (cortex in/out)
+// ------------------------------------------------------------------------------------------------
+
+// ------------------------------------------------------------------------------------------------
+// fused multi-tensor AdamW (+ EMA of the parameters) — torch.optim.AdamW semantics
+// (true_batch_001.py:45-48) and ModelEma.update (ema.py:47-55) in one pass over the parameters.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_ema_kernel(const TensorListEntry* list, int ntensors, float decay_w,
+                                                        float omb1, float beta2, float omb2, float eps,
+                                                        float step_size, float bc2_sqrt, float ema_decay,
+                                                        float ema_omd, float grad_scale) {
+    // blockIdx.y = tensor, blockIdx.x strides over its elements.  Scalars are computed on the host in
+    // double exactly as torch does: decay_w = 1 - lr*wd, omb = 1 - beta, step_size = lr / (1 - beta1^t).
+    const TensorListEntry e = list[blockIdx.y];
+    float* p = e.param; const float* g = e.grad; float* m = e.exp_avg; float* v = e.exp_avg_sq; float* ema = e.ema;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < e.numel; i += (i64)gridDim.x * 256) {
+        float gi = g[i] * grad_scale;
+        float pi = p[i] * decay_w;
+        float mi = m[i] + omb1 * (gi - m[i]);                    // exp_avg.lerp_(grad, 1 - beta1)
+        float vi = beta2 * v[i] + omb2 * gi * gi;                // mul_(beta2).addcmul_(g, g, 1 - beta2)
+        float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi - step_size * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (ema) ema[i] = ema_decay * ema[i] + ema_omd * pi;
+    }
+}
+// EMA of float buffers (running stats) and int64 counters (num_batches_tracked: float result truncated, ema.py:52)
+__global__ __launch_bounds__(256) void ema_lerp_kernel(const TensorListEntry* list, int ntensors, float decay, float omd) {
+    const TensorListEntry e = list[blockIdx.y];
+    if (e.is_int64) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            long long* d = reinterpret_cast<long long*>(e.ema);
+            const long long* sp = reinterpret_cast<const long long*>(e.param);
+            for (i64 i = 0; i < e.numel; ++i) d[i] = (long long)(decay * (float)d[i] + omd * (float)sp[i]);
+        }
+        return;
+    }
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < e.numel; i += (i64)gridDim.x * 256)
+        e.ema[i] = decay * e.ema[i] + omd * e.param[i];
+}
+int k_adamw_ema(const TensorListEntry* list, int ntensors, int max_blocks, float decay_w, float omb1, float beta2,
+                float omb2, float eps, float step_size, float bc2_sqrt, float ema_decay, float ema_omd,
+                float grad_scale, hipStream_t s) {
+    if (ntensors <= 0) return 0;
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3(max_blocks, ntensors), dim3(256), 0, s, list, ntensors, decay_w, omb1,
+                       beta2, omb2, eps, step_size, bc2_sqrt, ema_decay, ema_omd, grad_scale);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_ema_lerp(const TensorListEntry* list, int ntensors, int max_blocks, float decay, float omd, hipStream_t s) {
+    if (ntensors <= 0) return 0;
+    hipLaunchKernelGGL(ema_lerp_kernel, dim3(max_blocks, ntensors), dim3(256), 0, s, list, ntensors, decay, omd);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small utilities
+// ------------------------------------------------------------------------------------------------
+__global__ void fill_f32_kernel(float* p, float v, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+int k_fill_f32(float* p, float v, int n, hipStream_t s) {
+    hipLaunchKernelGGL(fill_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+// Σg, Σg·ŷ for a linear (no activation) BatchNorm: g, y plain tensors [rows][C]
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_plain_kernel(const T* g, const T* y, const float* coef, i64 rows,
+                                                                  int C, double* stats) {
+    SLICE_SETUP(C)
+    __shared__ float lstat[2 * NCV * KC];
+    if (tid < 2 * NCV * KC) lstat[tid] = 0.f;
+    __syncthreads();
+    float s0[KC], s1[KC];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+    if (chan_ok) {
+        float mu[KC], is[KC];
+        ld_coef<KC>(coef + 2 * C + chan, mu);
+        ld_coef<KC>(coef + 3 * C + chan, is);
+        for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
+            float gv[KC], yv[KC];
+            ld_vec<T>(g + row * C + chan, gv);
+            ld_vec<T>(y + row * C + chan, yv);
+#pragma unroll
+            for (int i = 0; i < KC; ++i) { s0[i] += gv[i]; s1[i] += gv[i] * (yv[i] - mu[i]) * is[i]; }
+        }
+    }
+    slice_stats_flush<KC>(lstat, s0, s1, cv, c0, C, stats, blockIdx.x % DWN_NREP);
+}
+int k_bn_bwd_reduce_plain(const void* g, const void* y, const float* coef, i64 rows, int C, double* stats, int dtype,
+                          hipStream_t s) {
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((bn_bwd_reduce_plain_kernel<bf16_t>), slice_grid(rows, C, 8, 1024), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, coef, rows, C, stats),
+        hipLaunchKernelGGL((bn_bwd_reduce_plain_kernel<float>), slice_grid(rows, C, 4, 1024), dim3(256), 0, s, (const float*)g, (const float*)y, coef, rows, C, stats));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,18 @@
+// Internal launch-argument structs and launcher prototypes shared by the kernel files and the C-ABI layer.
+#pragma once
+#include "dwn_common.h"
+
+enum { EPI_STORE = DWN_EPI_STORE, EPI_READOUT = DWN_EPI_READOUT, EPI_DG = DWN_EPI_DG };
+typedef dwn_gemm_nn_args GemmNN;
+typedef dwn_gemm_tn_args GemmTN;
+typedef dwn_dw_spatial_fwd_args DwSpatialFwd;
+typedef dwn_dw_spatial_bwd_args DwSpatialBwd;
+typedef dwn_dw_temporal_fwd_args DwTemporalFwd;
+typedef dwn_dw_temporal_bwd_args DwTemporalBwd;
+
+int launch_gemm_nn(const GemmNN& g, int dtype, hipStream_t s);
+int launch_gemm_tn(const GemmTN& g, int dtype, hipStream_t s);
+int launch_dw_spatial_fwd(const DwSpatialFwd& a, int dtype, hipStream_t s);
+int launch_dw_spatial_bwd(const DwSpatialBwd& a, int dtype, hipStream_t s);
+int launch_dw_temporal_fwd(const DwTemporalFwd& a, int dtype, hipStream_t s);
+int launch_dw_temporal_bwd(const DwTemporalBwd& a, int dtype, hipStream_t s);

@@ -1,0 +1,70 @@
+// Prototypes of the glue-kernel launchers (dwn_elementwise.hip).  All return 0 or a negative/positive error code.
+#pragma once
+#include "dwn_internal.h"
+
+struct ResGeom {
+    int BT, T, Hin, Win, Hout, Wout, Cin, Cout;
+    const int* hsrc; const int* wsrc;     // [Hout], [Wout]: nearest source index (dwiseneuro.py:127-129)
+    const int* hinv; const int* winv;     // [Hin], [Win]: inverse map or -1
+};
+
+typedef dwn_tensor_entry TensorListEntry;
+
+int k_bn_finalize_train(const double* stats, int stat_c, double count, const float* gamma, const float* beta,
+                        float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef, int C,
+                        hipStream_t s);
+int k_bn_finalize_eval(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                       float* coef, int C, hipStream_t s);
+int k_bn_bwd_finalize(const double* stats, double count, const float* coef, float* dgamma, float* dbeta, float* abc,
+                      int C, hipStream_t s);
+int k_ew_apply(const LoadDesc& d, int kind, void* out, i64 ldo, i64 rows, int C, int dtype, hipStream_t s);
+int k_colstats(const LoadDesc& d, int kind, i64 rows, int C, double* stats, int dtype, hipStream_t s);
+int k_stem_fwd(const float* x, const float* w, void* y, int B, int Cin, i64 S, int C0, double* stats, int dtype,
+               hipStream_t s);
+int k_stem_bwd(const LoadDesc& dy, const float* x, float* dw, int B, int Cin, i64 S, int C0, int dtype, hipStream_t s);
+int k_shortcut_stats(const LoadDesc& xin, const ResGeom& gm, double* stats, int dtype, hipStream_t s);
+int k_residual_fwd(const LoadDesc& xin, const void* y4, const float* coef4, const float* coefsc, const float* dscale,
+                   const ResGeom& gm, void* out, int dtype, hipStream_t s);
+int k_residual_bwd_reduce(const LoadDesc& xin, const void* y4, const void* dout, const float* coef4,
+                          const float* coefsc, const float* dscale, const ResGeom& gm, double* stats4,
+                          double* statssc, int dtype, hipStream_t s);
+int k_residual_bwd_dy4(const void* y4, const void* dout, const float* abc4, const float* dscale, const ResGeom& gm,
+                       void* dy4, int dtype, hipStream_t s);
+int k_residual_bwd_dx(const LoadDesc& xin, const void* da0, const void* dout, const float* abcsc, const ResGeom& gm,
+                      void* dx, int dtype, hipStream_t s);
+int k_se_pool(const LoadDesc& z3, int B, int C, int rows_per_sample, float* pooled, int dtype, hipStream_t s);
+int k_se_mlp_fwd(const float* pooled_sum, float inv_s, const float* wr, const float* br, const float* we,
+                 const float* be, int B, int C, int R, float* pmean, float* hid_pre, float* gate, hipStream_t s);
+int k_se_mlp_bwd(const float* dg, const float* gate, const float* hid_pre, const float* pmean, const float* wr,
+                 const float* we, int B, int C, int R, float inv_s, float* dgp, float* dhp, float* dps, float* dwr,
+                 float* dbr, float* dwe, float* dbe, hipStream_t s);
+int k_bn3_bwd_reduce(const LoadDesc& d, const float* coef3, i64 rows, int C, double* stats, int dtype, hipStream_t s);
+int k_pool_fwd(const void* x, void* out, i64 BT, int HW, int C, int dtype, hipStream_t s);
+int k_pool_bwd(const void* dpool, void* dx, i64 BT, int HW, int C, int dtype, hipStream_t s);
+int k_cortex_residual_fwd(const void* y, const void* x, const float* coef, const float* coefsc, const float* dscale,
+                          int M, int Tn, int Cin, int C, int groups, void* out, int dtype, hipStream_t s);
+int k_cortex_bwd_reduce(const void* y, const void* x, const void* dout, const float* gmask, int gmask_ld,
+                        const float* coef, const float* coefsc, const float* dscale, int M, int Tn, int Cin, int C,
+                        int groups, double* stats, double* statssc, int dtype, hipStream_t s);
+int k_cortex_bwd_dy(const void* y, const void* dout, const float* gmask, int gmask_ld, const float* coef,
+                    const float* abc, const float* dscale, int M, int Tn, int C, int groups, void* dy, int dtype,
+                    hipStream_t s);
+int k_cortex_bwd_dx(const void* dxmain, const void* x, const void* dout, const float* gmask, int gmask_ld,
+                    const float* abcsc, int M, int Tn, int Cin, int C, void* dx, int dtype, hipStream_t s);
+int k_pack_weight(const float* src, void* dst, int groups, int R, int C, int transpose, int Rd, int Cd, int dtype,
+                  hipStream_t s);
+int k_pack_dw(const float* src, float* dst, int C, int taps, hipStream_t s);
+int k_readout_dz(const float* dout, const float* out, float beta, int B, int Tn, int n_valid, int Rg, int Rp,
+                 int groups, void* dz, float* db, int dtype, hipStream_t s);
+int k_poisson_fwd(const float* pred, const float* target, const float* w, i64 per_sample, i64 total, float eps,
+                  double* loss, hipStream_t s);
+int k_poisson_bwd(const float* pred, const float* target, const float* w, const float* gscale, i64 per_sample,
+                  i64 total, float eps, float* dpred, hipStream_t s);
+int k_f64_to_f32(const double* src, float* dst, int n, hipStream_t s);
+int k_adamw_ema(const TensorListEntry* list, int ntensors, int max_blocks, float decay_w, float omb1, float beta2,
+                float omb2, float eps, float step_size, float bc2_sqrt, float ema_decay, float ema_omd,
+                float grad_scale, hipStream_t s);
+int k_ema_lerp(const TensorListEntry* list, int ntensors, int max_blocks, float decay, float omd, hipStream_t s);
+int k_fill_f32(float* p, float v, int n, hipStream_t s);
+int k_bn_bwd_reduce_plain(const void* g, const void* y, const float* coef, i64 rows, int C, double* stats, int dtype,
+                          hipStream_t s);

@@ -1,0 +1,468 @@
+"""torch.autograd.Function wrappers over the C-ABI composites of libdwiseneuro_hip.so.
+
+One Function per reference module on the hot path (src/models/dwiseneuro.py): stem, [PositionalEncoding3d +
+InvertedResidual3d], pool, ShuffleLayer, Readout, and MicePoissonLoss (src/losses.py).  PyTorch is plumbing
+here: it owns device memory (every buffer, saved tensor and workspace is a torch tensor), the stream, and the
+autograd graph; all arithmetic runs in the hand-written HIP kernels.  There is no fallback path: tensors must
+live on a GPU and the shared library must be present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.DWN_F32, torch.bfloat16: L.DWN_BF16}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device: torch.device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"sensorium_amd.{what}: tensors must be on a GPU (got {t.device}); "
+                           "the HIP path has no CPU fallback")
+
+
+def _bn_struct(bn: torch.nn.modules.batchnorm._BatchNorm, coef: torch.Tensor, dgamma=None, dbeta=None) -> L.BN:
+    s = L.BN()
+    s.gamma = bn.weight.data_ptr()
+    s.beta = bn.bias.data_ptr()
+    s.running_mean = bn.running_mean.data_ptr()
+    s.running_var = bn.running_var.data_ptr()
+    s.num_batches_tracked = bn.num_batches_tracked.data_ptr()
+    s.coef = coef.data_ptr()
+    s.dgamma = _ptr(dgamma)
+    s.dbeta = _ptr(dbeta)
+    return s
+
+
+def _check_bn(bn):
+    if bn.momentum is None or not bn.affine or not bn.track_running_stats:
+        raise RuntimeError("sensorium_amd: BatchNorm must be affine with running stats and a fixed momentum")
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------------
+# index maps / positional-encoding tables (host side, cached by the modules)
+# ------------------------------------------------------------------------------------------------
+def nearest_src_index(out_size: int, in_size: int) -> np.ndarray:
+    """F.interpolate(mode='nearest') source index (reference: dwiseneuro.py:127-129)."""
+    scale = np.float32(in_size) / np.float32(out_size)
+    src = np.floor(np.arange(out_size, dtype=np.float32) * scale).astype(np.int64)
+    return np.minimum(src, in_size - 1).astype(np.int32)
+
+
+def inverse_index(src: np.ndarray, in_size: int) -> np.ndarray:
+    inv = np.full(in_size, -1, dtype=np.int32)
+    inv[src] = np.arange(len(src), dtype=np.int32)
+    if len(np.unique(src)) != len(src):
+        raise RuntimeError("nearest-neighbour shortcut map is not injective (stride < 1?)")
+    return inv
+
+
+def pe_axis_tables(channels: int, inv_freq: torch.Tensor, t: int, h: int, w: int):
+    """Separable positional-encoding tables PT[t][C], PH[h][C], PW[w][C] (reference: dwiseneuro.py:163-182):
+    enc[c](t,h,w) = PT[t][c] + PH[h][c] + PW[w][c] where every channel depends on exactly one axis."""
+    ch = int(math.ceil(channels / 6) * 2)
+    if ch % 2:
+        ch += 1
+    inv = inv_freq.detach().float().cpu()
+    tabs = []
+    for axis, size in enumerate((t, h, w)):
+        arg = inv[:, None] * torch.arange(size).float()[None, :]
+        emb = torch.cat([arg.sin(), arg.cos()], dim=0)              # [ch, size]
+        tab = torch.zeros(size, channels, dtype=torch.float32)
+        lo = axis * ch
+        n = max(0, min(ch, channels - lo))
+        if n > 0:
+            tab[:, lo:lo + n] = emb[:n].t()
+        tabs.append(tab.contiguous())
+    return tabs
+
+
+# ------------------------------------------------------------------------------------------------
+# stem
+# ------------------------------------------------------------------------------------------------
+class StemFn(torch.autograd.Function):
+    """Conv3d(C_in->C0, 1x1x1, bias=False) + BatchNorm3d on the NCDHW fp32 input (dwiseneuro.py:306-309).
+    Returns the channels-last activation [B,T,H,W,C0] in the compute dtype."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, mod, dtype):
+        _require_gpu(x, "StemFn")
+        conv, bn = mod.stem[0], mod.stem[1].bn
+        _check_bn(bn)
+        x = x.contiguous().float()
+        B, Cin, T, H, W = x.shape
+        C0 = weight.shape[0]
+        dev = x.device
+        y0 = torch.empty(B, T, H, W, C0, dtype=dtype, device=dev)
+        out = torch.empty_like(y0)
+        coef = torch.empty(4 * C0, dtype=torch.float32, device=dev)
+        a = L.StemArgs()
+        a.dtype = _DT[dtype]; a.training = int(bn.training); a.B = B; a.Cin = Cin; a.C0 = C0; a.S = T * H * W
+        a.eps = bn.eps; a.momentum = bn.momentum
+        a.x = x.data_ptr(); a.w = weight.data_ptr(); a.bn = _bn_struct(bn, coef)
+        a.y0 = y0.data_ptr(); a.out = out.data_ptr()
+        ws = _ws(L.lib.dwn_stem_workspace_bytes(C.byref(a)), dev)
+        a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
+        L.check(L.lib.dwn_stem_forward(C.byref(a), dev.index, _stream(dev)), "dwn_stem_forward")
+        ctx.mod = mod; ctx.dtype = dtype; ctx.was_training = bn.training
+        ctx.save_for_backward(x, weight, y0, coef)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, y0, coef = ctx.saved_tensors
+        if not ctx.was_training:
+            raise RuntimeError("sensorium_amd: backward through eval-mode BatchNorm is not built")
+        bn = ctx.mod.stem[1].bn
+        dev = x.device
+        B, Cin, T, H, W = x.shape
+        C0 = weight.shape[0]
+        dout = dout.contiguous()
+        dw = torch.zeros(C0, Cin, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(C0, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C0, dtype=torch.float32, device=dev)
+        a = L.StemArgs()
+        a.dtype = _DT[ctx.dtype]; a.training = 1; a.B = B; a.Cin = Cin; a.C0 = C0; a.S = T * H * W
+        a.eps = bn.eps; a.momentum = bn.momentum
+        a.x = x.data_ptr(); a.w = weight.data_ptr(); a.bn = _bn_struct(bn, coef, dgamma, dbeta)
+        a.y0 = y0.data_ptr(); a.dout = dout.data_ptr(); a.dw = dw.data_ptr()
+        ws = _ws(L.lib.dwn_stem_workspace_bytes(C.byref(a)), dev)
+        a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
+        L.check(L.lib.dwn_stem_backward(C.byref(a), dev.index, _stream(dev)), "dwn_stem_backward")
+        return None, dw.view_as(weight), dgamma, dbeta, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# PositionalEncoding3d + InvertedResidual3d
+# ------------------------------------------------------------------------------------------------
+_BLOCK_PARAMS = ("w_pw", "g1", "b1", "w_dws", "g2", "b2", "w_dwt", "g3", "b3", "se_wr", "se_br", "se_we", "se_be",
+                 "w_pwl", "g4", "b4", "gsc", "bsc")
+
+
+def _block_args(blk, geom, x, dtype, training, coefs, saved, drop_scale):
+    """Fill the fields shared by forward and backward."""
+    B, T, Hin, Win, Cin = x.shape
+    a = L.BlockArgs()
+    a.dtype = _DT[dtype]; a.training = int(training)
+    a.B = B; a.T = T; a.Hin = Hin; a.Win = Win
+    a.Hout = (Hin - 1) // blk.spatial_stride + 1
+    a.Wout = (Win - 1) // blk.spatial_stride + 1
+    a.Cin = Cin; a.Cmid = blk.mid_features; a.Cout = blk.out_features
+    a.stride = blk.spatial_stride; a.ks = blk.spatial_kernel; a.kt = blk.temporal_kernel
+    a.se_r = blk.se.conv_reduce.out_channels
+    bn1 = blk.conv_pw[1].bn
+    a.eps = bn1.eps; a.momentum = bn1.momentum
+    a.x = x.data_ptr()
+    pe_t, pe_h, pe_w, hsrc, wsrc, hinv, winv = geom
+    a.pe_t = pe_t.data_ptr(); a.pe_h = pe_h.data_ptr(); a.pe_w = pe_w.data_ptr()
+    a.hsrc = hsrc.data_ptr(); a.wsrc = wsrc.data_ptr(); a.hinv = hinv.data_ptr(); a.winv = winv.data_ptr()
+    a.w_pw = blk.conv_pw[0].weight.data_ptr()
+    a.w_dws = blk.spat_covn_dw[0].weight.data_ptr()
+    a.w_dwt = blk.temp_covn_dw[0].weight.data_ptr()
+    a.w_pwl = blk.conv_pwl[0].weight.data_ptr()
+    a.se_wr = blk.se.conv_reduce.weight.data_ptr(); a.se_br = blk.se.conv_reduce.bias.data_ptr()
+    a.se_we = blk.se.conv_expand.weight.data_ptr(); a.se_be = blk.se.conv_expand.bias.data_ptr()
+    a.drop_scale = _ptr(drop_scale)
+    a.se_pmean = saved["pmean"].data_ptr(); a.se_hidpre = saved["hidpre"].data_ptr()
+    a.se_gate = saved["gate"].data_ptr()
+    return a
+
+
+class BlockFn(torch.autograd.Function):
+    """x -> InvertedResidual3d(x + PositionalEncoding3d) (dwiseneuro.py:136-144, 184-192), channels-last."""
+
+    @staticmethod
+    def forward(ctx, x, drop_scale, blk, geom, dtype, *params):
+        _require_gpu(x, "BlockFn")
+        x = x.contiguous()
+        dev = x.device
+        B, T, Hin, Win, Cin = x.shape
+        s = blk.spatial_stride
+        Hout, Wout = (Hin - 1) // s + 1, (Win - 1) // s + 1
+        Cmid, Cout = blk.mid_features, blk.out_features
+        bns = blk.bn_modules()
+        for bn in bns:
+            _check_bn(bn)
+        training = bns[0].training
+        f32 = dict(dtype=torch.float32, device=dev)
+        y1 = torch.empty(B, T, Hin, Win, Cmid, dtype=dtype, device=dev)
+        y2 = torch.empty(B, T, Hout, Wout, Cmid, dtype=dtype, device=dev)
+        y3 = torch.empty_like(y2)
+        y4 = torch.empty(B, T, Hout, Wout, Cout, dtype=dtype, device=dev)
+        out = torch.empty_like(y4)
+        coefs = [torch.empty(4 * c, **f32) for c in (Cmid, Cmid, Cmid, Cout, Cout)]
+        R = blk.se.conv_reduce.out_channels
+        saved = dict(pmean=torch.empty(B, Cmid, **f32), hidpre=torch.empty(B, R, **f32),
+                     gate=torch.empty(B, Cmid, **f32))
+        a = _block_args(blk, geom, x, dtype, training, coefs, saved, drop_scale)
+        a.out = out.data_ptr()
+        a.y1 = y1.data_ptr(); a.y2 = y2.data_ptr(); a.y3 = y3.data_ptr(); a.y4 = y4.data_ptr()
+        a.bn1, a.bn2, a.bn3, a.bn4, a.bnsc = (_bn_struct(bn, cf) for bn, cf in zip(bns, coefs))
+        ws = _ws(L.lib.dwn_block_workspace_bytes(C.byref(a), 0), dev)
+        a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
+        L.check(L.lib.dwn_block_forward(C.byref(a), dev.index, _stream(dev)), "dwn_block_forward")
+        ctx.blk = blk; ctx.geom = geom; ctx.dtype = dtype; ctx.was_training = training
+        if getattr(blk, "_capture", False):        # test hook: expose the raw intermediates
+            blk._captured = dict(y1=y1, y2=y2, y3=y3, y4=y4, coefs=coefs, **saved)
+        ctx.has_drop = drop_scale is not None
+        tensors = [x, y1, y2, y3, y4, *coefs, saved["pmean"], saved["hidpre"], saved["gate"]]
+        if drop_scale is not None:
+            tensors.append(drop_scale)
+        ctx.save_for_backward(*tensors)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.was_training:
+            raise RuntimeError("sensorium_amd: backward through eval-mode BatchNorm is not built")
+        blk, dtype = ctx.blk, ctx.dtype
+        t = ctx.saved_tensors
+        x, y1, y2, y3, y4 = t[:5]
+        coefs = list(t[5:10])
+        saved = dict(pmean=t[10], hidpre=t[11], gate=t[12])
+        drop_scale = t[13] if ctx.has_drop else None
+        dev = x.device
+        dout = dout.contiguous()
+        B, T, Hin, Win, Cin = x.shape
+        Hout, Wout = y2.shape[2], y2.shape[3]
+        Cmid, Cout = blk.mid_features, blk.out_features
+        f32 = dict(dtype=torch.float32, device=dev)
+        a = _block_args(blk, ctx.geom, x, dtype, True, coefs, saved, drop_scale)
+        a.y1 = y1.data_ptr(); a.y2 = y2.data_ptr(); a.y3 = y3.data_ptr(); a.y4 = y4.data_ptr()
+        bns = blk.bn_modules()
+        dg = [torch.empty(c, **f32) for c in (Cmid, Cmid, Cmid, Cout, Cout)]
+        db = [torch.empty(c, **f32) for c in (Cmid, Cmid, Cmid, Cout, Cout)]
+        a.bn1, a.bn2, a.bn3, a.bn4, a.bnsc = (_bn_struct(bn, cf, g_, b_) for bn, cf, g_, b_ in zip(bns, coefs, dg, db))
+        m_in, m_out = B * T * Hin * Win, B * T * Hout * Wout
+        buf_a = torch.empty(max(m_in, m_out) * Cmid, dtype=dtype, device=dev)
+        buf_b = torch.empty(m_out * Cmid, dtype=dtype, device=dev)
+        dy4 = torch.empty(m_out * Cout, dtype=dtype, device=dev)
+        da0 = torch.empty(m_in * Cin, dtype=dtype, device=dev)
+        dx = torch.empty_like(x)
+        R = blk.se.conv_reduce.out_channels
+        dw_pw = torch.zeros(Cmid, Cin, **f32)
+        dw_dws = torch.zeros(Cmid, blk.spatial_kernel * blk.spatial_kernel, **f32)
+        dw_dwt = torch.zeros(Cmid, blk.temporal_kernel, **f32)
+        dw_pwl = torch.zeros(Cout, Cmid, **f32)
+        dse_wr = torch.empty(R, Cmid, **f32); dse_br = torch.empty(R, **f32)
+        dse_we = torch.empty(Cmid, R, **f32); dse_be = torch.empty(Cmid, **f32)
+        a.dout = dout.data_ptr(); a.dx = dx.data_ptr()
+        a.buf_a = buf_a.data_ptr(); a.buf_b = buf_b.data_ptr(); a.dy4 = dy4.data_ptr(); a.da0 = da0.data_ptr()
+        a.dw_pw = dw_pw.data_ptr(); a.dw_dws = dw_dws.data_ptr(); a.dw_dwt = dw_dwt.data_ptr()
+        a.dw_pwl = dw_pwl.data_ptr()
+        a.dse_wr = dse_wr.data_ptr(); a.dse_br = dse_br.data_ptr(); a.dse_we = dse_we.data_ptr()
+        a.dse_be = dse_be.data_ptr()
+        ws = _ws(L.lib.dwn_block_workspace_bytes(C.byref(a), 1), dev)
+        a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
+        L.check(L.lib.dwn_block_backward(C.byref(a), dev.index, _stream(dev)), "dwn_block_backward")
+        grads = (dw_pw.view_as(blk.conv_pw[0].weight), dg[0], db[0],
+                 dw_dws.view_as(blk.spat_covn_dw[0].weight), dg[1], db[1],
+                 dw_dwt.view_as(blk.temp_covn_dw[0].weight), dg[2], db[2],
+                 dse_wr.view_as(blk.se.conv_reduce.weight), dse_br,
+                 dse_we.view_as(blk.se.conv_expand.weight), dse_be,
+                 dw_pwl.view_as(blk.conv_pwl[0].weight), dg[3], db[3], dg[4], db[4])
+        return (dx, None, None, None, None) + grads
+
+
+# ------------------------------------------------------------------------------------------------
+# pool
+# ------------------------------------------------------------------------------------------------
+class PoolFn(torch.autograd.Function):
+    """AdaptiveAvgPool3d((None,1,1)) + squeeze (dwiseneuro.py:374,400): [B,T,H,W,C] -> [B,T,C]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x, "PoolFn")
+        x = x.contiguous()
+        B, T, H, W, Cc = x.shape
+        out = torch.empty(B, T, Cc, dtype=x.dtype, device=x.device)
+        a = L.PoolArgs()
+        a.dtype = _DT[x.dtype]; a.BT = B * T; a.HW = H * W; a.C = Cc; a.x = x.data_ptr(); a.out = out.data_ptr()
+        L.check(L.lib.dwn_pool_forward(C.byref(a), x.device.index, _stream(x.device)), "dwn_pool_forward")
+        ctx.shape = (B, T, H, W, Cc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, H, W, Cc = ctx.shape
+        dout = dout.contiguous()
+        dx = torch.empty(B, T, H, W, Cc, dtype=dout.dtype, device=dout.device)
+        a = L.PoolArgs()
+        a.dtype = _DT[dout.dtype]; a.BT = B * T; a.HW = H * W; a.C = Cc; a.dout = dout.data_ptr(); a.dx = dx.data_ptr()
+        L.check(L.lib.dwn_pool_backward(C.byref(a), dout.device.index, _stream(dout.device)), "dwn_pool_backward")
+        return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# cortex ShuffleLayer
+# ------------------------------------------------------------------------------------------------
+class CortexFn(torch.autograd.Function):
+    """ShuffleLayer.forward (dwiseneuro.py:228-234) on [B,T,C_in] -> [B,T,C]."""
+
+    @staticmethod
+    def forward(ctx, x, drop_scale, layer, dtype, weight, g, b, gsc, bsc):
+        _require_gpu(x, "CortexFn")
+        x = x.contiguous()
+        dev = x.device
+        B, T, Cin = x.shape
+        Cc = layer.out_features
+        bn, bnsc = layer.bn.bn, layer.bn_sc.bn
+        _check_bn(bn); _check_bn(bnsc)
+        training = bn.training
+        y = torch.empty(B, T, Cc, dtype=dtype, device=dev)
+        out = torch.empty_like(y)
+        coef = torch.empty(4 * Cc, dtype=torch.float32, device=dev)
+        coefsc = torch.empty(4 * Cc, dtype=torch.float32, device=dev)
+        a = L.CortexArgs()
+        a.dtype = _DT[dtype]; a.training = int(training); a.B = B; a.T = T; a.Cin = Cin; a.C = Cc
+        a.groups = layer.groups; a.eps = bn.eps; a.momentum = bn.momentum
+        a.x = x.data_ptr(); a.out = out.data_ptr(); a.y = y.data_ptr(); a.w = weight.data_ptr()
+        a.bn = _bn_struct(bn, coef); a.bnsc = _bn_struct(bnsc, coefsc); a.drop_scale = _ptr(drop_scale)
+        ws = _ws(L.lib.dwn_cortex_workspace_bytes(C.byref(a), 0), dev)
+        a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
+        L.check(L.lib.dwn_cortex_forward(C.byref(a), dev.index, _stream(dev)), "dwn_cortex_forward")
+        ctx.layer = layer; ctx.dtype = dtype; ctx.was_training = training; ctx.has_drop = drop_scale is not None
+        tensors = [x, y, coef, coefsc, weight]
+        if drop_scale is not None:
+            tensors.append(drop_scale)
+        ctx.save_for_backward(*tensors)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.was_training:
+            raise RuntimeError("sensorium_amd: backward through eval-mode BatchNorm is not built")
+        layer, dtype = ctx.layer, ctx.dtype
+        t = ctx.saved_tensors
+        x, y, coef, coefsc, weight = t[:5]
+        drop_scale = t[5] if ctx.has_drop else None
+        dev = x.device
+        dout = dout.contiguous()
+        B, T, Cin = x.shape
+        Cc = layer.out_features
+        bn, bnsc = layer.bn.bn, layer.bn_sc.bn
+        f32 = dict(dtype=torch.float32, device=dev)
+        dgm, dbm, dgs, dbs = (torch.empty(Cc, **f32) for _ in range(4))
+        dw = torch.zeros(Cc, Cin // layer.groups, **f32)
+        dx = torch.empty_like(x)
+        a = L.CortexArgs()
+        a.dtype = _DT[dtype]; a.training = 1; a.B = B; a.T = T; a.Cin = Cin; a.C = Cc
+        a.groups = layer.groups; a.eps = bn.eps; a.momentum = bn.momentum
+        a.x = x.data_ptr(); a.y = y.data_ptr(); a.w = weight.data_ptr()
+        a.bn = _bn_struct(bn, coef, dgm, dbm); a.bnsc = _bn_struct(bnsc, coefsc, dgs, dbs)
+        a.drop_scale = _ptr(drop_scale)
+        a.dout = dout.data_ptr(); a.dx = dx.data_ptr(); a.dw = dw.data_ptr()
+        ws = _ws(L.lib.dwn_cortex_workspace_bytes(C.byref(a), 1), dev)
+        a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
+        L.check(L.lib.dwn_cortex_backward(C.byref(a), dev.index, _stream(dev)), "dwn_cortex_backward")
+        return dx, None, None, None, dw.view_as(weight), dgm, dbm, dgs, dbs
+
+
+# ------------------------------------------------------------------------------------------------
+# readout
+# ------------------------------------------------------------------------------------------------
+class ReadoutFn(torch.autograd.Function):
+    """Readout.forward (dwiseneuro.py:283-287): Dropout1d -> grouped Conv1d(k=1)+bias -> [:N] -> Softplus(beta).
+    x: [B,T,C] (compute dtype) -> [B,N,T] fp32."""
+
+    @staticmethod
+    def forward(ctx, x, drop_mask, mod, weight, bias):
+        _require_gpu(x, "ReadoutFn")
+        x = x.contiguous()
+        dev = x.device
+        B, T, Cin = x.shape
+        n = mod.out_features
+        out = torch.empty(B, n, T, dtype=torch.float32, device=dev)
+        a = L.ReadoutArgs()
+        a.dtype = _DT[x.dtype]; a.B = B; a.T = T; a.Cin = Cin; a.groups = mod.groups; a.n_out = n
+        a.softplus_beta = mod.softplus_beta
+        a.x = x.data_ptr(); a.w = weight.data_ptr(); a.bias = bias.data_ptr(); a.drop_mask = _ptr(drop_mask)
+        a.out = out.data_ptr()
+        ws = _ws(L.lib.dwn_readout_workspace_bytes(C.byref(a), 0), dev)
+        a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
+        L.check(L.lib.dwn_readout_forward(C.byref(a), dev.index, _stream(dev)), "dwn_readout_forward")
+        ctx.mod = mod; ctx.has_mask = drop_mask is not None
+        tensors = [x, weight, bias, out]
+        if drop_mask is not None:
+            tensors.append(drop_mask)
+        ctx.save_for_backward(*tensors)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod = ctx.mod
+        t = ctx.saved_tensors
+        x, weight, bias, out = t[:4]
+        drop_mask = t[4] if ctx.has_mask else None
+        dev = x.device
+        dout = dout.contiguous().float()
+        B, T, Cin = x.shape
+        n = mod.out_features
+        dx = torch.empty_like(x)
+        dw = torch.zeros(weight.shape[0], weight.shape[1], dtype=torch.float32, device=dev)
+        db = torch.zeros(bias.shape[0], dtype=torch.float32, device=dev)
+        a = L.ReadoutArgs()
+        a.dtype = _DT[x.dtype]; a.B = B; a.T = T; a.Cin = Cin; a.groups = mod.groups; a.n_out = n
+        a.softplus_beta = mod.softplus_beta
+        a.x = x.data_ptr(); a.w = weight.data_ptr(); a.bias = bias.data_ptr(); a.drop_mask = _ptr(drop_mask)
+        a.out = out.data_ptr(); a.dout = dout.data_ptr(); a.dx = dx.data_ptr(); a.dw = dw.data_ptr()
+        a.dbias = db.data_ptr()
+        ws = _ws(L.lib.dwn_readout_workspace_bytes(C.byref(a), 1), dev)
+        a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
+        L.check(L.lib.dwn_readout_backward(C.byref(a), dev.index, _stream(dev)), "dwn_readout_backward")
+        return dx, None, None, dw.view_as(weight), db
+
+
+# ------------------------------------------------------------------------------------------------
+# MicePoissonLoss
+# ------------------------------------------------------------------------------------------------
+class PoissonLossFn(torch.autograd.Function):
+    """sum_{b,n,t} w[b] * (x - y*log(x + eps)) for one mouse (losses.py:14-20); w already normalised.
+    The reduction runs in a double accumulator on the device and is returned as an fp32 scalar."""
+
+    @staticmethod
+    def forward(ctx, pred, target, w, eps):
+        _require_gpu(pred, "PoissonLossFn")
+        pred = pred.contiguous().float()
+        target = target.contiguous().float()
+        w = w.contiguous().float()
+        dev = pred.device
+        acc = torch.zeros(1, dtype=torch.float64, device=dev)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        per_sample = pred[0].numel()
+        L.check(L.lib.dwn_poisson_loss_forward(pred.data_ptr(), target.data_ptr(), w.data_ptr(), per_sample,
+                                               pred.numel(), eps, acc.data_ptr(), dev.index, _stream(dev)),
+                "dwn_poisson_loss_forward")
+        L.check(L.lib.dwn_f64_to_f32(acc.data_ptr(), out.data_ptr(), 1, dev.index, _stream(dev)), "dwn_f64_to_f32")
+        ctx.eps = eps
+        ctx.save_for_backward(pred, target, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target, w = ctx.saved_tensors
+        dev = pred.device
+        gscale = gout.contiguous().float()
+        dpred = torch.empty_like(pred)
+        L.check(L.lib.dwn_poisson_loss_backward(pred.data_ptr(), target.data_ptr(), w.data_ptr(),
+                                                gscale.data_ptr(), pred[0].numel(), pred.numel(), ctx.eps,
+                                                dpred.data_ptr(), dev.index, _stream(dev)),
+                "dwn_poisson_loss_backward")
+        return dpred, None, None, None

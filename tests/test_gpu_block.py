@@ -1,0 +1,133 @@
+"""GPU parity of one PositionalEncoding3d + InvertedResidual3d block (forward intermediates, output, input
+gradient, every parameter gradient, BN running statistics) against the CPU oracle — which itself is pinned to
+the reference (src/models/dwiseneuro.py:136-144, 184-192) by tests/golden.
+
+fp32 path: <= 1e-3 relative (north-star tolerance; gradients norm-relative).
+bf16 path: 4e-2 forward / 8e-2 gradients relative L2 (bf16 storage of every activation; stated separately).
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dwiseneuro_oracle as orc  # noqa: E402
+from tests.gpu_helpers import dev, rel  # noqa: E402
+
+
+def make_block(cin, cout, stride, expansion, se_ratio, seed):
+    from sensorium_amd.dwiseneuro import InvertedResidual3d, PositionalEncoding3d
+    torch.manual_seed(seed)
+    blk = InvertedResidual3d(cin, cout, spatial_kernel=3, temporal_kernel=5, spatial_stride=stride,
+                             expansion_ratio=expansion, se_reduce_ratio=se_ratio)
+    pe = PositionalEncoding3d(cin)
+    g = torch.Generator().manual_seed(seed)
+    for name, p in blk.named_parameters():
+        if p.dim() > 1:
+            fan = p[0].numel()
+            p.data = torch.randn(p.shape, generator=g) * (1.5 / math.sqrt(fan))
+        elif "bn" in name and name.endswith("weight"):
+            p.data = torch.rand(p.shape, generator=g) + 0.5
+        else:
+            p.data = torch.randn(p.shape, generator=g) * 0.2
+    for name, b in blk.named_buffers():
+        if name.endswith("running_mean"):
+            b.data = torch.randn(b.shape, generator=g) * 0.1
+        elif name.endswith("running_var"):
+            b.data = torch.rand(b.shape, generator=g) + 0.5
+    return blk, pe
+
+
+CASES = [
+    # cin, cout, stride, exp, se_ratio, B, T, H, W
+    (8, 8, 1, 3, 4, 2, 6, 5, 6),
+    (8, 16, 2, 3, 4, 3, 6, 9, 11),
+    (16, 16, 1, 3, 4, 2, 5, 3, 3),
+    (64, 64, 2, 7, 32, 2, 4, 12, 16),
+    (64, 128, 1, 7, 32, 1, 8, 9, 16),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("drop", [False, True])
+def test_block_train_forward_backward(case, dtype, drop):
+    cin, cout, stride, exp, ser, B, T, H, W = case
+    if drop and cin != 8:
+        pytest.skip("drop-path variant only on the small cases")
+    blk, pe = make_block(cin, cout, stride, exp, ser, seed=cin + stride)
+    sd = {"blk." + k: v.clone() for k, v in blk.state_dict().items()}
+    torch.manual_seed(1)
+    x = torch.randn(B, T, H, W, cin) * 1.5 + 0.3
+    drop_scale = torch.tensor([0.0, 1.25, 1.25][:B]) if drop else None
+
+    # ---- oracle (float64 ground truth on CPU)
+    sd64 = {k: (v.double().requires_grad_(True) if v.is_floating_point() and "running" not in k else v)
+            for k, v in sd.items()}
+    x64 = x.double().requires_grad_(True)
+    taps, new_stats = {}, {}
+    a0 = x64 + orc.pe_table(cin, T, H, W, pe.inv_freq, torch.float64)
+    ref = orc.inverted_residual(a0, "blk", sd64, stride, True, drop_scale, new_stats, taps)
+    gout = torch.randn(ref.shape, generator=torch.Generator().manual_seed(7)).double()
+    (ref * gout).sum().backward()
+
+    # ---- HIP
+    blk = blk.to(dev()).train()
+    pe = pe.to(dev())
+    blk._capture = True
+    xd = x.to(dev()).to(dtype).requires_grad_(True)
+    if drop:
+        blk.drop_path.sample = lambda b, d: drop_scale.to(d)
+    out = blk(xd, pe, dtype)
+    out.backward(gout.to(dev()).to(dtype))
+    torch.cuda.synchronize()
+
+    ft, gt = (1e-3, 1e-3) if dtype == torch.float32 else (4e-2, 8e-2)
+    cap = blk._captured
+    for name in ("y1", "y2", "y3", "y4"):
+        e = rel(cap[name].float(), taps[name])
+        assert e < ft, f"forward intermediate {name}: rel err {e:.3e}"
+    e = rel(out.float(), ref)
+    assert e < ft, f"block output rel err {e:.3e}"
+    # running statistics (momentum 0.1, unbiased variance)
+    for k, v in new_stats.items():
+        mine = blk.state_dict()[k[4:]]
+        if v.is_floating_point():
+            assert rel(mine, v) < (1e-4 if dtype == torch.float32 else 2e-2), k
+        else:
+            assert int(mine) == int(v), k
+    # gradients, in backward-chain order so the first failure localises the bug
+    order = ["conv_pwl.1.bn", "bn_sc.bn", "conv_pwl.0", "se.conv_expand", "se.conv_reduce", "temp_covn_dw.1.bn",
+             "temp_covn_dw.0", "spat_covn_dw.1.bn", "spat_covn_dw.0", "conv_pw.1.bn", "conv_pw.0"]
+    named = dict(blk.named_parameters())
+    gnorm = math.sqrt(sum(float(v.grad.norm()) ** 2 for k, v in sd64.items() if getattr(v, "grad", None) is not None))
+    for prefix in order:
+        for suffix in ("weight", "bias"):
+            key = f"{prefix}.{suffix}"
+            if key not in named:
+                continue
+            g_ref = sd64["blk." + key].grad
+            g_mine = named[key].grad
+            assert g_mine is not None, key
+            err = float((g_mine.double().cpu() - g_ref).norm()) / (float(g_ref.norm()) + 1e-4 * gnorm)
+            assert err < gt, f"grad {key}: rel err {err:.3e}"
+    e = rel(xd.grad.float(), x64.grad)
+    assert e < gt, f"input grad rel err {e:.3e}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_block_eval_forward(dtype):
+    cin, cout, stride, exp, ser, B, T, H, W = CASES[1]
+    blk, pe = make_block(cin, cout, stride, exp, ser, seed=3)
+    sd = {"blk." + k: v.clone().double() if v.is_floating_point() else v.clone() for k, v in blk.state_dict().items()}
+    x = torch.randn(B, T, H, W, cin, generator=torch.Generator().manual_seed(2))
+    a0 = x.double() + orc.pe_table(cin, T, H, W, pe.inv_freq, torch.float64)
+    ref = orc.inverted_residual(a0, "blk", sd, stride, False, None, None)
+    blk = blk.to(dev()).eval()
+    before = {k: v.clone() for k, v in blk.state_dict().items()}
+    with torch.no_grad():
+        out = blk(x.to(dev()).to(dtype), pe.to(dev()), dtype)
+    assert rel(out.float(), ref) < (1e-3 if dtype == torch.float32 else 4e-2)
+    for k, v in blk.state_dict().items():      # eval must not touch the BN buffers
+        assert torch.equal(v, before[k]), k

@@ -1,0 +1,164 @@
+"""GPU parity of the MFMA GEMM kernels (dwn_gemm_nn / dwn_gemm_tn) through the C-ABI.
+
+Reference arithmetic: the 1x1x1 / grouped k=1 convolutions of src/models/dwiseneuro.py:91,118,207,276 are
+row-major GEMMs; the oracle states them as ``x @ W.T`` (oracle.pointwise).  Tolerances: fp32 path 1e-3
+(north star), bf16 storage path 4e-2 relative L2 (inputs are rounded to bf16 on both sides, so the
+observed error is ~1e-3; the bound is the separately stated bf16 tolerance of SURVEY.md §7g).
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.gpu_helpers import dev, load_desc, read_stats, rel, stats_buffer, stream, tol  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def L():
+    import sensorium_amd._lib as lib
+    return lib
+
+
+def _dt(L, dtype):
+    return L.DWN_BF16 if dtype == torch.bfloat16 else L.DWN_F32
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(128, 64, 64), (300, 448, 64), (257, 24, 8), (1000, 128, 448), (64, 256, 1792),
+                                   (513, 896, 128)])
+def test_gemm_nn_plain_with_stats(L, dtype, M, N, K):
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=dev()).to(dtype)
+    b = (torch.randn(N, K, device=dev()) / K ** 0.5).to(dtype)
+    # asymmetric integer-valued check as well (catches swapped row/col maps that random data would hide by tolerance)
+    c = torch.empty(M, N, dtype=dtype, device=dev())
+    st = stats_buffer(N)
+    g = L.GemmNNArgs()
+    g.a = load_desc(L, a, K)
+    g.a_kind = L.LD_PLAIN
+    g.b = b.data_ptr(); g.ldb = K; g.c = c.data_ptr(); g.ldc = N
+    g.M, g.N, g.K, g.groups = M, N, K, 1
+    g.stats = st.data_ptr(); g.stat_nchan = N; g.epi = L.EPI_STORE
+    L.check(L.lib.dwn_gemm_nn(C.byref(g), _dt(L, dtype), 0, stream()), "gemm_nn")
+    torch.cuda.synchronize()
+    ref = a.double() @ b.double().t()
+    assert rel(c, ref) < tol(dtype, 1e-5, 6e-3)
+    s0, s1 = read_stats(st, N)
+    cf = c.double()
+    assert rel(s0, cf.sum(0)) < 1e-4 and rel(s1, (cf * cf).sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_nn_exact_small_integers(L, dtype):
+    """A = I-like / asymmetric B with small integers: exact in both dtypes, catches any transposed tile map."""
+    M, N, K = 256, 128, 64
+    a = torch.zeros(M, K, device=dev())
+    a[torch.arange(M), torch.arange(M) % K] = 1.0
+    a[:, 0] += (torch.arange(M, device=dev()) % 3).float()
+    b = ((torch.arange(N, device=dev())[:, None] * 3 + torch.arange(K, device=dev())[None, :]) % 7 - 3).float()
+    c = torch.empty(M, N, dtype=dtype, device=dev())
+    g = L.GemmNNArgs()
+    a_t, b_t = a.to(dtype), b.to(dtype)
+    g.a = load_desc(L, a_t, K); g.a_kind = L.LD_PLAIN
+    g.b = b_t.data_ptr(); g.ldb = K; g.c = c.data_ptr(); g.ldc = N
+    g.M, g.N, g.K, g.groups = M, N, K, 1
+    L.check(L.lib.dwn_gemm_nn(C.byref(g), _dt(L, dtype), 0, stream()), "gemm_nn")
+    torch.cuda.synchronize()
+    assert torch.equal(c.float(), a @ b.t())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_nn_loaders(L, dtype):
+    """PE, BN+SiLU+gate and BN-backward-affine prologues against plain torch math."""
+    torch.manual_seed(3)
+    B, T, H, W, K, N = 2, 3, 5, 6, 24, 40
+    M = B * T * H * W
+    x = torch.randn(M, K, device=dev()).to(dtype)
+    w = (torch.randn(N, K, device=dev()) / K ** 0.5).to(dtype)
+    pt, ph, pw = (torch.randn(s, K, device=dev()) for s in (T, H, W))
+    out = torch.empty(M, N, dtype=dtype, device=dev())
+
+    def run(desc, kind):
+        g = L.GemmNNArgs()
+        g.a = desc; g.a_kind = kind
+        g.b = w.data_ptr(); g.ldb = K; g.c = out.data_ptr(); g.ldc = N
+        g.M, g.N, g.K, g.groups = M, N, K, 1
+        L.check(L.lib.dwn_gemm_nn(C.byref(g), _dt(L, dtype), 0, stream()), "gemm_nn")
+        torch.cuda.synchronize()
+        return out.clone()
+
+    def rt(v):   # operand rounding of the MFMA input
+        return v.to(dtype).double()
+
+    # PE
+    got = run(load_desc(L, x, K, pe_t=pt, pe_h=ph, pe_w=pw, pT=T, pH=H, pW=W, pe_ld=K), L.LD_PE)
+    enc = (pt[:, None, None, :] + ph[None, :, None, :] + pw[None, None, :, :]).expand(B, T, H, W, K).reshape(M, K)
+    ref = rt(x.float() + enc) @ w.double().t()
+    assert rel(got, ref) < tol(dtype, 1e-5, 6e-3)
+    # BN + SiLU + per-sample gate
+    sc, sh = torch.rand(K, device=dev()) + 0.5, torch.randn(K, device=dev())
+    gate = torch.rand(B, K, device=dev())
+    got = run(load_desc(L, x, K, v1=sc, v2=sh, act=1, gate=gate, gate_ld=K, rows_per_sample=T * H * W), L.LD_BNACT)
+    h = x.float() * sc + sh
+    u = h * torch.sigmoid(h) * gate.repeat_interleave(T * H * W, 0)
+    assert rel(got, rt(u) @ w.double().t()) < tol(dtype, 1e-5, 6e-3)
+    # AFFINE2
+    y = torch.randn(M, K, device=dev()).to(dtype)
+    a1, a2, a3 = (torch.randn(K, device=dev()) for _ in range(3))
+    got = run(load_desc(L, x, K, q=y, v1=a1, v2=a2, v3=a3), L.LD_AFFINE2)
+    v = a1 * x.float() + a2 * y.float() + a3
+    assert rel(got, rt(v) @ w.double().t()) < tol(dtype, 1e-5, 6e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_nn_grouped(L, dtype):
+    torch.manual_seed(5)
+    M, groups, Kg, Ng = 200, 2, 32, 48
+    x = torch.randn(M, groups * Kg, device=dev()).to(dtype)
+    w = (torch.randn(groups * Ng, Kg, device=dev()) / Kg ** 0.5).to(dtype)
+    out = torch.empty(M, groups * Ng, dtype=dtype, device=dev())
+    g = L.GemmNNArgs()
+    g.a = load_desc(L, x, groups * Kg); g.a_kind = L.LD_PLAIN
+    g.b = w.data_ptr(); g.ldb = Kg; g.c = out.data_ptr(); g.ldc = groups * Ng
+    g.M, g.N, g.K, g.groups = M, Ng, Kg, groups
+    L.check(L.lib.dwn_gemm_nn(C.byref(g), _dt(L, dtype), 0, stream()), "gemm_nn")
+    torch.cuda.synchronize()
+    ref = torch.cat([x[:, i * Kg:(i + 1) * Kg].double() @ w[i * Ng:(i + 1) * Ng].double().t() for i in range(groups)], 1)
+    assert rel(out, ref) < tol(dtype, 1e-5, 6e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,R,Cc", [(256, 64, 448), (1000, 448, 64), (333, 24, 8), (4100, 256, 136)])
+def test_gemm_tn(L, dtype, M, R, Cc):
+    torch.manual_seed(M)
+    p = torch.randn(M, R, device=dev()).to(dtype)
+    q = torch.randn(M, Cc, device=dev()).to(dtype)
+    dw = torch.zeros(R, Cc, device=dev())
+    g = L.GemmTNArgs()
+    g.p = load_desc(L, p, R); g.p_kind = L.LD_PLAIN
+    g.q = load_desc(L, q, Cc); g.q_kind = L.LD_PLAIN
+    g.M, g.R, g.Cc = M, R, Cc
+    g.dw = dw.data_ptr(); g.lddw = Cc; g.groups = 1; g.nsplit = 0
+    L.check(L.lib.dwn_gemm_tn(C.byref(g), _dt(L, dtype), 0, stream()), "gemm_tn")
+    torch.cuda.synchronize()
+    ref = p.double().t() @ q.double()
+    assert rel(dw, ref) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_tn_exact(L, dtype):
+    M, R, Cc = 96, 32, 48
+    p = ((torch.arange(M, device=dev())[:, None] * 2 + torch.arange(R, device=dev())[None, :]) % 5 - 2).float()
+    q = ((torch.arange(M, device=dev())[:, None] + 3 * torch.arange(Cc, device=dev())[None, :]) % 7 - 3).float()
+    dw = torch.zeros(R, Cc, device=dev())
+    pt_, qt_ = p.to(dtype), q.to(dtype)
+    g = L.GemmTNArgs()
+    g.p = load_desc(L, pt_, R); g.p_kind = L.LD_PLAIN
+    g.q = load_desc(L, qt_, Cc); g.q_kind = L.LD_PLAIN
+    g.M, g.R, g.Cc = M, R, Cc
+    g.dw = dw.data_ptr(); g.lddw = Cc; g.groups = 1; g.nsplit = 0
+    L.check(L.lib.dwn_gemm_tn(C.byref(g), _dt(L, dtype), 0, stream()), "gemm_tn")
+    torch.cuda.synchronize()
+    assert torch.equal(dw, p.t() @ q)
