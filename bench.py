@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Benchmark of the DwiseNeuro training hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one full ``MouseModel.train_step`` (src/argus_models.py:43-71 semantics) over one batch of
+synthetic clips already resident in HBM: forward, Poisson loss, backward, (N>1: gradient all-reduce over
+RCCL overlapped with backward), fused AdamW step, EMA update.  Workload = BASELINE.json ``configs[1]``:
+configs/true_batch_001.py single-mouse training (expansion 7, 1 readout of 7863 neurons, dropout 0.4, drop-path
+0.1), bf16 storage, B=32 clips of T=32 frames at 36x64 per GPU (weak scaling).
+
+Rank 0 prints ONE JSON line: metric/value/unit (+ ``roofline`` for the dominant kernel family measured live
+with HIP events on the launch stream, and ``cpu_baseline`` = the CPU oracle timed on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+NUM_NEURONS_MOUSE0 = 7863          # src/constants.py:26 (first mouse)
+CORE_FEATURES = (64, 64, 64, 64, 128, 128, 128, 256, 256)
+STRIDES = (2, 1, 1, 1, 2, 1, 1, 2, 1)
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def model_params(expansion=7, readouts=(NUM_NEURONS_MOUSE0,)):
+    return {
+        "nn_module": ("dwiseneuro", {
+            "readout_outputs": tuple(readouts), "in_channels": 5, "core_features": CORE_FEATURES,
+            "spatial_strides": STRIDES, "spatial_kernel": 3, "temporal_kernel": 5, "expansion_ratio": expansion,
+            "se_reduce_ratio": 32, "cortex_features": (1024, 2048, 4096), "groups": 2, "softplus_beta": 0.07,
+            "drop_rate": 0.4, "drop_path_rate": 0.1}),
+        "loss": ("mice_poisson", {"log_input": False, "full": False, "eps": 1e-8}),
+        "optimizer": ("AdamW", {"lr": 3e-4 * 32 / 4, "weight_decay": 0.05}),
+        "amp": True, "iter_size": 1,
+    }
+
+
+def block_shapes(batch, frames, height, width, expansion):
+    """(M_in, M_out, Cmid) per block."""
+    out = []
+    h, w = height, width
+    for c, s in zip(CORE_FEATURES, STRIDES):
+        ho, wo = (h - 1) // s + 1, (w - 1) // s + 1
+        out.append((batch * frames * h * w, batch * frames * ho * wo, c * expansion))
+        h, w = ho, wo
+    return out
+
+
+# algorithmic bytes per *step* of each timed kernel family (read input once + write output once;
+# backward = read x + read dy + write dx), in elements of the storage dtype
+def family_algorithmic_elems(shapes):
+    e = {}
+    e["dws_fwd"] = sum(mi * c + mo * c for mi, mo, c in shapes)
+    e["dwt_fwd"] = sum(2 * mo * c for mi, mo, c in shapes)
+    e["dws_bwd"] = sum(mi * c + mo * c + mi * c for mi, mo, c in shapes)
+    e["dwt_bwd"] = sum(3 * mo * c for mi, mo, c in shapes)
+    return e
+
+
+def cpu_baseline(frames, height, width, expansion):
+    """The CPU oracle (a port: oracle/dwiseneuro_oracle.py, pinned to the reference by tests/golden) timed on this
+    host: one fwd+loss+bwd step on a bounded sample (B=1 clip of the benchmark's T x H x W)."""
+    from oracle import dwiseneuro_oracle as orc
+    import numpy as np
+    orc.DW_IMPL = "library"        # depth-wise convs through torch's conv3d, like the reference's CPU path
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    b = 1
+    sd = orc.make_state_dict(readout_outputs=(NUM_NEURONS_MOUSE0,), expansion_ratio=expansion, seed=0)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and "inv_freq" not in k
+              else v) for k, v in sd.items()}
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.normal(size=(b, 5, frames, height, width)).astype(np.float32) * 40 + 80)
+    target = torch.from_numpy(np.maximum(rng.normal(size=(b, NUM_NEURONS_MOUSE0, frames)), 0).astype(np.float32))
+    w = torch.ones(b, 1)
+
+    def step(xx, tt):
+        preds = orc.forward(sd, xx, strides=STRIDES, readout_outputs=(NUM_NEURONS_MOUSE0,), training=True)
+        loss = orc.mice_poisson_loss(preds, [tt], w[: xx.shape[0]])
+        loss.backward()
+        return float(loss.detach())
+
+    step(x[:1, :, :4], target[:1, :, :4])          # tiny warm-up (thread pool, allocator)
+    t0 = time.perf_counter()
+    step(x, target)
+    dt = time.perf_counter() - t0
+    return {"value": round(b / dt, 4), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"1 fwd+loss+bwd step of the CPU oracle, B={b}, T={frames}, {height}x{width}, expansion "
+                      f"{expansion}, 1 readout, fp32, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--height", type=int, default=36)
+    ap.add_argument("--width", type=int, default=64)
+    ap.add_argument("--expansion", type=int, default=7)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--roofline-family", default="dwt_bwd")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="time every kernel family (adds event overhead)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import sensorium_amd._lib as L
+    from sensorium_amd.argus_models import MouseModel
+    from sensorium_amd.synthetic import make_batch
+
+    params = model_params(args.expansion)
+    params["device"] = str(dev)
+    params["amp"] = args.dtype == "bf16"
+    torch.manual_seed(1234)            # identical init on every rank (GradBuckets also broadcasts rank 0)
+    model = MouseModel(params)
+    # reference init rule (src/utils.py:46-56): conv ~ N(0, sqrt(2/fan_out)), BN weight 1 / bias 0
+    import math
+    for m in model.nn_module.modules():
+        if isinstance(m, (torch.nn.Conv1d, torch.nn.Conv3d)):
+            fan_out = math.prod(m.kernel_size) * m.out_channels // m.groups
+            torch.nn.init.normal_(m.weight, 0, math.sqrt(2.0 / fan_out))
+            if m.bias is not None:
+                torch.nn.init.zeros_(m.bias)
+    model.set_ema(0.999)
+    batch = make_batch(args.batch, args.frames, args.height, args.width, (NUM_NEURONS_MOUSE0,),
+                       seed=20231122 + rank, device=dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.train_step(batch, sync_loss=False)
+    fam_names = L.FAMILIES
+    if args.profile_all:
+        mask = (1 << len(fam_names)) - 1
+    else:
+        mask = 1 << fam_names.index(args.roofline_family)
+    sync()
+    L.check(L.lib.dwn_profile_enable(mask, local_rank), "profile_enable")
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = model.train_step(batch, sync_loss=False)
+    sync()
+    elapsed = time.perf_counter() - t0
+    loss_value = float(last["loss"])
+    import ctypes as C
+    fam_ms = {}
+    for i, name in enumerate(fam_names):
+        if (mask >> i) & 1:
+            ms, n = C.c_double(0), C.c_longlong(0)
+            L.check(L.lib.dwn_profile_collect(i, C.byref(ms), C.byref(n)), "profile_collect")
+            fam_ms[name] = (ms.value, n.value)
+    L.lib.dwn_profile_enable(0, local_rank)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        clips = args.batch * world * args.steps
+        value = clips / elapsed
+        esize = 2 if args.dtype == "bf16" else 4
+        shapes = block_shapes(args.batch, args.frames, args.height, args.width, args.expansion)
+        alg = family_algorithmic_elems(shapes)
+        roof = None
+        fam = args.roofline_family
+        if fam in fam_ms and fam in alg and fam_ms[fam][1] > 0:
+            ms, n = fam_ms[fam]
+            launches_per_step = n / args.steps
+            bytes_per_launch = alg[fam] * esize / launches_per_step
+            avg_ms = ms / n
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            roof = {"kernel": fam, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launches_per_step": launches_per_step, "avg_launch_ms": round(avg_ms, 4),
+                    "algorithmic_bytes_per_launch": int(bytes_per_launch)}
+        out = {
+            "metric": "training clips/sec (DwiseNeuro fwd+bwd+optimizer, B=32 T=32 36x64 per GPU)",
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs/true_batch_001.py single-mouse training (expansion 7, 1 readout x 7863 "
+                                   "neurons, dropout 0.4, drop-path 0.1), AdamW + EMA",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world, "frames": args.frames,
+                       "height": args.height, "width": args.width, "parallelism": f"dp{world}"},
+            "clips_per_s_per_gpu": round(value / world, 2), "loss": round(loss_value, 3),
+            "roofline": roof,
+        }
+        if args.profile_all:
+            out["family_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in fam_ms.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.frames, args.height, args.width, args.expansion)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -210,6 +210,16 @@ typedef struct dwn_tensor_entry {
     long long numel; int is_int64; int pad_;
 } dwn_tensor_entry;
 
+/* opt-in kernel-family timer: HIP events recorded on the launch stream around the block-level kernels.
+ * Used by bench.py for the live roofline measurement; disabled (mask 0) by default. */
+enum {
+    DWN_FAM_PW_FWD = 0, DWN_FAM_DWS_FWD, DWN_FAM_DWT_FWD, DWN_FAM_SE_POOL, DWN_FAM_PWL_FWD, DWN_FAM_RESID_FWD,
+    DWN_FAM_RESID_BWD, DWN_FAM_PWL_DGRAD, DWN_FAM_PWL_WGRAD, DWN_FAM_BN3_REDUCE, DWN_FAM_DWT_BWD, DWN_FAM_DWS_BWD,
+    DWN_FAM_PW_DGRAD, DWN_FAM_PW_WGRAD, DWN_FAM_COUNT
+};
+int dwn_profile_enable(unsigned long long family_mask, int device);
+int dwn_profile_collect(int family, double* total_ms, long long* launches);
+
 int dwn_abi_version(void);
 int dwn_sizeof(const char* struct_name);   /* sizeof of a struct of this header, -1 if unknown (binding self-check) */
 const char* dwn_last_error(void);

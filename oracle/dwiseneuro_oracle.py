@@ -168,10 +168,20 @@ def pointwise(x: Tensor, weight: Tensor) -> Tensor:
     return x @ w2.t()
 
 
+# "stencil": explicit shifted sums (independent restatement, used for parity).  "library": the same op through
+# torch.nn.functional.conv3d — the third-party kernel the reference itself calls — used only as the *fast* CPU
+# baseline in bench.py; tests/test_oracle_golden.py checks the two agree.
+DW_IMPL = "stencil"
+
+
 def dw_spatial(x: Tensor, weight: Tensor, stride: int) -> Tensor:
     """Depth-wise (1,k,k) conv, stride (1,s,s), pad k//2 (dwiseneuro.py:96-100).  x: [B,T,H,W,C]."""
     k = weight.shape[-1]
     p = k // 2
+    if DW_IMPL == "library":
+        y = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3), weight.to(x.dtype), stride=(1, stride, stride),
+                                       padding=(0, p, p), groups=x.shape[-1])
+        return y.permute(0, 2, 3, 4, 1)
     b, t, h, w, c = x.shape
     ho = (h + 2 * p - k) // stride + 1
     wo = (w + 2 * p - k) // stride + 1
@@ -190,6 +200,10 @@ def dw_temporal(x: Tensor, weight: Tensor) -> Tensor:
     """Depth-wise (k,1,1) conv along T, pad k//2 (dwiseneuro.py:105-109).  x: [B,T,H,W,C]."""
     k = weight.shape[2]
     p = k // 2
+    if DW_IMPL == "library":
+        y = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3), weight.to(x.dtype), padding=(p, 0, 0),
+                                       groups=x.shape[-1])
+        return y.permute(0, 2, 3, 4, 1)
     b, t, h, w, c = x.shape
     xp = torch.zeros(b, t + 2 * p, h, w, c, dtype=x.dtype)
     xp[:, p:p + t] = x

@@ -23,6 +23,8 @@ DWN_F32, DWN_BF16 = 0, 1
 DWN_NREP = 32
 LD_PLAIN, LD_PE, LD_BNACT, LD_AFFINE2, LD_DY3 = 0, 1, 2, 3, 4
 EPI_STORE, EPI_READOUT, EPI_DG = 0, 1, 2
+FAMILIES = ("pw_fwd", "dws_fwd", "dwt_fwd", "se_pool", "pwl_fwd", "resid_fwd", "resid_bwd", "pwl_dgrad", "pwl_wgrad",
+            "bn3_reduce", "dwt_bwd", "dws_bwd", "pw_dgrad", "pw_wgrad")
 
 
 class LoadDesc(C.Structure):
@@ -134,6 +136,8 @@ SYMBOLS = {
     "dwn_abi_version": (c_i, []),
     "dwn_sizeof": (c_i, [C.c_char_p]),
     "dwn_last_error": (C.c_char_p, []),
+    "dwn_profile_enable": (c_i, [C.c_ulonglong, c_i]),
+    "dwn_profile_collect": (c_i, [c_i, _P(c_d), _P(c_ll)]),
     "dwn_gemm_nn": (c_i, [_P(GemmNNArgs), c_i, c_i, c_p]),
     "dwn_gemm_tn": (c_i, [_P(GemmTNArgs), c_i, c_i, c_p]),
     "dwn_dw_spatial_fwd": (c_i, [_P(DwSpatialFwdArgs), c_i, c_i, c_p]),

@@ -1,0 +1,166 @@
+"""MouseModel: the train / val / predict step of the reference's ``src/argus_models.py`` (an ``argus.Model``
+subclass) restated without the third-party ``argus`` engine (not installable offline).
+
+Same constructor contract (``params`` dict with ``nn_module``/``loss``/``optimizer``/``device``/``amp``/
+``iter_size`` exactly as configs/true_batch_001.py:20-61), same method names, arguments, return dict and
+numerics-relevant order of operations (argus_models.py:43-99):
+
+    train_step: train() -> zero_grad -> per chunk [to device, autocast, distill targets, forward, loss/iter_size,
+                backward, loss.item()] -> optimizer step -> EMA update -> {'prediction','target','loss'}
+
+MI355X-specific differences, none of which change results: autocast selects bf16 (no GradScaler needed — the
+scaler object is kept, disabled, for API compatibility); AdamW is the fused multi-tensor HIP kernel with the
+parameter EMA folded in; the distillation target fill (argus_models.py:37-41) is vectorised with ``where``
+instead of a python loop over ``argwhere``; under ``torch.distributed`` gradients are all-reduced through
+``GradBuckets`` while backward is still running.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from .ddp import GradBuckets
+from .dwiseneuro import DwiseNeuro
+from .ema import ModelEma
+from .losses import MicePoissonLoss
+from .optim import FusedAdamWEma
+
+
+def deep_to(obj, device, non_blocking: bool = False):
+    if torch.is_tensor(obj):
+        return obj.to(device, non_blocking=non_blocking)
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(deep_to(o, device, non_blocking) for o in obj)
+    if isinstance(obj, dict):
+        return {k: deep_to(v, device, non_blocking) for k, v in obj.items()}
+    return obj
+
+
+def deep_detach(obj):
+    if torch.is_tensor(obj):
+        return obj.detach()
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(deep_detach(o) for o in obj)
+    return obj
+
+
+def deep_chunk(obj, chunks: int):
+    if chunks == 1:
+        return [obj]
+    if torch.is_tensor(obj):
+        return list(torch.chunk(obj, chunks, dim=0))
+    if isinstance(obj, (list, tuple)):
+        parts = [deep_chunk(o, chunks) for o in obj]
+        return [type(obj)(p[i] for p in parts) for i in range(chunks)]
+    raise TypeError(type(obj))
+
+
+class MouseModel:
+    nn_module = {"dwiseneuro": DwiseNeuro}
+    loss = {"mice_poisson": MicePoissonLoss}
+    optimizer = {"AdamW": FusedAdamWEma}
+
+    def __init__(self, params: dict):
+        self.params = params
+        name, kwargs = params["nn_module"]
+        self.device = torch.device(params.get("device", "cuda:0"))
+        self.nn_module = self.nn_module[name](**kwargs).to(self.device)
+        lname, lkwargs = params.get("loss", ("mice_poisson", {}))
+        self.loss = self.loss[lname](**lkwargs)
+        self.iter_size = int(params.get("iter_size", 1))
+        self.amp = bool(params.get("amp", False))
+        self.grad_scaler = torch.amp.GradScaler("cuda", enabled=False)   # bf16 needs no loss scaling
+        self.model_ema: Optional[ModelEma] = None
+        self.distill_model: Optional[torch.nn.Module] = None
+        self.distill_ratio: float = 0.0
+        self._opt_spec = params.get("optimizer", ("AdamW", {"lr": 1e-3}))
+        self.optimizer = None
+        self.buckets: Optional[GradBuckets] = None
+        self.prediction_transform = lambda x: x
+
+    # -- setup ------------------------------------------------------------------------------------------
+    def set_ema(self, decay: float):
+        """train.py:53 — must be called before the first step; the parameter EMA rides in the optimizer kernel."""
+        self.model_ema = ModelEma(self.nn_module, decay=decay)
+        self.optimizer = None
+
+    def _ensure_optimizer(self):
+        if self.optimizer is not None:
+            return
+        oname, okwargs = self._opt_spec
+        params = [p for p in self.nn_module.parameters() if p.requires_grad]
+        ema_params = None
+        decay = 0.999
+        if self.model_ema is not None:
+            ema_params = [p for p in self.model_ema.ema.parameters()]
+            decay = self.model_ema.decay
+        self.optimizer = MouseModel.optimizer[oname](params, ema_params=ema_params, ema_decay=decay, **okwargs)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.buckets = GradBuckets(self.nn_module)
+
+    def train(self):
+        self.nn_module.train()
+
+    def eval(self):
+        self.nn_module.eval()
+
+    # -- argus_models.py:31-41 -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def add_distill_predictions(self, input, target):
+        if self.distill_model is None or not self.distill_ratio:
+            return
+        distill_prediction = self.distill_model(input)
+        target_tensors, mice_weights = target
+        distill_mask = mice_weights == 0.0
+        distill_weight = (self.distill_ratio / (1.0 - self.distill_ratio) * mice_weights.sum() / distill_mask.sum())
+        for m, pred in enumerate(distill_prediction):
+            sel = distill_mask[:, m]
+            target_tensors[m].copy_(torch.where(sel[:, None, None], pred.to(target_tensors[m].dtype),
+                                                target_tensors[m]))
+        mice_weights.copy_(torch.where(distill_mask, distill_weight.to(mice_weights.dtype), mice_weights))
+
+    # -- argus_models.py:43-71 -----------------------------------------------------------------------------
+    def train_step(self, batch, state=None, sync_loss: bool = True) -> dict:
+        self._ensure_optimizer()
+        self.train()
+        if self.buckets is not None:
+            self.buckets.zero_grad()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+        loss_value = 0
+        for chunk_batch in deep_chunk(batch, self.iter_size):
+            input, target = deep_to(chunk_batch, self.device, non_blocking=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
+                self.add_distill_predictions(input, target)
+                prediction = self.nn_module(input)
+                loss = self.loss(prediction, target)
+                loss = loss / self.iter_size
+            loss.backward()
+            loss_value = loss_value + (loss.item() if sync_loss else loss.detach())
+        if self.buckets is not None:
+            self.buckets.finish()
+        self.optimizer.step()
+        if self.model_ema is not None:
+            self.model_ema.update(self.nn_module, skip_parameters=True)
+        return {"prediction": self.prediction_transform(deep_detach(prediction)), "target": deep_detach(target),
+                "loss": loss_value}
+
+    # -- argus_models.py:73-87 -----------------------------------------------------------------------------
+    def val_step(self, batch, state=None) -> dict:
+        self.eval()
+        with torch.no_grad():
+            input, target = deep_to(batch, self.device, non_blocking=True)
+            module = self.nn_module if self.model_ema is None else self.model_ema.ema
+            prediction = module(input)
+            loss = self.loss(prediction, target)
+            return {"prediction": self.prediction_transform(prediction), "target": target, "loss": loss.item()}
+
+    # -- argus_models.py:89-99 -----------------------------------------------------------------------------
+    def predict(self, input, mouse_index: Optional[int] = None):
+        with torch.no_grad():
+            self.eval()
+            input = deep_to(input, self.device)
+            module = self.nn_module if self.model_ema is None else self.model_ema.ema
+            return self.prediction_transform(module(input, mouse_index))

@@ -14,6 +14,33 @@ int dwn_set_error(int code, const char* msg) {
 }
 
 #define TRY(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
+
+// ---- opt-in kernel-family timer (HIP events on the launch stream).  Off by default: zero cost and no state.
+// bench.py turns it on for the kernel family it reports a roofline for (dwn_profile_enable / _collect).
+#include <vector>
+namespace {
+struct ProfFam { std::vector<hipEvent_t> beg, end; size_t used = 0; };
+static unsigned long long g_prof_mask = 0;
+static ProfFam g_prof[DWN_FAM_COUNT];
+constexpr size_t PROF_POOL = 8192;
+struct ProfScope {
+    int fam; hipStream_t s; bool on;
+    ProfScope(int f, hipStream_t st) : fam(f), s(st), on(false) {
+        if (!((g_prof_mask >> f) & 1ull)) return;
+        ProfFam& p = g_prof[f];
+        if (p.used >= p.beg.size()) return;
+        on = true;
+        (void)hipEventRecord(p.beg[p.used], s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        ProfFam& p = g_prof[fam];
+        (void)hipEventRecord(p.end[p.used], s);
+        p.used++;
+    }
+};
+}  // namespace
+#define PROF(fam, call) do { ProfScope ps__((fam), s); TRY(call); } while (0)
 #define HIP_TRY(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return dwn_set_error((int)e__, hipGetErrorString(e__)); } while (0)
 #define ENTER(device) do { g_err[0] = 0; HIP_TRY(hipSetDevice(device)); } while (0)
 
@@ -160,6 +187,34 @@ int dwn_sizeof(const char* name) {
 }
 const char* dwn_last_error(void) { return g_err; }
 
+int dwn_profile_enable(unsigned long long family_mask, int device) {
+    ENTER(device);
+    for (int f = 0; f < DWN_FAM_COUNT; ++f) {
+        ProfFam& p = g_prof[f];
+        p.used = 0;
+        if (((family_mask >> f) & 1ull) && p.beg.empty()) {
+            p.beg.resize(PROF_POOL); p.end.resize(PROF_POOL);
+            for (size_t i = 0; i < PROF_POOL; ++i) { HIP_TRY(hipEventCreate(&p.beg[i])); HIP_TRY(hipEventCreate(&p.end[i])); }
+        }
+    }
+    g_prof_mask = family_mask;
+    return 0;
+}
+int dwn_profile_collect(int family, double* total_ms, long long* launches) {
+    if (family < 0 || family >= DWN_FAM_COUNT) return dwn_set_error(-2, "profile_collect: bad family");
+    ProfFam& p = g_prof[family];
+    double tot = 0;
+    for (size_t i = 0; i < p.used; ++i) {
+        HIP_TRY(hipEventSynchronize(p.end[i]));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, p.beg[i], p.end[i]));
+        tot += ms;
+    }
+    *total_ms = tot; *launches = (long long)p.used;
+    p.used = 0;
+    return 0;
+}
+
 int dwn_gemm_nn(const dwn_gemm_nn_args* a, int dtype, int device, void* stream) {
     ENTER(device);
     return launch_gemm_nn(*a, dtype, (hipStream_t)stream);
@@ -259,7 +314,7 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     {
         GemmNN g = nn_base(xin, LD_PE, w.wpw, a.Cin, a.y1, a.Cmid, (int)Min, a.Cmid, a.Cin, 1);
         g.stats = tr ? w.st1 : nullptr; g.stat_nchan = a.Cmid;
-        TRY(launch_gemm_nn(g, dt, s));
+        PROF(DWN_FAM_PW_FWD, launch_gemm_nn(g, dt, s));
     }
     TRY(bn_finalize(w.st1, a.Cmid, (double)Min, a.bn1, a.Cmid, tr, a.momentum, a.eps, s));
     // spat_covn_dw (:96-102)
@@ -268,7 +323,7 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
         d.in = ld_bnact(a.y1, a.Cmid, a.bn1.coef, a.Cmid, 1, nullptr, 0, 1);
         d.w = w.wdws; d.out = a.y2; d.planes = a.B * a.T; d.Hin = a.Hin; d.Win = a.Win; d.Hout = a.Hout;
         d.Wout = a.Wout; d.C = a.Cmid; d.stride = a.stride; d.ks = a.ks; d.stats = tr ? w.st2 : nullptr;
-        TRY(launch_dw_spatial_fwd(d, dt, s));
+        PROF(DWN_FAM_DWS_FWD, launch_dw_spatial_fwd(d, dt, s));
     }
     TRY(bn_finalize(w.st2, a.Cmid, (double)Mout, a.bn2, a.Cmid, tr, a.momentum, a.eps, s));
     // temp_covn_dw (:105-111)
@@ -277,12 +332,12 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
         d.in = ld_bnact(a.y2, a.Cmid, a.bn2.coef, a.Cmid, 1, nullptr, 0, 1);
         d.w = w.wdwt; d.out = a.y3; d.B = a.B; d.T = a.T; d.HW = a.Hout * a.Wout; d.C = a.Cmid; d.kt = a.kt;
         d.stats = tr ? w.st3 : nullptr;
-        TRY(launch_dw_temporal_fwd(d, dt, s));
+        PROF(DWN_FAM_DWT_FWD, launch_dw_temporal_fwd(d, dt, s));
     }
     TRY(bn_finalize(w.st3, a.Cmid, (double)Mout, a.bn3, a.Cmid, tr, a.momentum, a.eps, s));
     // se (:38-43)
     LoadDesc z3 = ld_bnact(a.y3, a.Cmid, a.bn3.coef, a.Cmid, 1, nullptr, 0, S_out);
-    TRY(k_se_pool(z3, a.B, a.Cmid, S_out, w.pooled, dt, s));
+    PROF(DWN_FAM_SE_POOL, k_se_pool(z3, a.B, a.Cmid, S_out, w.pooled, dt, s));
     TRY(k_se_mlp_fwd(w.pooled, 1.0f / (float)S_out, a.se_wr, a.se_br, a.se_we, a.se_be, a.B, a.Cmid, a.se_r,
                      a.se_pmean, a.se_hidpre, a.se_gate, s));
     // conv_pwl (:117-120): y4 = (silu(bn3(y3)) * gate) @ W2^T
@@ -290,14 +345,15 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
         LoadDesc u = ld_bnact(a.y3, a.Cmid, a.bn3.coef, a.Cmid, 1, a.se_gate, a.Cmid, S_out);
         GemmNN g = nn_base(u, LD_BNACT, w.wpwl, a.Cmid, a.y4, a.Cout, (int)Mout, a.Cout, a.Cmid, 1);
         g.stats = tr ? w.st4 : nullptr; g.stat_nchan = a.Cout;
-        TRY(launch_gemm_nn(g, dt, s));
+        PROF(DWN_FAM_PWL_FWD, launch_gemm_nn(g, dt, s));
     }
     TRY(bn_finalize(w.st4, a.Cout, (double)Mout, a.bn4, a.Cout, tr, a.momentum, a.eps, s));
     // shortcut (:125-134) + residual (:143)
     ResGeom gm = geom_of(a);
-    if (tr) TRY(k_shortcut_stats(xin, gm, w.stsc, dt, s));
+    if (tr) PROF(DWN_FAM_RESID_FWD, k_shortcut_stats(xin, gm, w.stsc, dt, s));
     TRY(bn_finalize(w.stsc, a.Cin, (double)Mout, a.bnsc, a.Cout, tr, a.momentum, a.eps, s));
-    return k_residual_fwd(xin, a.y4, a.bn4.coef, a.bnsc.coef, a.drop_scale, gm, a.out, dt, s);
+    PROF(DWN_FAM_RESID_FWD, k_residual_fwd(xin, a.y4, a.bn4.coef, a.bnsc.coef, a.drop_scale, gm, a.out, dt, s));
+    return 0;
 }
 
 int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
@@ -323,22 +379,22 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     LoadDesc xin = ld_pe(a.x, a.Cin, a.pe_t, a.pe_h, a.pe_w, a.T, a.Hin, a.Win);
     ResGeom gm = geom_of(a);
     // residual + the two linear BNs (bn4 = conv_pwl.1.bn, bnsc = bn_sc.bn)
-    TRY(k_residual_bwd_reduce(xin, a.y4, a.dout, a.bn4.coef, a.bnsc.coef, a.drop_scale, gm, w.st4, w.stsc, dt, s));
+    PROF(DWN_FAM_RESID_BWD, k_residual_bwd_reduce(xin, a.y4, a.dout, a.bn4.coef, a.bnsc.coef, a.drop_scale, gm, w.st4, w.stsc, dt, s));
     TRY(k_bn_bwd_finalize(w.st4, (double)Mout, a.bn4.coef, a.bn4.dgamma, a.bn4.dbeta, w.abc4, a.Cout, s));
     TRY(k_bn_bwd_finalize(w.stsc, (double)Mout, a.bnsc.coef, a.bnsc.dgamma, a.bnsc.dbeta, w.abcsc, a.Cout, s));
-    TRY(k_residual_bwd_dy4(a.y4, a.dout, w.abc4, a.drop_scale, gm, a.dy4, dt, s));
+    PROF(DWN_FAM_RESID_BWD, k_residual_bwd_dy4(a.y4, a.dout, w.abc4, a.drop_scale, gm, a.dy4, dt, s));
     // conv_pwl backward: du = dy4 @ W2 (+ SE gate gradient), dW2 = dy4^T @ u
     void* du = a.buf_a;
     {
         GemmNN g = nn_base(ld_plain(a.dy4, a.Cout), LD_PLAIN, w.wpwl, a.Cout, du, a.Cmid, (int)Mout, a.Cmid, a.Cout, 1);
         g.epi = EPI_DG; g.y3 = a.y3; g.ldy3 = a.Cmid; g.s3 = a.bn3.coef; g.t3 = a.bn3.coef + a.Cmid; g.dg = dg;
         g.dg_ld = a.Cmid; g.rows_per_sample = S_out;
-        TRY(launch_gemm_nn(g, dt, s));
+        PROF(DWN_FAM_PWL_DGRAD, launch_gemm_nn(g, dt, s));
     }
     {
         LoadDesc u = ld_bnact(a.y3, a.Cmid, a.bn3.coef, a.Cmid, 1, a.se_gate, a.Cmid, S_out);
         GemmTN g = tn_base(ld_plain(a.dy4, a.Cout), LD_PLAIN, u, LD_BNACT, (int)Mout, a.Cout, a.Cmid, a.dw_pwl, a.Cmid, 1);
-        TRY(launch_gemm_tn(g, dt, s));
+        PROF(DWN_FAM_PWL_WGRAD, launch_gemm_tn(g, dt, s));
     }
     // SE backward
     TRY(k_se_mlp_bwd(dg, a.se_gate, a.se_hidpre, a.se_pmean, a.se_wr, a.se_we, a.B, a.Cmid, a.se_r,
@@ -348,7 +404,7 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     d3.p = du; d3.q = a.y3; d3.ld = a.Cmid; d3.v1 = w.ident3; d3.v2 = w.ident3 + a.Cmid; d3.v3 = w.ident3 + 2 * a.Cmid;
     d3.v4 = a.bn3.coef; d3.v5 = a.bn3.coef + a.Cmid; d3.gate = a.se_gate; d3.gate2 = w.dps; d3.gate_ld = a.Cmid;
     d3.rows_per_sample = S_out;
-    TRY(k_bn3_bwd_reduce(d3, a.bn3.coef, Mout, a.Cmid, w.st3, dt, s));
+    PROF(DWN_FAM_BN3_REDUCE, k_bn3_bwd_reduce(d3, a.bn3.coef, Mout, a.Cmid, w.st3, dt, s));
     TRY(k_bn_bwd_finalize(w.st3, (double)Mout, a.bn3.coef, a.bn3.dgamma, a.bn3.dbeta, w.abc3, a.Cmid, s));
     // temporal dw backward
     {
@@ -357,7 +413,7 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
         d.y2 = ld_ycoef(a.y2, a.Cmid, a.bn2.coef, a.Cmid);
         d.w = w.wdwt; d.dh2 = a.buf_b; d.dw = a.dw_dwt; d.B = a.B; d.T = a.T; d.HW = a.Hout * a.Wout; d.C = a.Cmid;
         d.kt = a.kt; d.stats = w.st2;
-        TRY(launch_dw_temporal_bwd(d, dt, s));
+        PROF(DWN_FAM_DWT_BWD, launch_dw_temporal_bwd(d, dt, s));
     }
     TRY(k_bn_bwd_finalize(w.st2, (double)Mout, a.bn2.coef, a.bn2.dgamma, a.bn2.dbeta, w.abc2, a.Cmid, s));
     // spatial dw backward (du is dead: reuse buf_a for dh1)
@@ -368,20 +424,21 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
         d.y1 = ld_ycoef(a.y1, a.Cmid, a.bn1.coef, a.Cmid);
         d.w = w.wdws; d.dh1 = dh1; d.dw = a.dw_dws; d.planes = a.B * a.T; d.Hin = a.Hin; d.Win = a.Win;
         d.Hout = a.Hout; d.Wout = a.Wout; d.C = a.Cmid; d.stride = a.stride; d.ks = a.ks; d.stats = w.st1;
-        TRY(launch_dw_spatial_bwd(d, dt, s));
+        PROF(DWN_FAM_DWS_BWD, launch_dw_spatial_bwd(d, dt, s));
     }
     TRY(k_bn_bwd_finalize(w.st1, (double)Min, a.bn1.coef, a.bn1.dgamma, a.bn1.dbeta, w.abc1, a.Cmid, s));
     // conv_pw backward
     LoadDesc dy1 = ld_affine2(dh1, a.y1, a.Cmid, w.abc1, a.Cmid);
     {
         GemmNN g = nn_base(dy1, LD_AFFINE2, w.wpw, a.Cmid, a.da0, a.Cin, (int)Min, a.Cin, a.Cmid, 1);
-        TRY(launch_gemm_nn(g, dt, s));
+        PROF(DWN_FAM_PW_DGRAD, launch_gemm_nn(g, dt, s));
     }
     {
         GemmTN g = tn_base(dy1, LD_AFFINE2, xin, LD_PE, (int)Min, a.Cmid, a.Cin, a.dw_pw, a.Cin, 1);
-        TRY(launch_gemm_tn(g, dt, s));
+        PROF(DWN_FAM_PW_WGRAD, launch_gemm_tn(g, dt, s));
     }
-    return k_residual_bwd_dx(xin, a.da0, a.dout, w.abcsc, gm, a.dx, dt, s);
+    PROF(DWN_FAM_RESID_BWD, k_residual_bwd_dx(xin, a.da0, a.dout, w.abcsc, gm, a.dx, dt, s));
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ pool

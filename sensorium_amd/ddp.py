@@ -1,0 +1,88 @@
+"""Data-parallel gradient exchange for the DwiseNeuro step: one process per GPU, flat fp32 gradient buckets,
+RCCL all-reduce over xGMI launched from autograd hooks so it overlaps with the rest of backward.
+
+The reference has no distributed code; this is the one exchange step data parallelism adds:
+an all-reduce (mean) of the parameter gradients per iteration.  Buckets are built in *reverse* registration
+order — readouts (≈16 M params each, ready first in backward) lead, the ~200 small trunk tensors share one
+flat buffer — so the big transfers are issued while the core backward (≈95 % of the step) is still running.
+BatchNorm statistics stay local to each rank (standard DDP semantics).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradBuckets:
+    def __init__(self, module: torch.nn.Module, bucket_cap_mb: float = 64.0, process_group=None,
+                 broadcast_init: bool = True):
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        params = [p for p in module.parameters() if p.requires_grad]
+        if self.world > 1 and broadcast_init:
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src=0, group=process_group)
+        self.buckets: List[dict] = []
+        cap = int(bucket_cap_mb * 1024 * 1024 / 4)
+        cur: List[torch.nn.Parameter] = []
+        cur_n = 0
+        for p in reversed(params):
+            if cur and cur_n + p.numel() > cap:
+                self._add_bucket(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self._add_bucket(cur)
+        self._handles: List = []
+        self._hooks = []
+        if self.world > 1:
+            for bi, b in enumerate(self.buckets):
+                for p in b["params"]:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+
+    def _add_bucket(self, params):
+        n = sum(p.numel() for p in params)
+        flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
+        off = 0
+        for p in params:
+            p.grad = flat[off:off + p.numel()].view_as(p)      # gradients accumulate straight into the bucket
+            off += p.numel()
+        self.buckets.append(dict(params=params, flat=flat, pending=len(params), count=len(params)))
+
+    def _make_hook(self, bi: int):
+        def hook(_param):
+            b = self.buckets[bi]
+            b["pending"] -= 1
+            if b["pending"] == 0:
+                op = dist.ReduceOp.AVG if dist.get_backend(self.pg) == "nccl" else dist.ReduceOp.SUM
+                self._handles.append((dist.all_reduce(b["flat"], op=op, group=self.pg, async_op=True), bi, op))
+        return hook
+
+    def zero_grad(self):
+        """Keep the views alive: zero the flat buffers instead of dropping ``.grad``."""
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["pending"] = b["count"]
+            off = 0
+            for p in b["params"]:
+                if p.grad is None or p.grad.data_ptr() != b["flat"].data_ptr() + off * 4:
+                    p.grad = b["flat"][off:off + p.numel()].view_as(p)
+                off += p.numel()
+
+    def finish(self):
+        """Wait for the outstanding all-reduces (call after backward, before the optimizer step)."""
+        for handle, bi, op in self._handles:
+            handle.wait()
+            if op == dist.ReduceOp.SUM:
+                self.buckets[bi]["flat"].div_(self.world)
+        self._handles.clear()
+        if self.world > 1:
+            for b in self.buckets:
+                if b["pending"] not in (0, b["count"]):
+                    raise RuntimeError("GradBuckets: a bucket saw only part of its gradients this step")
+
+    def num_elements(self) -> int:
+        return sum(b["flat"].numel() for b in self.buckets)

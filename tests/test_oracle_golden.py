@@ -148,3 +148,18 @@ def test_make_state_dict_layout():
     n_params = sum(v.numel() for k, v in sd.items() if "running" not in k and "num_batches" not in k
                    and "inv_freq" not in k)
     assert abs(n_params - 25.19e6) < 0.02e6        # 25.19 M params (1 mouse, exp 7)
+
+
+def test_library_conv_path_equals_stencil_path(golden_dir):
+    """bench.py's cpu_baseline uses the oracle with depth-wise convs routed through torch's conv3d (what the
+    reference calls on CPU); it must compute the same function as the explicit-stencil oracle."""
+    z, sd = load_case(golden_dir, "tiny_model_eval.npz")
+    x = torch.from_numpy(z["x"])
+    a = orc.forward(sd, x, training=True, **TINY)
+    try:
+        orc.DW_IMPL = "library"
+        b = orc.forward(sd, x, training=True, **TINY)
+    finally:
+        orc.DW_IMPL = "stencil"
+    for m in range(2):
+        assert rel(b[m].numpy(), a[m].numpy()) < 1e-5
