@@ -39,6 +39,7 @@ extern "C" {
 #define DWN_LD_BNACT 2   /* act(v1*p + v2) * gate[b]             (dwiseneuro.py:16-22, 38-43) */
 #define DWN_LD_AFFINE2 3 /* v1*p + v2*q + v3                     (BatchNorm backward) */
 #define DWN_LD_DY3 4     /* v1*((p*gate[b]+gate2[b])*silu'(v4*q+v5)) + v2*q + v3 (SE + BN3 backward) */
+#define DWN_LD_GATE 5    /* p * gate[b]                          (SE gate on a materialised activation) */
 
 typedef struct dwn_load_desc {
     const void* p;
@@ -146,6 +147,8 @@ typedef struct dwn_stem_args {
     const float* x;      /* [B][Cin][S] fp32 */
     const float* w;      /* [C0][Cin] */
     dwn_bn bn;
+    const float *pe_t, *pe_h, *pe_w;   /* optional: positional encoding of the FIRST block, added to `out`  */
+    int T, H, W;                       /* (dwiseneuro.py:184-192); S = T*H*W                                 */
     void* y0;            /* raw conv output [B*S][C0] (saved) */
     void* out;           /* BN output [B*S][C0] */
     const void* dout;    /* backward: grad wrt out */
@@ -160,7 +163,11 @@ typedef struct dwn_block_args {
     float eps, momentum;
     const void* x; void* out;
     void *y1, *y2, *y3, *y4;
-    const float *pe_t, *pe_h, *pe_w;
+    void* z3;                                /* silu(bn3(y3)), materialised once by the SE pooling pass (saved) */
+    int x_has_pe;                            /* 1: x already contains this block's positional encoding          */
+    void* a0;                                /* x_has_pe == 0: [M_in][Cin] buffer receiving x + PE (saved)      */
+    const float *pe_t, *pe_h, *pe_w;         /* this block's PE tables [T][Cin], [Hin][Cin], [Win][Cin]         */
+    const float *out_pe_t, *out_pe_h, *out_pe_w;  /* next block's PE tables ([T|Hout|Wout][Cout]) added to out, or null */
     const float *w_pw, *w_dws, *w_dwt, *w_pwl, *se_wr, *se_br, *se_we, *se_be;
     dwn_bn bn1, bn2, bn3, bn4, bnsc;
     const float* drop_scale;                 /* [B] DropPath factor mask/keep (dwiseneuro.py:46-54) or null */

@@ -21,7 +21,7 @@ c_sz = C.c_size_t
 
 DWN_F32, DWN_BF16 = 0, 1
 DWN_NREP = 32
-LD_PLAIN, LD_PE, LD_BNACT, LD_AFFINE2, LD_DY3 = 0, 1, 2, 3, 4
+LD_PLAIN, LD_PE, LD_BNACT, LD_AFFINE2, LD_DY3, LD_GATE = 0, 1, 2, 3, 4, 5
 EPI_STORE, EPI_READOUT, EPI_DG = 0, 1, 2
 FAMILIES = ("pw_fwd", "dws_fwd", "dwt_fwd", "se_pool", "pwl_fwd", "resid_fwd", "resid_bwd", "pwl_dgrad", "pwl_wgrad",
             "bn3_reduce", "dwt_bwd", "dws_bwd", "pw_dgrad", "pw_wgrad")
@@ -77,7 +77,9 @@ class BN(C.Structure):
 
 class StemArgs(C.Structure):
     _fields_ = [("dtype", c_i), ("training", c_i), ("B", c_i), ("Cin", c_i), ("C0", c_i), ("S", c_ll),
-                ("eps", c_f), ("momentum", c_f), ("x", c_p), ("w", c_p), ("bn", BN), ("y0", c_p), ("out", c_p),
+                ("eps", c_f), ("momentum", c_f), ("x", c_p), ("w", c_p), ("bn", BN),
+                ("pe_t", c_p), ("pe_h", c_p), ("pe_w", c_p), ("T", c_i), ("H", c_i), ("W", c_i),
+                ("y0", c_p), ("out", c_p),
                 ("dout", c_p), ("dw", c_p), ("ws", c_p), ("ws_bytes", c_sz)]
 
 
@@ -87,7 +89,9 @@ class BlockArgs(C.Structure):
                 ("Cmid", c_i), ("Cout", c_i), ("stride", c_i), ("ks", c_i), ("kt", c_i), ("se_r", c_i),
                 ("eps", c_f), ("momentum", c_f),
                 ("x", c_p), ("out", c_p), ("y1", c_p), ("y2", c_p), ("y3", c_p), ("y4", c_p),
+                ("z3", c_p), ("x_has_pe", c_i), ("a0", c_p),
                 ("pe_t", c_p), ("pe_h", c_p), ("pe_w", c_p),
+                ("out_pe_t", c_p), ("out_pe_h", c_p), ("out_pe_w", c_p),
                 ("w_pw", c_p), ("w_dws", c_p), ("w_dwt", c_p), ("w_pwl", c_p), ("se_wr", c_p), ("se_br", c_p),
                 ("se_we", c_p), ("se_be", c_p),
                 ("bn1", BN), ("bn2", BN), ("bn3", BN), ("bn4", BN), ("bnsc", BN),

@@ -270,8 +270,8 @@ int dwn_stem_forward(const dwn_stem_args* a, int device, void* stream) {
     if (a->training) HIP_TRY(hipMemsetAsync(st, 0, nstat(a->C0) * sizeof(double), s));
     TRY(k_stem_fwd(a->x, a->w, a->y0, a->B, a->Cin, a->S, a->C0, a->training ? st : nullptr, a->dtype, s));
     TRY(bn_finalize(st, a->C0, (double)M, a->bn, a->C0, a->training, a->momentum, a->eps, s));
-    LoadDesc d = ld_bnact(a->y0, a->C0, a->bn.coef, a->C0, 0, nullptr, 0, 1);
-    return k_ew_apply(d, LD_BNACT, a->out, a->C0, M, a->C0, a->dtype, s);
+    if (a->pe_t && (i64)a->T * a->H * a->W != a->S) return dwn_set_error(-2, "stem: T*H*W != S");
+    return k_stem_bn_pe(a->y0, a->bn.coef, a->pe_t, a->pe_h, a->pe_w, a->T, a->H, a->W, M, a->C0, a->out, a->dtype, s);
 }
 int dwn_stem_backward(const dwn_stem_args* a, int device, void* stream) {
     ENTER(device);
@@ -309,10 +309,18 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     TRY(k_pack_dw(a.w_dws, w.wdws, a.Cmid, a.ks * a.ks, s));
     TRY(k_pack_dw(a.w_dwt, w.wdwt, a.Cmid, a.kt, s));
 
-    // conv_pw (dwiseneuro.py:90-93): y1 = (x + PE) @ W1^T, Σ/Σ² for bn1
-    LoadDesc xin = ld_pe(a.x, a.Cin, a.pe_t, a.pe_h, a.pe_w, a.T, a.Hin, a.Win);
+    // PositionalEncoding3d (dwiseneuro.py:184-192): normally already folded into x by the producer (stem /
+    // previous block's residual kernel); stand-alone callers get it materialised here
+    const void* a0 = a.x;
+    if (!a.x_has_pe) {
+        if (!a.a0) return dwn_set_error(-2, "block_forward: a0 buffer required when x_has_pe == 0");
+        TRY(k_ew_apply(ld_pe(a.x, a.Cin, a.pe_t, a.pe_h, a.pe_w, a.T, a.Hin, a.Win), LD_PE, a.a0, a.Cin, Min, a.Cin, dt, s));
+        a0 = a.a0;
+    }
+    // conv_pw (dwiseneuro.py:90-93): y1 = a0 @ W1^T, Σ/Σ² for bn1
+    LoadDesc xin = ld_plain(a0, a.Cin);
     {
-        GemmNN g = nn_base(xin, LD_PE, w.wpw, a.Cin, a.y1, a.Cmid, (int)Min, a.Cmid, a.Cin, 1);
+        GemmNN g = nn_base(xin, LD_PLAIN, w.wpw, a.Cin, a.y1, a.Cmid, (int)Min, a.Cmid, a.Cin, 1);
         g.stats = tr ? w.st1 : nullptr; g.stat_nchan = a.Cmid;
         PROF(DWN_FAM_PW_FWD, launch_gemm_nn(g, dt, s));
     }
@@ -337,13 +345,14 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     TRY(bn_finalize(w.st3, a.Cmid, (double)Mout, a.bn3, a.Cmid, tr, a.momentum, a.eps, s));
     // se (:38-43)
     LoadDesc z3 = ld_bnact(a.y3, a.Cmid, a.bn3.coef, a.Cmid, 1, nullptr, 0, S_out);
-    PROF(DWN_FAM_SE_POOL, k_se_pool(z3, a.B, a.Cmid, S_out, w.pooled, dt, s));
+    PROF(DWN_FAM_SE_POOL, k_se_pool(z3, a.B, a.Cmid, S_out, w.pooled, a.z3, dt, s));
     TRY(k_se_mlp_fwd(w.pooled, 1.0f / (float)S_out, a.se_wr, a.se_br, a.se_we, a.se_be, a.B, a.Cmid, a.se_r,
                      a.se_pmean, a.se_hidpre, a.se_gate, s));
     // conv_pwl (:117-120): y4 = (silu(bn3(y3)) * gate) @ W2^T
     {
-        LoadDesc u = ld_bnact(a.y3, a.Cmid, a.bn3.coef, a.Cmid, 1, a.se_gate, a.Cmid, S_out);
-        GemmNN g = nn_base(u, LD_BNACT, w.wpwl, a.Cmid, a.y4, a.Cout, (int)Mout, a.Cout, a.Cmid, 1);
+        LoadDesc u = ld_plain(a.z3, a.Cmid);
+        u.gate = a.se_gate; u.gate_ld = a.Cmid; u.rows_per_sample = S_out;
+        GemmNN g = nn_base(u, LD_GATE, w.wpwl, a.Cmid, a.y4, a.Cout, (int)Mout, a.Cout, a.Cmid, 1);
         g.stats = tr ? w.st4 : nullptr; g.stat_nchan = a.Cout;
         PROF(DWN_FAM_PWL_FWD, launch_gemm_nn(g, dt, s));
     }
@@ -352,7 +361,8 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     ResGeom gm = geom_of(a);
     if (tr) PROF(DWN_FAM_RESID_FWD, k_shortcut_stats(xin, gm, w.stsc, dt, s));
     TRY(bn_finalize(w.stsc, a.Cin, (double)Mout, a.bnsc, a.Cout, tr, a.momentum, a.eps, s));
-    PROF(DWN_FAM_RESID_FWD, k_residual_fwd(xin, a.y4, a.bn4.coef, a.bnsc.coef, a.drop_scale, gm, a.out, dt, s));
+    PROF(DWN_FAM_RESID_FWD, k_residual_fwd(xin, a.y4, a.bn4.coef, a.bnsc.coef, a.drop_scale, gm, a.out_pe_t, a.out_pe_h,
+                                           a.out_pe_w, a.out, dt, s));
     return 0;
 }
 
@@ -376,7 +386,7 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     TRY(k_fill_f32(w.ident3, 1.0f, a.Cmid, s));
     HIP_TRY(hipMemsetAsync(w.ident3 + a.Cmid, 0, 2 * (size_t)a.Cmid * sizeof(float), s));
 
-    LoadDesc xin = ld_pe(a.x, a.Cin, a.pe_t, a.pe_h, a.pe_w, a.T, a.Hin, a.Win);
+    LoadDesc xin = ld_plain(a.x_has_pe ? a.x : a.a0, a.Cin);     // block input including its positional encoding
     ResGeom gm = geom_of(a);
     // residual + the two linear BNs (bn4 = conv_pwl.1.bn, bnsc = bn_sc.bn)
     PROF(DWN_FAM_RESID_BWD, k_residual_bwd_reduce(xin, a.y4, a.dout, a.bn4.coef, a.bnsc.coef, a.drop_scale, gm, w.st4, w.stsc, dt, s));
@@ -387,13 +397,14 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     void* du = a.buf_a;
     {
         GemmNN g = nn_base(ld_plain(a.dy4, a.Cout), LD_PLAIN, w.wpwl, a.Cout, du, a.Cmid, (int)Mout, a.Cmid, a.Cout, 1);
-        g.epi = EPI_DG; g.y3 = a.y3; g.ldy3 = a.Cmid; g.s3 = a.bn3.coef; g.t3 = a.bn3.coef + a.Cmid; g.dg = dg;
+        g.epi = EPI_DG; g.y3 = a.z3; g.ldy3 = a.Cmid; g.s3 = nullptr; g.t3 = nullptr; g.dg = dg;
         g.dg_ld = a.Cmid; g.rows_per_sample = S_out;
         PROF(DWN_FAM_PWL_DGRAD, launch_gemm_nn(g, dt, s));
     }
     {
-        LoadDesc u = ld_bnact(a.y3, a.Cmid, a.bn3.coef, a.Cmid, 1, a.se_gate, a.Cmid, S_out);
-        GemmTN g = tn_base(ld_plain(a.dy4, a.Cout), LD_PLAIN, u, LD_BNACT, (int)Mout, a.Cout, a.Cmid, a.dw_pwl, a.Cmid, 1);
+        LoadDesc u = ld_plain(a.z3, a.Cmid);
+        u.gate = a.se_gate; u.gate_ld = a.Cmid; u.rows_per_sample = S_out;
+        GemmTN g = tn_base(ld_plain(a.dy4, a.Cout), LD_PLAIN, u, LD_GATE, (int)Mout, a.Cout, a.Cmid, a.dw_pwl, a.Cmid, 1);
         PROF(DWN_FAM_PWL_WGRAD, launch_gemm_tn(g, dt, s));
     }
     // SE backward
@@ -404,12 +415,13 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     d3.p = du; d3.q = a.y3; d3.ld = a.Cmid; d3.v1 = w.ident3; d3.v2 = w.ident3 + a.Cmid; d3.v3 = w.ident3 + 2 * a.Cmid;
     d3.v4 = a.bn3.coef; d3.v5 = a.bn3.coef + a.Cmid; d3.gate = a.se_gate; d3.gate2 = w.dps; d3.gate_ld = a.Cmid;
     d3.rows_per_sample = S_out;
-    PROF(DWN_FAM_BN3_REDUCE, k_bn3_bwd_reduce(d3, a.bn3.coef, Mout, a.Cmid, w.st3, dt, s));
+    // ... and dh3 replaces du in place, so the temporal kernel reads (dh3, y3) with the plain BN-backward affine
+    PROF(DWN_FAM_BN3_REDUCE, k_bn3_bwd_reduce(d3, a.bn3.coef, Mout, a.Cmid, w.st3, du, dt, s));
     TRY(k_bn_bwd_finalize(w.st3, (double)Mout, a.bn3.coef, a.bn3.dgamma, a.bn3.dbeta, w.abc3, a.Cmid, s));
     // temporal dw backward
     {
         DwTemporalBwd d; memset(&d, 0, sizeof(d));
-        d.dy = d3; d.dy.v1 = w.abc3; d.dy.v2 = w.abc3 + a.Cmid; d.dy.v3 = w.abc3 + 2 * a.Cmid; d.dy_kind = LD_DY3;
+        d.dy = ld_affine2(du, a.y3, a.Cmid, w.abc3, a.Cmid); d.dy_kind = LD_AFFINE2;
         d.y2 = ld_ycoef(a.y2, a.Cmid, a.bn2.coef, a.Cmid);
         d.w = w.wdwt; d.dh2 = a.buf_b; d.dw = a.dw_dwt; d.B = a.B; d.T = a.T; d.HW = a.Hout * a.Wout; d.C = a.Cmid;
         d.kt = a.kt; d.stats = w.st2;
@@ -434,7 +446,7 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
         PROF(DWN_FAM_PW_DGRAD, launch_gemm_nn(g, dt, s));
     }
     {
-        GemmTN g = tn_base(dy1, LD_AFFINE2, xin, LD_PE, (int)Min, a.Cmid, a.Cin, a.dw_pw, a.Cin, 1);
+        GemmTN g = tn_base(dy1, LD_AFFINE2, xin, LD_PLAIN, (int)Min, a.Cmid, a.Cin, a.dw_pw, a.Cin, 1);
         PROF(DWN_FAM_PW_WGRAD, launch_gemm_tn(g, dt, s));
     }
     PROF(DWN_FAM_RESID_BWD, k_residual_bwd_dx(xin, a.da0, a.dout, w.abcsc, gm, a.dx, dt, s));

@@ -74,7 +74,8 @@ template <int KC> __device__ __forceinline__ void ld_coef(const float* p, float*
 }
 
 // ---- activation math
-__device__ __forceinline__ float sigmoidf_(float h) { return 1.0f / (1.0f + __expf(-h)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): an IEEE fp32 division would cost ~10 VALU instructions per element
+__device__ __forceinline__ float sigmoidf_(float h) { return __builtin_amdgcn_rcpf(1.0f + __expf(-h)); }
 __device__ __forceinline__ float siluf_(float h) { return h * sigmoidf_(h); }
 // d silu(h) / dh
 __device__ __forceinline__ float silu_gradf_(float h) {
@@ -82,10 +83,51 @@ __device__ __forceinline__ float silu_gradf_(float h) {
     return s * (1.0f + h * (1.0f - s));
 }
 
+// ---- 4-channel vectors (16 B fp32 / 8 B bf16): the unit of the streaming (stencil / elementwise) kernels.
+// Half the registers per thread of the 16-byte bf16 vector -> twice the waves in flight to hide HBM latency.
+template <typename T> struct V4 { };
+template <> struct V4<float> {
+    typedef uint4 raw_t;
+    static constexpr int NCV = 8;       // vectors per 128-byte channel slice
+    static __device__ __forceinline__ void unpack(const raw_t& r, float* o) {
+        o[0] = __uint_as_float(r.x); o[1] = __uint_as_float(r.y); o[2] = __uint_as_float(r.z); o[3] = __uint_as_float(r.w);
+    }
+    static __device__ __forceinline__ raw_t pack(const float* v) {
+        return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+    }
+    static __device__ __forceinline__ raw_t zero() { return make_uint4(0, 0, 0, 0); }
+};
+template <> struct V4<bf16_t> {
+    typedef uint2 raw_t;
+    static constexpr int NCV = 16;
+    static __device__ __forceinline__ void unpack(const raw_t& r, float* o) {
+        o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+        o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+    }
+    static __device__ __forceinline__ raw_t pack(const float* v) {
+        uint2 r;
+        r.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        r.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        return r;
+    }
+    static __device__ __forceinline__ raw_t zero() { return make_uint2(0, 0); }
+};
+template <typename T> __device__ __forceinline__ typename V4<T>::raw_t ld4_raw(const T* p) {
+    return *reinterpret_cast<const typename V4<T>::raw_t*>(p);
+}
+template <typename T> __device__ __forceinline__ void ld4(const T* p, float* o) { V4<T>::unpack(ld4_raw<T>(p), o); }
+template <typename T> __device__ __forceinline__ void st4(T* p, const float* v) {
+    *reinterpret_cast<typename V4<T>::raw_t*>(p) = V4<T>::pack(v);
+}
+__device__ __forceinline__ void ldc4(const float* p, float* o) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+
 // ---- the operand "loader": how a kernel reads one 16-byte channel vector of an operand.
 // Fusing the producer's batch-norm / activation / gate / positional-encoding / BN-backward affine
 // into the consumer's load is what removes the elementwise HBM round trips.
-enum { LD_PLAIN = 0, LD_PE = 1, LD_BNACT = 2, LD_AFFINE2 = 3, LD_DY3 = 4 };
+enum { LD_PLAIN = 0, LD_PE = 1, LD_BNACT = 2, LD_AFFINE2 = 3, LD_DY3 = 4, LD_GATE = 5 };
 
 typedef dwn_load_desc LoadDesc;   // field meanings: include/dwn.h and the loader below
 
@@ -94,11 +136,14 @@ __device__ __forceinline__ void load_op(const LoadDesc& d, i64 row, int col, flo
     constexpr int KC = TT<T>::KC;
     const T* p = reinterpret_cast<const T*>(d.p) + row * d.ld + col;
     ld_vec<T>(p, o);
+    // row indices fit 32 bits (rows = B*T*H*W < 2^31): 32-bit unsigned div/mod is ~10x cheaper than the i64 form
+    const unsigned r32 = (unsigned)row;
     if constexpr (KIND == LD_PE) {
-        int w = (int)(row % d.pW);
-        i64 r2 = row / d.pW;
-        int h = (int)(r2 % d.pH);
-        int t = (int)((r2 / d.pH) % d.pT);
+        const unsigned r2 = r32 / (unsigned)d.pW;
+        const int w = (int)(r32 - r2 * (unsigned)d.pW);
+        const unsigned r3 = r2 / (unsigned)d.pH;
+        const int h = (int)(r2 - r3 * (unsigned)d.pH);
+        const int t = (int)(r3 % (unsigned)d.pT);
         float a[KC], b[KC], c[KC];
         ld_coef<KC>(d.pe_t + (i64)t * d.pe_ld + col, a);
         ld_coef<KC>(d.pe_h + (i64)h * d.pe_ld + col, b);
@@ -115,12 +160,18 @@ __device__ __forceinline__ void load_op(const LoadDesc& d, i64 row, int col, flo
             o[i] = d.act ? siluf_(h) : h;
         }
         if (d.gate) {
-            int b = (int)(row / d.rows_per_sample);
+            int b = (int)(r32 / (unsigned)d.rows_per_sample);
             float g[KC];
             ld_coef<KC>(d.gate + (i64)b * d.gate_ld + col, g);
 #pragma unroll
             for (int i = 0; i < KC; ++i) o[i] *= g[i];
         }
+    } else if constexpr (KIND == LD_GATE) {
+        int b = (int)(r32 / (unsigned)d.rows_per_sample);
+        float g[KC];
+        ld_coef<KC>(d.gate + (i64)b * d.gate_ld + col, g);
+#pragma unroll
+        for (int i = 0; i < KC; ++i) o[i] *= g[i];
     } else if constexpr (KIND == LD_AFFINE2) {
         float y[KC], a1[KC], a2[KC], a3[KC];
         ld_vec<T>(reinterpret_cast<const T*>(d.q) + row * d.ld + col, y);
@@ -138,7 +189,7 @@ __device__ __forceinline__ void load_op(const LoadDesc& d, i64 row, int col, flo
         ld_coef<KC>(d.v3 + col, a3);
         ld_coef<KC>(d.v4 + col, s);
         ld_coef<KC>(d.v5 + col, t);
-        int b = (int)(row / d.rows_per_sample);
+        int b = (int)(r32 / (unsigned)d.rows_per_sample);
         ld_coef<KC>(d.gate + (i64)b * d.gate_ld + col, g);
         ld_coef<KC>(d.gate2 + (i64)b * d.gate_ld + col, g2);
 #pragma unroll
@@ -149,6 +200,68 @@ __device__ __forceinline__ void load_op(const LoadDesc& d, i64 row, int col, flo
         }
     }
 }
+
+// ---- hoisted form for kernels where a thread's channel column is fixed while it walks rows (GEMM staging):
+// the per-channel coefficient vectors are loaded once (ColCoef::load) instead of once per 16-byte data chunk —
+// otherwise every data load drags 4-6 coefficient loads through the L1/TA path, which then bounds the kernel.
+template <int KIND, typename T> struct ColCoef {
+    static constexpr int KC = TT<T>::KC;
+    float c1[KC], c2[KC], c3[KC], c4[KC], c5[KC], g[KC], g2[KC];
+    int gb;                                    // sample whose gate vectors are cached (-1: none)
+    int col;
+    __device__ __forceinline__ void load(const LoadDesc& d, int column) {
+        col = column; gb = -1;
+        if constexpr (KIND == LD_BNACT) { ld_coef<KC>(d.v1 + col, c1); ld_coef<KC>(d.v2 + col, c2); }
+        if constexpr (KIND == LD_AFFINE2 || KIND == LD_DY3) {
+            ld_coef<KC>(d.v1 + col, c1); ld_coef<KC>(d.v2 + col, c2); ld_coef<KC>(d.v3 + col, c3);
+        }
+        if constexpr (KIND == LD_DY3) { ld_coef<KC>(d.v4 + col, c4); ld_coef<KC>(d.v5 + col, c5); }
+    }
+    __device__ __forceinline__ void gate_for(const LoadDesc& d, unsigned row) {
+        int b = (int)(row / (unsigned)d.rows_per_sample);
+        if (b != gb) {
+            gb = b;
+            ld_coef<KC>(d.gate + (i64)b * d.gate_ld + col, g);
+            if constexpr (KIND == LD_DY3) ld_coef<KC>(d.gate2 + (i64)b * d.gate_ld + col, g2);
+        }
+    }
+    // p, q: raw 16-byte vectors already loaded (q unused for single-tensor kinds)
+    __device__ __forceinline__ uint4 apply(const LoadDesc& d, unsigned row, const uint4& p, const uint4& q) {
+        if constexpr (KIND == LD_PLAIN) { return p; }
+        float o[KC];
+        unpack16<T>(p, o);
+        if constexpr (KIND == LD_GATE) {
+            gate_for(d, row);
+#pragma unroll
+            for (int i = 0; i < KC; ++i) o[i] *= g[i];
+        } else if constexpr (KIND == LD_BNACT) {
+#pragma unroll
+            for (int i = 0; i < KC; ++i) { float h = fmaf(o[i], c1[i], c2[i]); o[i] = d.act ? siluf_(h) : h; }
+            if (d.gate) {
+                gate_for(d, row);
+#pragma unroll
+                for (int i = 0; i < KC; ++i) o[i] *= g[i];
+            }
+        } else if constexpr (KIND == LD_AFFINE2) {
+            float y[KC];
+            unpack16<T>(q, y);
+#pragma unroll
+            for (int i = 0; i < KC; ++i) o[i] = fmaf(c1[i], o[i], fmaf(c2[i], y[i], c3[i]));
+        } else if constexpr (KIND == LD_DY3) {
+            float y[KC];
+            unpack16<T>(q, y);
+            gate_for(d, row);
+#pragma unroll
+            for (int i = 0; i < KC; ++i) {
+                float h = fmaf(y[i], c4[i], c5[i]);
+                float dh = fmaf(o[i], g[i], g2[i]) * silu_gradf_(h);
+                o[i] = fmaf(c1[i], dh, fmaf(c2[i], y[i], c3[i]));
+            }
+        }
+        return pack16<T>(o);
+    }
+    static constexpr bool two_tensors = (KIND == LD_AFFINE2 || KIND == LD_DY3);
+};
 
 // ---- cross-workgroup statistics: double atomics into one of DWN_NREP replicas
 __device__ __forceinline__ void stat_add(double* base, int rep, int nchan, int which, int c, float v) {

@@ -6,6 +6,7 @@
 #include "dwn_kernels.h"
 
 #define NCV 8
+#define DISPATCH_T(dtype, CALL_BF, CALL_F) do { if ((dtype) == DWN_BF16) { CALL_BF; } else { CALL_F; } } while (0)
 
 // every "sliced" kernel: thread -> (cv = tid % 8, pl = tid / 8), channel slice = blockIdx.y
 #define SLICE_SETUP(Cval)                                   \
@@ -171,6 +172,7 @@ static int ew_apply_t(const LoadDesc& d, int kind, void* out, i64 ldo, i64 rows,
         case LD_BNACT: hipLaunchKernelGGL((ew_apply_kernel<T, LD_BNACT>), grid, dim3(256), 0, s, d, o, ldo, rows, C); break;
         case LD_AFFINE2: hipLaunchKernelGGL((ew_apply_kernel<T, LD_AFFINE2>), grid, dim3(256), 0, s, d, o, ldo, rows, C); break;
         case LD_DY3: hipLaunchKernelGGL((ew_apply_kernel<T, LD_DY3>), grid, dim3(256), 0, s, d, o, ldo, rows, C); break;
+        case LD_GATE: hipLaunchKernelGGL((ew_apply_kernel<T, LD_GATE>), grid, dim3(256), 0, s, d, o, ldo, rows, C); break;
         default: return dwn_set_error(-3, "ew_apply: bad loader kind");
     }
     DWN_CHECK_LAUNCH();
@@ -272,6 +274,45 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(LoadDesc dy, const float*
     }
 }
 
+// out[row][c] = scale*y0 + shift (+ positional encoding of the first block)
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bn_pe_kernel(const T* y0, const float* coef, const float* pe_t,
+                                                         const float* pe_h, const float* pe_w, int Tn, int H, int W,
+                                                         i64 rows, int C, T* out) {
+    SLICE_SETUP(C)
+    if (!chan_ok) return;
+    float sc[KC], sh[KC];
+    ld_coef<KC>(coef + chan, sc);
+    ld_coef<KC>(coef + C + chan, sh);
+    for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
+        float v[KC];
+        ld_vec<T>(y0 + row * C + chan, v);
+#pragma unroll
+        for (int i = 0; i < KC; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
+        if (pe_t) {
+            unsigned r32 = (unsigned)row;
+            unsigned r2 = r32 / (unsigned)W, w = r32 - r2 * (unsigned)W;
+            unsigned r3 = r2 / (unsigned)H, h = r2 - r3 * (unsigned)H;
+            unsigned t = r3 % (unsigned)Tn;
+            float pa[KC], pb[KC], pc[KC];
+            ld_coef<KC>(pe_t + (i64)t * C + chan, pa);
+            ld_coef<KC>(pe_h + (i64)h * C + chan, pb);
+            ld_coef<KC>(pe_w + (i64)w * C + chan, pc);
+#pragma unroll
+            for (int i = 0; i < KC; ++i) v[i] = round_t<T>(v[i]) + ((pa[i] + pb[i]) + pc[i]);
+        }
+        st_vec<T>(out + row * C + chan, v);
+    }
+}
+int k_stem_bn_pe(const void* y0, const float* coef, const float* pe_t, const float* pe_h, const float* pe_w, int Tn,
+                 int H, int W, i64 rows, int C, void* out, int dtype, hipStream_t s) {
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((stem_bn_pe_kernel<bf16_t>), slice_grid(rows, C, 8), dim3(256), 0, s, (const bf16_t*)y0, coef, pe_t, pe_h, pe_w, Tn, H, W, rows, C, (bf16_t*)out),
+        hipLaunchKernelGGL((stem_bn_pe_kernel<float>), slice_grid(rows, C, 4), dim3(256), 0, s, (const float*)y0, coef, pe_t, pe_h, pe_w, Tn, H, W, rows, C, (float*)out));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
 int k_stem_fwd(const float* x, const float* w, void* y, int B, int Cin, i64 S, int C0, double* stats, int dtype,
                hipStream_t s) {
     if (dtype == DWN_BF16) {
@@ -320,7 +361,7 @@ __global__ __launch_bounds__(256) void shortcut_stats_kernel(LoadDesc xin, ResGe
             i64 bt = r2 / gm.Hout;
             i64 rin = (bt * gm.Hin + gm.hsrc[ho]) * gm.Win + gm.wsrc[wo];
             float v[KC];
-            load_op<LD_PE, T>(xin, rin, chan, v);
+            load_op<LD_PLAIN, T>(xin, rin, chan, v);
 #pragma unroll
             for (int i = 0; i < KC; ++i) { float r = round_t<T>(v[i]); s0[i] += r; s1[i] += r * r; }
         }
@@ -331,6 +372,7 @@ __global__ __launch_bounds__(256) void shortcut_stats_kernel(LoadDesc xin, ResGe
 template <typename T>
 __global__ __launch_bounds__(256) void residual_fwd_kernel(LoadDesc xin, const T* y4, const float* coef4,
                                                            const float* coefsc, const float* dscale, ResGeom gm,
+                                                           const float* ope_t, const float* ope_h, const float* ope_w,
                                                            T* out) {
     SLICE_SETUP(gm.Cout)
     if (!chan_ok) return;
@@ -347,12 +389,20 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(LoadDesc xin, const T
         i64 bt = r2 / gm.Hout;
         i64 rin = (bt * gm.Hin + gm.hsrc[ho]) * gm.Win + gm.wsrc[wo];
         float sv[KC], yv[KC], o[KC];
-        load_op<LD_PE, T>(xin, rin, csrc, sv);
+        load_op<LD_PLAIN, T>(xin, rin, csrc, sv);
         ld_vec<T>(y4 + row * gm.Cout + chan, yv);
         float d = dscale ? dscale[row / rows_per_b] : 1.0f;
 #pragma unroll
         for (int i = 0; i < KC; ++i)
             o[i] = d * fmaf(yv[i], s4[i], t4[i]) + fmaf(round_t<T>(sv[i]), ss[i], ts[i]);
+        if (ope_t) {       // the NEXT block's positional encoding is folded into this block's output
+            float pa[KC], pb[KC], pc[KC];
+            ld_coef<KC>(ope_t + (i64)(bt % gm.T) * gm.Cout + chan, pa);
+            ld_coef<KC>(ope_h + (i64)ho * gm.Cout + chan, pb);
+            ld_coef<KC>(ope_w + (i64)wo * gm.Cout + chan, pc);
+#pragma unroll
+            for (int i = 0; i < KC; ++i) o[i] = round_t<T>(o[i]) + ((pa[i] + pb[i]) + pc[i]);
+        }
         st_vec<T>(out + row * gm.Cout + chan, o);
     }
 }
@@ -385,7 +435,7 @@ __global__ __launch_bounds__(256) void residual_bwd_reduce_kernel(LoadDesc xin, 
             i64 bt = r2 / gm.Hout;
             i64 rin = (bt * gm.Hin + gm.hsrc[ho]) * gm.Win + gm.wsrc[wo];
             float sv[KC], yv[KC], g[KC];
-            load_op<LD_PE, T>(xin, rin, csrc, sv);
+            load_op<LD_PLAIN, T>(xin, rin, csrc, sv);
             ld_vec<T>(y4 + row * gm.Cout + chan, yv);
             ld_vec<T>(dout + row * gm.Cout + chan, g);
             float d = dscale ? dscale[row / rows_per_b] : 1.0f;
@@ -443,7 +493,7 @@ __global__ __launch_bounds__(256) void residual_bwd_dx_kernel(LoadDesc xin, cons
         if (ho >= 0 && wo >= 0) {
             i64 rout = (bt * gm.Hout + ho) * gm.Wout + wo;
             float sv[KC];
-            load_op<LD_PE, T>(xin, row, chan, sv);
+            load_op<LD_PLAIN, T>(xin, row, chan, sv);
             for (int cc = chan; cc < gm.Cout; cc += gm.Cin) {
                 float g[KC], a1[KC], a2[KC], a3[KC];
                 ld_vec<T>(dout + rout * gm.Cout + cc, g);
@@ -457,7 +507,6 @@ __global__ __launch_bounds__(256) void residual_bwd_dx_kernel(LoadDesc xin, cons
     }
 }
 
-#define DISPATCH_T(dtype, CALL_BF, CALL_F) do { if ((dtype) == DWN_BF16) { CALL_BF; } else { CALL_F; } } while (0)
 
 int k_shortcut_stats(const LoadDesc& xin, const ResGeom& gm, double* stats, int dtype, hipStream_t s) {
     i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
@@ -468,11 +517,12 @@ int k_shortcut_stats(const LoadDesc& xin, const ResGeom& gm, double* stats, int 
     return 0;
 }
 int k_residual_fwd(const LoadDesc& xin, const void* y4, const float* coef4, const float* coefsc, const float* dscale,
-                   const ResGeom& gm, void* out, int dtype, hipStream_t s) {
+                   const ResGeom& gm, const float* ope_t, const float* ope_h, const float* ope_w, void* out, int dtype,
+                   hipStream_t s) {
     i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL((residual_fwd_kernel<bf16_t>), slice_grid(rows, gm.Cout, 8), dim3(256), 0, s, xin, (const bf16_t*)y4, coef4, coefsc, dscale, gm, (bf16_t*)out),
-        hipLaunchKernelGGL((residual_fwd_kernel<float>), slice_grid(rows, gm.Cout, 4), dim3(256), 0, s, xin, (const float*)y4, coef4, coefsc, dscale, gm, (float*)out));
+        hipLaunchKernelGGL((residual_fwd_kernel<bf16_t>), slice_grid(rows, gm.Cout, 8), dim3(256), 0, s, xin, (const bf16_t*)y4, coef4, coefsc, dscale, gm, ope_t, ope_h, ope_w, (bf16_t*)out),
+        hipLaunchKernelGGL((residual_fwd_kernel<float>), slice_grid(rows, gm.Cout, 4), dim3(256), 0, s, xin, (const float*)y4, coef4, coefsc, dscale, gm, ope_t, ope_h, ope_w, (float*)out));
     DWN_CHECK_LAUNCH();
     return 0;
 }
@@ -511,7 +561,7 @@ int k_residual_bwd_dx(const LoadDesc& xin, const void* da0, const void* dout, co
 // pooled[b][c] += sum over a chunk of the sample's rows of silu(bn3(y3))
 template <typename T>
 __global__ __launch_bounds__(256) void se_pool_kernel(LoadDesc z3, int C, int rows_per_sample, int chunks,
-                                                      float* pooled) {
+                                                      float* pooled, T* z3out) {
     SLICE_SETUP(C)
     __shared__ float lacc[NCV * KC];
     if (tid < NCV * KC) lacc[tid] = 0.f;
@@ -527,8 +577,9 @@ __global__ __launch_bounds__(256) void se_pool_kernel(LoadDesc z3, int C, int ro
         for (int r = r_beg + pl; r < r_end; r += 32) {
             float v[KC];
             load_op<LD_BNACT, T>(z3, (i64)b * rows_per_sample + r, chan, v);
+            if (z3out) st_vec<T>(z3out + ((i64)b * rows_per_sample + r) * C + chan, v);
 #pragma unroll
-            for (int i = 0; i < KC; ++i) acc[i] += v[i];
+            for (int i = 0; i < KC; ++i) acc[i] += round_t<T>(v[i]);
         }
 #pragma unroll
     for (int i = 0; i < KC; ++i) atomicAdd(&lacc[cv * KC + i], acc[i]);
@@ -536,7 +587,7 @@ __global__ __launch_bounds__(256) void se_pool_kernel(LoadDesc z3, int C, int ro
     if (tid < NCV * KC && c0 + tid < C) atomicAdd(pooled + (i64)b * C + c0 + tid, lacc[tid]);
 }
 
-int k_se_pool(const LoadDesc& z3, int B, int C, int rows_per_sample, float* pooled, int dtype, hipStream_t s) {
+int k_se_pool(const LoadDesc& z3, int B, int C, int rows_per_sample, float* pooled, void* z3out, int dtype, hipStream_t s) {
     int KCv = dtype == DWN_BF16 ? 8 : 4;
     int slices = (C + NCV * KCv - 1) / (NCV * KCv);
     int chunks = (rows_per_sample + 255) / 256;
@@ -545,8 +596,8 @@ int k_se_pool(const LoadDesc& z3, int B, int C, int rows_per_sample, float* pool
     if (chunks < 1) chunks = 1;
     dim3 grid(B * chunks, slices);
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL((se_pool_kernel<bf16_t>), grid, dim3(256), 0, s, z3, C, rows_per_sample, chunks, pooled),
-        hipLaunchKernelGGL((se_pool_kernel<float>), grid, dim3(256), 0, s, z3, C, rows_per_sample, chunks, pooled));
+        hipLaunchKernelGGL((se_pool_kernel<bf16_t>), grid, dim3(256), 0, s, z3, C, rows_per_sample, chunks, pooled, (bf16_t*)z3out),
+        hipLaunchKernelGGL((se_pool_kernel<float>), grid, dim3(256), 0, s, z3, C, rows_per_sample, chunks, pooled, (float*)z3out));
     DWN_CHECK_LAUNCH();
     return 0;
 }
@@ -666,7 +717,7 @@ int k_se_mlp_bwd(const float* dg, const float* gate, const float* hid_pre, const
 // Σdh3, Σdh3·ŷ3 where dh3 = (du*gate + dpS) * silu'(bn3(y3))   (LD_DY3 with A1=1, A2=A3=0 gives dh3)
 template <typename T>
 __global__ __launch_bounds__(256) void bn3_bwd_reduce_kernel(LoadDesc d, const float* coef3, i64 rows, int C,
-                                                             double* stats) {
+                                                             double* stats, T* dh_out) {
     SLICE_SETUP(C)
     __shared__ float lstat[2 * NCV * KC];
     if (tid < 2 * NCV * KC) lstat[tid] = 0.f;
@@ -683,16 +734,17 @@ __global__ __launch_bounds__(256) void bn3_bwd_reduce_kernel(LoadDesc d, const f
             float dh[KC], y[KC];
             load_op<LD_DY3, T>(d, row, chan, dh);
             ld_vec<T>(yp + row * d.ld + chan, y);
+            if (dh_out) st_vec<T>(dh_out + row * d.ld + chan, dh);      // may alias d.p (element-wise in place)
 #pragma unroll
-            for (int i = 0; i < KC; ++i) { s0[i] += dh[i]; s1[i] += dh[i] * (y[i] - m3[i]) * i3[i]; }
+            for (int i = 0; i < KC; ++i) { float r = round_t<T>(dh[i]); s0[i] += r; s1[i] += r * (y[i] - m3[i]) * i3[i]; }
         }
     }
     slice_stats_flush<KC>(lstat, s0, s1, cv, c0, C, stats, blockIdx.x % DWN_NREP);
 }
-int k_bn3_bwd_reduce(const LoadDesc& d, const float* coef3, i64 rows, int C, double* stats, int dtype, hipStream_t s) {
+int k_bn3_bwd_reduce(const LoadDesc& d, const float* coef3, i64 rows, int C, double* stats, void* dh_out, int dtype, hipStream_t s) {
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL((bn3_bwd_reduce_kernel<bf16_t>), slice_grid(rows, C, 8, 2048), dim3(256), 0, s, d, coef3, rows, C, stats),
-        hipLaunchKernelGGL((bn3_bwd_reduce_kernel<float>), slice_grid(rows, C, 4, 2048), dim3(256), 0, s, d, coef3, rows, C, stats));
+        hipLaunchKernelGGL((bn3_bwd_reduce_kernel<bf16_t>), slice_grid(rows, C, 8, 2048), dim3(256), 0, s, d, coef3, rows, C, stats, (bf16_t*)dh_out),
+        hipLaunchKernelGGL((bn3_bwd_reduce_kernel<float>), slice_grid(rows, C, 4, 2048), dim3(256), 0, s, d, coef3, rows, C, stats, (float*)dh_out));
     DWN_CHECK_LAUNCH();
     return 0;
 }

@@ -47,7 +47,16 @@ __device__ __forceinline__ uint4 load_op_packed(const LoadDesc& d, i64 row, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// NN
+// NN — persistent: a workgroup owns one N-tile and a contiguous range of M-tiles.
+//   * K <= one k-tile (the point-wise expand convs, K = 64 bf16): the weight tile is loaded once and stays
+//     in LDS; the next M-tile's A rows are fetched (with their prologue) while the current tile is multiplied
+//     and stored.
+//   * MFMA operand roles are swapped (weights = A operand, activations = B operand) so that a lane's 4
+//     accumulator registers are 4 *consecutive output channels* of one row: the tile is staged to LDS with
+//     8/16-byte writes and leaves as whole 16-byte row segments.
+//   * BN Σ/Σ² (and the SE gate gradient) are accumulated in registers across all tiles of the range and
+//     flushed once per workgroup — per-tile global atomics on the same few hundred addresses serialise at
+//     the memory side (MI355X_MICROARCH.md § Global float atomics, "contention").
 // ------------------------------------------------------------------------------------------------
 template <typename T, int ALD, int EPI, int BN>
 __global__ __launch_bounds__(256) void gemm_nn_kernel(const GemmNN g) {
@@ -59,43 +68,73 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const GemmNN g) {
     constexpr int A_CH = BM * 8 / 256;
     constexpr int B_CH = BN * 8 / 256;
     constexpr int CROW = BN * (int)sizeof(T) + 16;     // epilogue staging row stride (bytes)
-    constexpr int SM_AB = (BM + BN) * ROWB;
-    constexpr int SM_C = 64 * CROW;
-    constexpr int SMEM = SM_AB > SM_C ? SM_AB : SM_C;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
-    __shared__ float lstat[2 * BN];
-    unsigned char* sA = smem;
-    unsigned char* sB = smem + BM * ROWB;
+    constexpr int CROWS = TT<T>::IS_BF16 ? 64 : 32;    // rows staged per epilogue pass
+    constexpr int NPASS = BM / CROWS;
+    constexpr int CPR = BN / KC;                       // 16-byte chunks per output row
+    __shared__ __attribute__((aligned(16))) unsigned char sA[BM * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char sB[BN * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char sC[CROWS * CROW];
+    __shared__ float lred[2 * BN];
 
     const int tid = threadIdx.x;
     const int ntn = (g.N + BN - 1) / BN;
     const int ntm = (g.M + BM - 1) / BM;
-    // XCD-aware order: blocks b and b+8 share an XCD's L2, so the N-tiles of one M-tile (which
-    // re-read the same A rows) are placed 8 apart.
+    // XCD-aware order: blocks b and b+8 share an XCD's L2, so the N-tiles of one M-range (which re-read the same
+    // A rows) are placed 8 apart.
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
     const int jj = bid >> 3;
     const int nt = jj % ntn;
-    const int mt = (jj / ntn) * 8 + xcd;
-    if (mt >= ntm) return;
+    const int mr = (jj / ntn) * 8 + xcd;
+    const int nranges = (int)(gridDim.x / ntn);
+    const int tpr = (ntm + nranges - 1) / nranges;
+    const int mt_beg = mr * tpr;
+    const int mt_end = (mt_beg + tpr < ntm) ? mt_beg + tpr : ntm;
+    if (mt_beg >= mt_end) return;
     const int grp = blockIdx.y;
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int n0 = nt * BN;
     const int acol0 = grp * g.K;
     const T* Bp = reinterpret_cast<const T*>(g.b) + (i64)grp * g.N * g.ldb;
     const int ccol0 = grp * g.N;
-
-    if (tid < 2 * BN) lstat[tid] = 0.f;
+    const bool single = g.K <= BK;
 
     uint4 ra[A_CH], rb[B_CH];
-    auto load_tiles = [&](int k0) {
+    // A staging: this thread's 16-byte column chunk (kc = tid & 7) is the same for its A_CH rows, so the
+    // per-channel prologue coefficients are loaded once per k-tile, not once per chunk
+    ColCoef<ALD == LD_PE ? LD_PLAIN : ALD, T> cf;
+    int cf_k = -1;
+    const T* Ap = reinterpret_cast<const T*>(g.a.p);
+    const T* Aq = reinterpret_cast<const T*>(g.a.q);
+    auto load_a = [&](int m0, int k0) {
+        const int kc = tid & 7;
+        const int k = k0 + kc * KC;
+        const bool kok = k < g.K;
+        if constexpr (ALD == LD_PE) {
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            int c = tid + 256 * i;
-            int row = c >> 3, kc = c & 7;
-            int m = m0 + row, k = k0 + kc * KC;
-            if (m < g.M && k < g.K) ra[i] = load_op_packed<ALD, T>(g.a, (i64)m, acol0 + k);
-            else ra[i] = make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < A_CH; ++i) {
+                int m = m0 + (tid >> 3) + 32 * i;
+                ra[i] = (m < g.M && kok) ? load_op_packed<LD_PE, T>(g.a, (i64)m, acol0 + k) : make_uint4(0, 0, 0, 0);
+            }
+        } else {
+            if (kok && k != cf_k) { cf.load(g.a, acol0 + k); cf_k = k; }
+            uint4 rp[A_CH], rq[A_CH];
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                int m = m0 + (tid >> 3) + 32 * i;
+                const bool ok = m < g.M && kok;
+                const i64 off = ok ? (i64)m * g.a.ld + acol0 + k : 0;
+                rp[i] = *reinterpret_cast<const uint4*>(Ap + off);
+                if constexpr (decltype(cf)::two_tensors) rq[i] = *reinterpret_cast<const uint4*>(Aq + off);
+                else rq[i] = make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                int m = m0 + (tid >> 3) + 32 * i;
+                ra[i] = (m < g.M && kok) ? cf.apply(g.a, (unsigned)m, rp[i], rq[i]) : make_uint4(0, 0, 0, 0);
+            }
         }
+    };
+    auto load_b = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < B_CH; ++i) {
             int c = tid + 256 * i;
@@ -105,13 +144,15 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const GemmNN g) {
             else rb[i] = make_uint4(0, 0, 0, 0);
         }
     };
-    auto store_tiles = [&]() {
+    auto store_a = [&]() {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
             int c = tid + 256 * i;
             int row = c >> 3, kc = c & 7;
             *reinterpret_cast<uint4*>(sA + row * ROWB + ((kc ^ (row & 7)) << 4)) = ra[i];
         }
+    };
+    auto store_b = [&]() {
 #pragma unroll
         for (int i = 0; i < B_CH; ++i) {
             int c = tid + 256 * i;
@@ -120,22 +161,12 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const GemmNN g) {
         }
     };
 
-    f32x4_t acc[4][NJ];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 15, lg = lane >> 4;
+    f32x4_t acc[4][NJ];
 
-    load_tiles(0);
-    store_tiles();
-    __syncthreads();
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
-        const bool has_next = (k0 + BK) < g.K;
-        if (has_next) load_tiles(k0 + BK);
+    auto mma_tile = [&]() {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             uint4 af[4], bfr[NJ];
@@ -150,150 +181,194 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const GemmNN g) {
                 int row = wn * (BN / 2) + j * 16 + lr;
                 bfr[j] = *reinterpret_cast<const uint4*>(sB + row * ROWB + ((chunk ^ (row & 7)) << 4));
             }
+            // swapped roles: D[n = 4*lg + r][m = lr] — acc[i][j][r] = C[m = i*16 + lr][n = j*16 + 4*lg + r]
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
+                for (int j = 0; j < NJ; ++j) Mma<T>::run(bfr[j], af[i], acc[i][j]);
+        }
+    };
+
+    // read-back role of this thread: one 16-byte column chunk, rows tid/CPR + k*(256/CPR)
+    const int ch = tid % CPR;
+    const int ncol = n0 + ch * KC;
+    float st0[KC], st1[KC], dgp[KC], s3[KC], t3[KC];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) { st0[i] = 0.f; st1[i] = 0.f; dgp[i] = 0.f; s3[i] = 0.f; t3[i] = 0.f; }
+    if constexpr (EPI == EPI_DG) {
+        if (ncol < g.N && g.s3) { ld_coef<KC>(g.s3 + ncol, s3); ld_coef<KC>(g.t3 + ncol, t3); }
+    }
+    [[maybe_unused]] int dg_b = -1;                    // sample whose partial sums dgp currently holds
+    T* Cp = reinterpret_cast<T*>(g.c);
+
+    // flush dgp (sample dg_b) through LDS: one global atomic per column per workgroup
+    auto flush_dg = [&]() {
+        if (tid < BN) lred[tid] = 0.f;
+        __syncthreads();
+        if (ncol < g.N) {
+#pragma unroll
+            for (int i = 0; i < KC; ++i) atomicAdd(&lred[ch * KC + i], dgp[i]);
         }
         __syncthreads();
-        if (has_next) {
-            store_tiles();
-            __syncthreads();
-        }
-    }
+        if (tid < BN && n0 + tid < g.N && dg_b >= 0) atomicAdd(g.dg + (i64)dg_b * g.dg_ld + n0 + tid, lred[tid]);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KC; ++i) dgp[i] = 0.f;
+    };
 
-    if constexpr (EPI == EPI_READOUT) {
-        // out[b][n][t] = softplus_beta(acc + bias[n]); 4 accumulator regs = 4 consecutive rows m = b*Tn + t
-        const float beta = g.sp_beta;
+    if (single) {
+        load_b(0);
+        store_b();
+        load_a(mt_beg * BM, 0);
+        store_a();
+        __syncthreads();
+    }
+    for (int mt = mt_beg; mt < mt_end; ++mt) {
+        const int m0 = mt * BM;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            int nl = n0 + wn * (BN / 2) + j * 16 + lr;
-            int n = ccol0 + nl;
-            if (nl >= g.N || n >= g.n_valid) continue;
-            float bias = g.bias ? g.bias[n] : 0.f;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int mb = m0 + wm * 64 + i * 16 + lg * 4;
-                float o[4];
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (single) {
+            if (mt + 1 < mt_end) load_a((mt + 1) * BM, 0);      // in flight under the MFMAs and the epilogue
+            mma_tile();
+        } else {
+            load_a(m0, 0);
+            load_b(0);
+            store_a();
+            store_b();
+            __syncthreads();
+            for (int k0 = 0; k0 < g.K; k0 += BK) {
+                const bool has_next = (k0 + BK) < g.K;
+                if (has_next) { load_a(m0, k0 + BK); load_b(k0 + BK); }
+                mma_tile();
+                __syncthreads();
+                if (has_next) {
+                    store_a();
+                    store_b();
+                    __syncthreads();
+                }
+            }
+        }
+
+        if constexpr (EPI == EPI_READOUT) {
+            // out[b][n][t] = softplus_beta(acc + bias[n]); lanes lr = 16 consecutive rows m = b*Tn + t
+            const float beta = g.sp_beta;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float z = acc[i][j][r] + bias;
-                    float bz = z * beta;
-                    o[r] = bz > 20.f ? z : log1pf(__expf(bz)) / beta;
-                }
-                if ((g.Tn & 3) == 0 && mb + 3 < g.M) {
-                    int b = mb / g.Tn, t = mb % g.Tn;
-                    *reinterpret_cast<float4*>(g.out_nct + ((i64)b * g.n_valid + n) * g.Tn + t) =
-                        make_float4(o[0], o[1], o[2], o[3]);
-                } else {
+                    int nl = n0 + wn * (BN / 2) + j * 16 + lg * 4 + r;
+                    int n = ccol0 + nl;
+                    if (nl >= g.N || n >= g.n_valid) continue;
+                    float bias = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        int m = mb + r;
-                        if (m < g.M) {
-                            int b = m / g.Tn, t = m % g.Tn;
-                            g.out_nct[((i64)b * g.n_valid + n) * g.Tn + t] = o[r];
+                    for (int i = 0; i < 4; ++i) {
+                        int m = m0 + wm * 64 + i * 16 + lr;
+                        if (m >= g.M) continue;
+                        float z = acc[i][j][r] + bias;
+                        float bz = z * beta;
+                        float o = bz > 20.f ? z : log1pf(__expf(bz)) / beta;
+                        int b = m / g.Tn, t = m % g.Tn;
+                        g.out_nct[((i64)b * g.n_valid + n) * g.Tn + t] = o;
+                    }
+                }
+        } else {
+            // ---- stage through LDS in passes of CROWS rows; leave as whole 16-byte row segments
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int prow0 = pass * CROWS;            // first tile row of this pass
+                if (wm == prow0 / 64) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int trow = wm * 64 + i * 16 + lr;
+                        if (trow >= prow0 && trow < prow0 + CROWS) {
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j) {
+                                const int col = wn * (BN / 2) + j * 16 + lg * 4;
+                                unsigned char* dst = sC + (trow - prow0) * CROW + col * (int)sizeof(T);
+                                if constexpr (TT<T>::IS_BF16) {
+                                    uint2 v;
+                                    v.x = (uint32_t)f2bf(acc[i][j][0]) | ((uint32_t)f2bf(acc[i][j][1]) << 16);
+                                    v.y = (uint32_t)f2bf(acc[i][j][2]) | ((uint32_t)f2bf(acc[i][j][3]) << 16);
+                                    *reinterpret_cast<uint2*>(dst) = v;
+                                } else {
+                                    *reinterpret_cast<float4*>(dst) =
+                                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                                }
+                            }
                         }
                     }
                 }
-            }
-        }
-        return;
-    } else {
-        // ---- batch-norm statistics of the stored (T-rounded) outputs, from registers
-        if (g.stats) {
+                __syncthreads();
+                const int mp = m0 + prow0;
+                for (int row = tid / CPR; row < CROWS; row += 256 / CPR) {
+                    const int m = mp + row;
+                    if (m >= g.M || ncol >= g.N) continue;
+                    const uint4 raw = *reinterpret_cast<const uint4*>(sC + row * CROW + ch * 16);
+                    *reinterpret_cast<uint4*>(Cp + (i64)m * g.ldc + ccol0 + ncol) = raw;
+                    float v[KC];
+                    unpack16<T>(raw, v);
+                    if (g.stats) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                float s = 0.f, ss = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = round_t<T>(acc[i][j][r]);
-                        s += v;
-                        ss += v * v;
+                        for (int i = 0; i < KC; ++i) { st0[i] += v[i]; st1[i] += v[i] * v[i]; }
                     }
-                s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
-                s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
-                if (lg == 0) {
-                    int col = wn * (BN / 2) + j * 16 + lr;
-                    atomicAdd(&lstat[col], s);
-                    atomicAdd(&lstat[BN + col], ss);
+                    if constexpr (EPI == EPI_DG) {
+                        // a pass straddles a sample boundary only if rows_per_sample % CROWS != 0: the rows of
+                        // the minority sample then use direct atomics
+                        const int b = m / g.rows_per_sample;
+                        float y[KC];
+                        ld_vec<T>(reinterpret_cast<const T*>(g.y3) + (i64)m * g.ldy3 + ncol, y);
+                        const int b_pass = mp / g.rows_per_sample;
+                        if (g.s3) {          // y3 raw: apply bn3 + SiLU here; else `y3` already holds z3
+#pragma unroll
+                            for (int i = 0; i < KC; ++i) y[i] = siluf_(fmaf(y[i], s3[i], t3[i]));
+                        }
+                        if (b == b_pass) {
+#pragma unroll
+                            for (int i = 0; i < KC; ++i) dgp[i] += v[i] * y[i];
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < KC; ++i) atomicAdd(g.dg + (i64)b * g.dg_ld + ncol + i, v[i] * y[i]);
+                        }
+                    }
+                }
+                if constexpr (EPI == EPI_DG) {
+                    // dgp belongs to sample b_pass; flush when the next pass starts a different sample (uniform)
+                    const int b_pass = mp / g.rows_per_sample;
+                    dg_b = b_pass;
+                    const int m_next = mp + CROWS;
+                    const bool last = (pass == NPASS - 1) && (mt + 1 == mt_end);
+                    const int b_next = (m_next < g.M ? m_next : g.M - 1) / g.rows_per_sample;
+                    if (last || b_next != b_pass || m_next >= g.M) flush_dg();
+                    else __syncthreads();
+                } else {
+                    __syncthreads();
                 }
             }
         }
+        if (single && mt + 1 < mt_end) {
+            if constexpr (EPI == EPI_READOUT) __syncthreads();   // no barrier in that epilogue: all waves must be done with sA
+            store_a();
+            __syncthreads();
+        }
+    }
+    if constexpr (EPI != EPI_READOUT) {
         if (g.stats) {
+            if (tid < 2 * BN) lred[tid] = 0.f;
+            __syncthreads();
+            if (ncol < g.N) {
+#pragma unroll
+                for (int i = 0; i < KC; ++i) {
+                    atomicAdd(&lred[ch * KC + i], st0[i]);
+                    atomicAdd(&lred[BN + ch * KC + i], st1[i]);
+                }
+            }
             __syncthreads();
             if (tid < 2 * BN) {
                 int col = tid % BN, which = tid / BN;
                 if (n0 + col < g.N)
-                    stat_add(g.stats, (int)(blockIdx.x % DWN_NREP), g.stat_nchan, which, ccol0 + n0 + col, lstat[tid]);
+                    stat_add(g.stats, (int)(blockIdx.x % DWN_NREP), g.stat_nchan, which, ccol0 + n0 + col, lred[tid]);
             }
-        }
-        // ---- stage the tile through LDS (two 64-row halves) so global stores are whole row segments
-        constexpr int CPR = BN / KC;
-        T* Cp = reinterpret_cast<T*>(g.c);
-        [[maybe_unused]] __shared__ float ldg[BN];
-        for (int half = 0; half < 2; ++half) {
-            if (wm == half) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            int row = i * 16 + lg * 4 + r;
-                            int col = wn * (BN / 2) + j * 16 + lr;
-                            *reinterpret_cast<T*>(smem + row * CROW + col * (int)sizeof(T)) = from_f<T>(acc[i][j][r]);
-                        }
-            }
-            __syncthreads();
-            const int mh = m0 + half * 64;
-            if constexpr (EPI == EPI_STORE) {
-                for (int c = tid; c < 64 * CPR; c += 256) {
-                    int row = c / CPR, ch = c % CPR;
-                    int m = mh + row, n = n0 + ch * KC;
-                    if (m < g.M && n < g.N)
-                        *reinterpret_cast<uint4*>(Cp + (i64)m * g.ldc + ccol0 + n) =
-                            *reinterpret_cast<const uint4*>(smem + row * CROW + ch * 16);
-                }
-            } else {  // EPI_DG: store + dg[b][n] += sum_rows C[m][n] * silu(s3[n]*y3[m][n] + t3[n])
-                const int ch = tid % CPR;              // fixed per thread (256 % CPR == 0)
-                const int n = n0 + ch * KC;
-                float s3[KC], t3[KC];
-                if (n < g.N) { ld_coef<KC>(g.s3 + n, s3); ld_coef<KC>(g.t3 + n, t3); }
-                const int mend = (mh + 64 < g.M ? mh + 64 : g.M);
-                if (mh < mend) {
-                    const int b_first = mh / g.rows_per_sample, b_last = (mend - 1) / g.rows_per_sample;
-                    for (int b = b_first; b <= b_last; ++b) {
-                        float part[KC];
-#pragma unroll
-                        for (int i = 0; i < KC; ++i) part[i] = 0.f;
-                        if (n < g.N) {
-                            for (int row = tid / CPR; row < 64; row += 256 / CPR) {
-                                int m = mh + row;
-                                if (m >= g.M || m / g.rows_per_sample != b) continue;
-                                uint4 raw = *reinterpret_cast<const uint4*>(smem + row * CROW + ch * 16);
-                                *reinterpret_cast<uint4*>(Cp + (i64)m * g.ldc + n) = raw;
-                                float du[KC], y[KC];
-                                unpack16<T>(raw, du);
-                                ld_vec<T>(reinterpret_cast<const T*>(g.y3) + (i64)m * g.ldy3 + n, y);
-#pragma unroll
-                                for (int i = 0; i < KC; ++i) part[i] += du[i] * siluf_(fmaf(y[i], s3[i], t3[i]));
-                            }
-                        }
-                        if (tid < BN) ldg[tid] = 0.f;
-                        __syncthreads();
-                        if (n < g.N) {
-#pragma unroll
-                            for (int i = 0; i < KC; ++i) atomicAdd(&ldg[ch * KC + i], part[i]);
-                        }
-                        __syncthreads();
-                        if (tid < BN && n0 + tid < g.N) atomicAdd(g.dg + (i64)b * g.dg_ld + n0 + tid, ldg[tid]);
-                        __syncthreads();
-                    }
-                }
-            }
-            __syncthreads();
         }
     }
 }
@@ -302,15 +377,16 @@ template <typename T, int ALD, int EPI>
 static int launch_nn_t(const GemmNN& g, hipStream_t s) {
     const int BM = 128;
     const int ntm = (g.M + BM - 1) / BM;
-    const int ntm8 = (ntm + 7) / 8 * 8;
-    // BN = 64 when N <= 64 (pw-linear into 64 channels); 128 otherwise
-    if (g.N <= 64) {
-        dim3 grid(ntm8 * ((g.N + 63) / 64), g.groups);
-        hipLaunchKernelGGL((gemm_nn_kernel<T, ALD, EPI, 64>), grid, dim3(256), 0, s, g);
-    } else {
-        dim3 grid(ntm8 * ((g.N + 127) / 128), g.groups);
-        hipLaunchKernelGGL((gemm_nn_kernel<T, ALD, EPI, 128>), grid, dim3(256), 0, s, g);
-    }
+    const int BNv = g.N <= 64 ? 64 : 128;
+    const int ntn = (g.N + BNv - 1) / BNv;
+    // ~3 resident workgroups per CU; every workgroup gets a contiguous range of M-tiles
+    int nranges = (768 + ntn * g.groups - 1) / (ntn * g.groups);
+    if (nranges > ntm) nranges = ntm;
+    if (nranges < 1) nranges = 1;
+    nranges = (nranges + 7) / 8 * 8;
+    dim3 grid(nranges * ntn, g.groups);
+    if (BNv == 64) hipLaunchKernelGGL((gemm_nn_kernel<T, ALD, EPI, 64>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_nn_kernel<T, ALD, EPI, 128>), grid, dim3(256), 0, s, g);
     DWN_CHECK_LAUNCH();
     return 0;
 }
@@ -333,6 +409,7 @@ static int launch_nn_d(const GemmNN& g, hipStream_t s) {
         case LD_PE: return launch_nn_t<T, LD_PE, EPI_STORE>(g, s);
         case LD_BNACT: return launch_nn_t<T, LD_BNACT, EPI_STORE>(g, s);
         case LD_AFFINE2: return launch_nn_t<T, LD_AFFINE2, EPI_STORE>(g, s);
+        case LD_GATE: return launch_nn_t<T, LD_GATE, EPI_STORE>(g, s);
     }
     return dwn_set_error(-3, "gemm_nn: unsupported loader kind");
 }
@@ -352,7 +429,7 @@ template <> struct TnCfg<float>  { static constexpr int PAD = 64; };   // 16-ban
 template <typename T, int PLD, int QLD>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN g) {
     constexpr int KC = TT<T>::KC;
-    constexpr int BR = 128, BC = 128, BMK = 32;
+    constexpr int BR = 128, BC = 128, BMK = TT<T>::IS_BF16 ? 64 : 32;   // M rows per step
     constexpr int RS = BR * (int)sizeof(T) + TnCfg<T>::PAD;      // LDS row stride (bytes), both tiles
     constexpr int CPR = BR / KC;                                  // 16-byte chunks per tile row
     constexpr int NCH = BMK * CPR / 256;                          // chunks per thread per tile (2 bf16 / 4 f32)
@@ -382,24 +459,53 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN g) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     uint4 rp[NCH], rq[NCH];
+    // this thread's column chunk (tid % CPR) never changes: hoist the prologue coefficients out of the M loop
+    const int chq = tid % CPR;
+    const int rcol = r0 + chq * KC, ccol = c0 + chq * KC;
+    const bool rok = rcol < Rl, cok = ccol < g.Cc;
+    ColCoef<PLD == LD_PE ? LD_PLAIN : PLD, T> cfp;
+    ColCoef<QLD == LD_PE ? LD_PLAIN : QLD, T> cfq;
+    if (rok) cfp.load(g.p, pcol0 + rcol);
+    if (cok) cfq.load(g.q, qcol0 + ccol);
+    const T* Pp = reinterpret_cast<const T*>(g.p.p);
+    const T* Pq = reinterpret_cast<const T*>(g.p.q);
+    const T* Qp = reinterpret_cast<const T*>(g.q.p);
+    const T* Qq = reinterpret_cast<const T*>(g.q.q);
     auto load_tiles = [&](i64 mb) {
+        uint4 p1[NCH], p2[NCH], q1[NCH], q2[NCH];
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            int c = tid + 256 * i;
-            int mrow = c / CPR, ch = c % CPR;
-            i64 m = mb + mrow;
-            int r = r0 + ch * KC, cc = c0 + ch * KC;
-            rp[i] = (m < mend && r < Rl) ? load_op_packed<PLD, T>(g.p, m, pcol0 + r) : make_uint4(0, 0, 0, 0);
-            rq[i] = (m < mend && cc < g.Cc) ? load_op_packed<QLD, T>(g.q, m, qcol0 + cc) : make_uint4(0, 0, 0, 0);
+            i64 m = mb + tid / CPR + (256 / CPR) * i;
+            const bool mok = m < mend;
+            const i64 offp = (mok && rok) ? m * g.p.ld + pcol0 + rcol : 0;
+            const i64 offq = (mok && cok) ? m * g.q.ld + qcol0 + ccol : 0;
+            if constexpr (PLD != LD_PE) {
+                p1[i] = *reinterpret_cast<const uint4*>(Pp + offp);
+                if constexpr (decltype(cfp)::two_tensors) p2[i] = *reinterpret_cast<const uint4*>(Pq + offp);
+                else p2[i] = make_uint4(0, 0, 0, 0);
+            }
+            if constexpr (QLD != LD_PE) {
+                q1[i] = *reinterpret_cast<const uint4*>(Qp + offq);
+                if constexpr (decltype(cfq)::two_tensors) q2[i] = *reinterpret_cast<const uint4*>(Qq + offq);
+                else q2[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            i64 m = mb + tid / CPR + (256 / CPR) * i;
+            const bool mok = m < mend;
+            if constexpr (PLD == LD_PE) rp[i] = (mok && rok) ? load_op_packed<LD_PE, T>(g.p, m, pcol0 + rcol) : make_uint4(0, 0, 0, 0);
+            else rp[i] = (mok && rok) ? cfp.apply(g.p, (unsigned)m, p1[i], p2[i]) : make_uint4(0, 0, 0, 0);
+            if constexpr (QLD == LD_PE) rq[i] = (mok && cok) ? load_op_packed<LD_PE, T>(g.q, m, qcol0 + ccol) : make_uint4(0, 0, 0, 0);
+            else rq[i] = (mok && cok) ? cfq.apply(g.q, (unsigned)m, q1[i], q2[i]) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_tiles = [&]() {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            int c = tid + 256 * i;
-            int mrow = c / CPR, ch = c % CPR;
-            *reinterpret_cast<uint4*>(sP + mrow * RS + ch * 16) = rp[i];
-            *reinterpret_cast<uint4*>(sQ + mrow * RS + ch * 16) = rq[i];
+            int mrow = tid / CPR + (256 / CPR) * i;
+            *reinterpret_cast<uint4*>(sP + mrow * RS + chq * 16) = rp[i];
+            *reinterpret_cast<uint4*>(sQ + mrow * RS + chq * 16) = rq[i];
         }
     };
 
@@ -414,30 +520,34 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN g) {
         if constexpr (TT<T>::IS_BF16) {
             // transposed fragments: lane 4q+p of each 16-lane group addresses row (8*lg + 4h + q), cols 4p..4p+3
             const int q = lr >> 2, p = lr & 3;
-            bf16x8_t af[4], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int colb = (wm * 64 + i * 16 + 4 * p) * 2;
-                auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(sP + (8 * lg + q) * RS + colb));
-                auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(sP + (8 * lg + 4 + q) * RS + colb));
-                af[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            for (int kb = 0; kb < BMK / 32; ++kb) {
+                bf16x8_t af[4], bfr[4];
+                const int rb = kb * 32 + 8 * lg + q;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int colb = (wm * 64 + i * 16 + 4 * p) * 2;
+                    auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t*)(sP + rb * RS + colb));
+                    auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t*)(sP + (rb + 4) * RS + colb));
+                    af[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int colb = (wn * 64 + j * 16 + 4 * p) * 2;
+                    auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t*)(sQ + rb * RS + colb));
+                    auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t*)(sQ + (rb + 4) * RS + colb));
+                    bfr[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int colb = (wn * 64 + j * 16 + 4 * p) * 2;
-                auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(sQ + (8 * lg + q) * RS + colb));
-                auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(sQ + (8 * lg + 4 + q) * RS + colb));
-                bfr[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         } else {
 #pragma unroll
             for (int ks = 0; ks < BMK / 4; ++ks) {
@@ -491,6 +601,7 @@ static int launch_tn_d(const GemmTN& g, hipStream_t s) {
     const int pk = g.p_kind, qk = g.q_kind;
     if (pk == LD_AFFINE2 && qk == LD_PE) return launch_tn_t<T, LD_AFFINE2, LD_PE>(g, s);
     if (pk == LD_PLAIN && qk == LD_BNACT) return launch_tn_t<T, LD_PLAIN, LD_BNACT>(g, s);
+    if (pk == LD_PLAIN && qk == LD_GATE) return launch_tn_t<T, LD_PLAIN, LD_GATE>(g, s);
     if (pk == LD_PLAIN && qk == LD_PLAIN) return launch_tn_t<T, LD_PLAIN, LD_PLAIN>(g, s);
     if (pk == LD_AFFINE2 && qk == LD_PLAIN) return launch_tn_t<T, LD_AFFINE2, LD_PLAIN>(g, s);
     return dwn_set_error(-3, "gemm_tn: unsupported loader combination");
@@ -502,11 +613,11 @@ int launch_gemm_tn(const GemmTN& g_in, int dtype, hipStream_t s) {
     if (g.nsplit <= 0) {
         int tiles = ((g.R + 127) / 128) * ((g.Cc + 127) / 128) * g.groups;
         int want = (1024 + tiles - 1) / tiles;
-        int maxsplit = (g.M + 255) / 256;
+        int maxsplit = (g.M + 511) / 512;
         if (want > maxsplit) want = maxsplit;
         if (want < 1) want = 1;
         int rows = (g.M + want - 1) / want;
-        rows = (rows + 31) / 32 * 32;
+        rows = (rows + 63) / 64 * 64;
         g.rows_per_split = rows;
         g.nsplit = (g.M + rows - 1) / rows;
     }

@@ -24,7 +24,10 @@ int k_stem_fwd(const float* x, const float* w, void* y, int B, int Cin, i64 S, i
 int k_stem_bwd(const LoadDesc& dy, const float* x, float* dw, int B, int Cin, i64 S, int C0, int dtype, hipStream_t s);
 int k_shortcut_stats(const LoadDesc& xin, const ResGeom& gm, double* stats, int dtype, hipStream_t s);
 int k_residual_fwd(const LoadDesc& xin, const void* y4, const float* coef4, const float* coefsc, const float* dscale,
-                   const ResGeom& gm, void* out, int dtype, hipStream_t s);
+                   const ResGeom& gm, const float* ope_t, const float* ope_h, const float* ope_w, void* out, int dtype,
+                   hipStream_t s);
+int k_stem_bn_pe(const void* y0, const float* coef, const float* pe_t, const float* pe_h, const float* pe_w, int Tn,
+                 int H, int W, i64 rows, int C, void* out, int dtype, hipStream_t s);
 int k_residual_bwd_reduce(const LoadDesc& xin, const void* y4, const void* dout, const float* coef4,
                           const float* coefsc, const float* dscale, const ResGeom& gm, double* stats4,
                           double* statssc, int dtype, hipStream_t s);
@@ -32,13 +35,13 @@ int k_residual_bwd_dy4(const void* y4, const void* dout, const float* abc4, cons
                        void* dy4, int dtype, hipStream_t s);
 int k_residual_bwd_dx(const LoadDesc& xin, const void* da0, const void* dout, const float* abcsc, const ResGeom& gm,
                       void* dx, int dtype, hipStream_t s);
-int k_se_pool(const LoadDesc& z3, int B, int C, int rows_per_sample, float* pooled, int dtype, hipStream_t s);
+int k_se_pool(const LoadDesc& z3, int B, int C, int rows_per_sample, float* pooled, void* z3out, int dtype, hipStream_t s);
 int k_se_mlp_fwd(const float* pooled_sum, float inv_s, const float* wr, const float* br, const float* we,
                  const float* be, int B, int C, int R, float* pmean, float* hid_pre, float* gate, hipStream_t s);
 int k_se_mlp_bwd(const float* dg, const float* gate, const float* hid_pre, const float* pmean, const float* wr,
                  const float* we, int B, int C, int R, float inv_s, float* dgp, float* dhp, float* dps, float* dwr,
                  float* dbr, float* dwe, float* dbe, hipStream_t s);
-int k_bn3_bwd_reduce(const LoadDesc& d, const float* coef3, i64 rows, int C, double* stats, int dtype, hipStream_t s);
+int k_bn3_bwd_reduce(const LoadDesc& d, const float* coef3, i64 rows, int C, double* stats, void* dh_out, int dtype, hipStream_t s);
 int k_pool_fwd(const void* x, void* out, i64 BT, int HW, int C, int dtype, hipStream_t s);
 int k_pool_bwd(const void* dpool, void* dx, i64 BT, int HW, int C, int dtype, hipStream_t s);
 int k_cortex_residual_fwd(const void* y, const void* x, const float* coef, const float* coefsc, const float* dscale,

@@ -166,11 +166,15 @@ class InvertedResidual3d(nn.Module):
             self._geom_cache = {key: geom}
         return geom
 
-    def forward(self, x: torch.Tensor, pe: PositionalEncoding3d, dtype: torch.dtype) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, pe: PositionalEncoding3d, dtype: torch.dtype, x_has_pe: bool = False,
+                out_pe=None) -> torch.Tensor:
+        """``x_has_pe``: the producer of ``x`` already added this block's positional encoding (the stem / the
+        previous block's residual kernel do, inside DepthwiseCore).  ``out_pe``: the NEXT block's PE tables, to be
+        folded into this block's output pass."""
         b, t, h, w, _ = x.shape
         geom = self.geometry(pe, t, h, w, x.device)
         drop = self.drop_path.sample(b, x.device)
-        return ops.BlockFn.apply(x, drop, self, geom, dtype, *self.parameters_in_kernel_order())
+        return ops.BlockFn.apply(x, drop, self, geom, dtype, x_has_pe, out_pe, *self.parameters_in_kernel_order())
 
 
 class ShuffleLayer(nn.Module):
@@ -261,11 +265,22 @@ class DepthwiseCore(nn.Module):
         self.blocks = nn.Sequential(*blocks)
 
     def forward(self, x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        # Every PositionalEncoding3d add is folded into the kernel that *produces* the tensor it is added to:
+        # the stem's BN pass for block 0, block i's residual pass for block i+1 (no separate elementwise pass, and
+        # the point-wise GEMM prologues stay plain loads).
         bn = self.stem[1].bn
-        x = ops.StemFn.apply(x, self.stem[0].weight, bn.weight, bn.bias, self, dtype)
         mods = list(self.blocks)
-        for pe, blk in zip(mods[0::2], mods[1::2]):
-            x = blk(x, pe, dtype)
+        pes, blks = mods[0::2], mods[1::2]
+        _, _, t, h, w = x.shape
+        sizes = []
+        for blk in blks:
+            sizes.append((h, w))
+            s = blk.spatial_stride
+            h, w = (h - 1) // s + 1, (w - 1) // s + 1
+        tables = [blk.geometry(pe, t, hw[0], hw[1], x.device)[:3] for pe, blk, hw in zip(pes, blks, sizes)]
+        x = ops.StemFn.apply(x, self.stem[0].weight, bn.weight, bn.bias, self, dtype, tables[0])
+        for i, (pe, blk) in enumerate(zip(pes, blks)):
+            x = blk(x, pe, dtype, True, tables[i + 1] if i + 1 < len(blks) else None)
         return x
 
 

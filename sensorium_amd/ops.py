@@ -102,7 +102,7 @@ class StemFn(torch.autograd.Function):
     Returns the channels-last activation [B,T,H,W,C0] in the compute dtype."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, mod, dtype):
+    def forward(ctx, x, weight, gamma, beta, mod, dtype, pe=None):
         _require_gpu(x, "StemFn")
         conv, bn = mod.stem[0], mod.stem[1].bn
         _check_bn(bn)
@@ -118,6 +118,9 @@ class StemFn(torch.autograd.Function):
         a.eps = bn.eps; a.momentum = bn.momentum
         a.x = x.data_ptr(); a.w = weight.data_ptr(); a.bn = _bn_struct(bn, coef)
         a.y0 = y0.data_ptr(); a.out = out.data_ptr()
+        if pe is not None:       # positional encoding of the first block, folded into the stem's output pass
+            a.pe_t, a.pe_h, a.pe_w = (t.data_ptr() for t in pe)
+        a.T, a.H, a.W = T, H, W
         ws = _ws(L.lib.dwn_stem_workspace_bytes(C.byref(a)), dev)
         a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
         L.check(L.lib.dwn_stem_forward(C.byref(a), dev.index, _stream(dev)), "dwn_stem_forward")
@@ -146,7 +149,7 @@ class StemFn(torch.autograd.Function):
         ws = _ws(L.lib.dwn_stem_workspace_bytes(C.byref(a)), dev)
         a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
         L.check(L.lib.dwn_stem_backward(C.byref(a), dev.index, _stream(dev)), "dwn_stem_backward")
-        return None, dw.view_as(weight), dgamma, dbeta, None, None
+        return None, dw.view_as(weight), dgamma, dbeta, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -156,7 +159,7 @@ _BLOCK_PARAMS = ("w_pw", "g1", "b1", "w_dws", "g2", "b2", "w_dwt", "g3", "b3", "
                  "w_pwl", "g4", "b4", "gsc", "bsc")
 
 
-def _block_args(blk, geom, x, dtype, training, coefs, saved, drop_scale):
+def _block_args(blk, geom, x, dtype, training, coefs, saved, drop_scale, x_has_pe, a0):
     """Fill the fields shared by forward and backward."""
     B, T, Hin, Win, Cin = x.shape
     a = L.BlockArgs()
@@ -170,6 +173,8 @@ def _block_args(blk, geom, x, dtype, training, coefs, saved, drop_scale):
     bn1 = blk.conv_pw[1].bn
     a.eps = bn1.eps; a.momentum = bn1.momentum
     a.x = x.data_ptr()
+    a.x_has_pe = int(x_has_pe)
+    a.a0 = _ptr(a0)
     pe_t, pe_h, pe_w, hsrc, wsrc, hinv, winv = geom
     a.pe_t = pe_t.data_ptr(); a.pe_h = pe_h.data_ptr(); a.pe_w = pe_w.data_ptr()
     a.hsrc = hsrc.data_ptr(); a.wsrc = wsrc.data_ptr(); a.hinv = hinv.data_ptr(); a.winv = winv.data_ptr()
@@ -189,7 +194,7 @@ class BlockFn(torch.autograd.Function):
     """x -> InvertedResidual3d(x + PositionalEncoding3d) (dwiseneuro.py:136-144, 184-192), channels-last."""
 
     @staticmethod
-    def forward(ctx, x, drop_scale, blk, geom, dtype, *params):
+    def forward(ctx, x, drop_scale, blk, geom, dtype, x_has_pe, out_pe, *params):
         _require_gpu(x, "BlockFn")
         x = x.contiguous()
         dev = x.device
@@ -205,24 +210,30 @@ class BlockFn(torch.autograd.Function):
         y1 = torch.empty(B, T, Hin, Win, Cmid, dtype=dtype, device=dev)
         y2 = torch.empty(B, T, Hout, Wout, Cmid, dtype=dtype, device=dev)
         y3 = torch.empty_like(y2)
+        z3 = torch.empty_like(y2)
+        a0 = None if x_has_pe else torch.empty_like(x)
         y4 = torch.empty(B, T, Hout, Wout, Cout, dtype=dtype, device=dev)
         out = torch.empty_like(y4)
         coefs = [torch.empty(4 * c, **f32) for c in (Cmid, Cmid, Cmid, Cout, Cout)]
         R = blk.se.conv_reduce.out_channels
         saved = dict(pmean=torch.empty(B, Cmid, **f32), hidpre=torch.empty(B, R, **f32),
                      gate=torch.empty(B, Cmid, **f32))
-        a = _block_args(blk, geom, x, dtype, training, coefs, saved, drop_scale)
+        a = _block_args(blk, geom, x, dtype, training, coefs, saved, drop_scale, x_has_pe, a0)
         a.out = out.data_ptr()
         a.y1 = y1.data_ptr(); a.y2 = y2.data_ptr(); a.y3 = y3.data_ptr(); a.y4 = y4.data_ptr()
+        a.z3 = z3.data_ptr()
+        if out_pe is not None:   # next block's positional encoding, folded into this block's residual pass
+            a.out_pe_t, a.out_pe_h, a.out_pe_w = (t.data_ptr() for t in out_pe)
         a.bn1, a.bn2, a.bn3, a.bn4, a.bnsc = (_bn_struct(bn, cf) for bn, cf in zip(bns, coefs))
         ws = _ws(L.lib.dwn_block_workspace_bytes(C.byref(a), 0), dev)
         a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
         L.check(L.lib.dwn_block_forward(C.byref(a), dev.index, _stream(dev)), "dwn_block_forward")
         ctx.blk = blk; ctx.geom = geom; ctx.dtype = dtype; ctx.was_training = training
         if getattr(blk, "_capture", False):        # test hook: expose the raw intermediates
-            blk._captured = dict(y1=y1, y2=y2, y3=y3, y4=y4, coefs=coefs, **saved)
+            blk._captured = dict(y1=y1, y2=y2, y3=y3, y4=y4, z3=z3, coefs=coefs, **saved)
         ctx.has_drop = drop_scale is not None
-        tensors = [x, y1, y2, y3, y4, *coefs, saved["pmean"], saved["hidpre"], saved["gate"]]
+        # the block input *including* its positional encoding is what backward needs
+        tensors = [x if x_has_pe else a0, y1, y2, y3, y4, *coefs, saved["pmean"], saved["hidpre"], saved["gate"], z3]
         if drop_scale is not None:
             tensors.append(drop_scale)
         ctx.save_for_backward(*tensors)
@@ -237,15 +248,17 @@ class BlockFn(torch.autograd.Function):
         x, y1, y2, y3, y4 = t[:5]
         coefs = list(t[5:10])
         saved = dict(pmean=t[10], hidpre=t[11], gate=t[12])
-        drop_scale = t[13] if ctx.has_drop else None
+        z3 = t[13]
+        drop_scale = t[14] if ctx.has_drop else None
         dev = x.device
         dout = dout.contiguous()
         B, T, Hin, Win, Cin = x.shape
         Hout, Wout = y2.shape[2], y2.shape[3]
         Cmid, Cout = blk.mid_features, blk.out_features
         f32 = dict(dtype=torch.float32, device=dev)
-        a = _block_args(blk, ctx.geom, x, dtype, True, coefs, saved, drop_scale)
+        a = _block_args(blk, ctx.geom, x, dtype, True, coefs, saved, drop_scale, True, None)
         a.y1 = y1.data_ptr(); a.y2 = y2.data_ptr(); a.y3 = y3.data_ptr(); a.y4 = y4.data_ptr()
+        a.z3 = z3.data_ptr()
         bns = blk.bn_modules()
         dg = [torch.empty(c, **f32) for c in (Cmid, Cmid, Cmid, Cout, Cout)]
         db = [torch.empty(c, **f32) for c in (Cmid, Cmid, Cmid, Cout, Cout)]
@@ -278,7 +291,7 @@ class BlockFn(torch.autograd.Function):
                  dse_wr.view_as(blk.se.conv_reduce.weight), dse_br,
                  dse_we.view_as(blk.se.conv_expand.weight), dse_be,
                  dw_pwl.view_as(blk.conv_pwl[0].weight), dg[3], db[3], dg[4], db[4])
-        return (dx, None, None, None, None) + grads
+        return (dx, None, None, None, None, None, None) + grads
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Kernel-level microbenchmarks through the C-ABI (development tool; not part of the product or the tests).
+Times individual launches at the benchmark's block shapes with CUDA/HIP events and prints achieved GB/s against
+the algorithmic bytes, next to a plain device copy of the same size."""
+import ctypes as C
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+import sensorium_amd._lib as L
+
+dev = torch.device("cuda", 0)
+BF = torch.bfloat16
+
+
+def timeit(fn, n=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def desc(p, ld, **kw):
+    d = L.LoadDesc()
+    d.p = p.data_ptr(); d.ld = ld; d.rows_per_sample = 1
+    for k, v in kw.items():
+        setattr(d, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    return d
+
+
+def report(name, ms, nbytes):
+    print(f"{name:58s} {ms*1e3:9.1f} us  {nbytes/ms/1e6:8.1f} GB/s", flush=True)
+
+
+def gemm_nn(M, N, K, kind="plain", stats=False, S=None, T=32, H=36, W=64):
+    a = torch.randn(M, K, device=dev).to(BF)
+    b = (torch.randn(N, K, device=dev) / K ** 0.5).to(BF)
+    c = torch.empty(M, N, dtype=BF, device=dev)
+    st = torch.zeros(32 * 2 * N, dtype=torch.float64, device=dev)
+    keep = []
+    if kind == "plain":
+        d, k = desc(a, K), L.LD_PLAIN
+    elif kind == "pe":
+        pt, ph, pw = (torch.randn(s, K, device=dev) for s in (T, H, W))
+        keep += [pt, ph, pw]
+        d, k = desc(a, K, pe_t=pt, pe_h=ph, pe_w=pw, pT=T, pH=H, pW=W, pe_ld=K), L.LD_PE
+    elif kind == "bnact":
+        sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev)
+        gate = torch.rand(M // S, K, device=dev)
+        keep += [sc, sh, gate]
+        d, k = desc(a, K, v1=sc, v2=sh, act=1, gate=gate, gate_ld=K, rows_per_sample=S), L.LD_BNACT
+    elif kind == "gate":
+        gate = torch.rand(M // S, K, device=dev)
+        keep += [gate]
+        d, k = desc(a, K, gate=gate, gate_ld=K, rows_per_sample=S), L.LD_GATE
+    elif kind == "affine2":
+        y = torch.randn(M, K, device=dev).to(BF)
+        a1, a2, a3 = (torch.randn(K, device=dev) for _ in range(3))
+        keep += [y, a1, a2, a3]
+        d, k = desc(a, K, q=y, v1=a1, v2=a2, v3=a3), L.LD_AFFINE2
+    g = L.GemmNNArgs()
+    g.a = d; g.a_kind = k; g.b = b.data_ptr(); g.ldb = K; g.c = c.data_ptr(); g.ldc = N
+    g.M, g.N, g.K, g.groups = M, N, K, 1
+    g.stats = st.data_ptr() if stats else None; g.stat_nchan = N; g.epi = L.EPI_STORE
+    ms = timeit(lambda: L.check(L.lib.dwn_gemm_nn(C.byref(g), L.DWN_BF16, 0, stream()), "nn"))
+    nb = (M * K * (2 if kind == "affine2" else 1) + M * N) * 2
+    report(f"gemm_nn M={M} N={N} K={K} {kind} stats={int(stats)}", ms, nb)
+
+
+def gemm_tn(M, R, Cc, pk="plain", qk="plain"):
+    p = torch.randn(M, R, device=dev).to(BF)
+    q = torch.randn(M, Cc, device=dev).to(BF)
+    dw = torch.zeros(R, Cc, device=dev)
+    keep = []
+    dp, kp = desc(p, R), L.LD_PLAIN
+    if pk == "affine2":
+        y = torch.randn(M, R, device=dev).to(BF)
+        a1, a2, a3 = (torch.randn(R, device=dev) for _ in range(3))
+        keep += [y, a1, a2, a3]
+        dp, kp = desc(p, R, q=y, v1=a1, v2=a2, v3=a3), L.LD_AFFINE2
+    dq, kq = desc(q, Cc), L.LD_PLAIN
+    g = L.GemmTNArgs()
+    g.p = dp; g.p_kind = kp; g.q = dq; g.q_kind = kq
+    g.M, g.R, g.Cc = M, R, Cc
+    g.dw = dw.data_ptr(); g.lddw = Cc; g.groups = 1; g.nsplit = 0
+    ms = timeit(lambda: L.check(L.lib.dwn_gemm_tn(C.byref(g), L.DWN_BF16, 0, stream()), "tn"))
+    nb = (M * R * (2 if pk == "affine2" else 1) + M * Cc) * 2
+    report(f"gemm_tn M={M} R={R} Cc={Cc} {pk}/{qk}", ms, nb)
+
+
+def copy(nbytes):
+    a = torch.empty(nbytes // 2, dtype=BF, device=dev).normal_()
+    b = torch.empty_like(a)
+    ms = timeit(lambda: b.copy_(a))
+    report(f"torch copy {nbytes/1e6:.0f} MB (read+write)", ms, 2 * nbytes)
+
+
+def dws_fwd(planes, Hin, Win, C, stride):
+    Hout, Wout = (Hin - 1) // stride + 1, (Win - 1) // stride + 1
+    x = torch.randn(planes * Hin * Win, C, device=dev).to(BF)
+    out = torch.empty(planes * Hout * Wout, C, dtype=BF, device=dev)
+    sc, sh = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+    w = torch.randn(9, C, device=dev)
+    st = torch.zeros(32 * 2 * C, dtype=torch.float64, device=dev)
+    a = L.DwSpatialFwdArgs()
+    a.inp = desc(x, C, v1=sc, v2=sh, act=1)
+    a.w = w.data_ptr(); a.out = out.data_ptr(); a.planes = planes; a.Hin = Hin; a.Win = Win; a.Hout = Hout
+    a.Wout = Wout; a.C = C; a.stride = stride; a.ks = 3; a.stats = st.data_ptr(); a.rows_band = 0
+    ms = timeit(lambda: L.check(L.lib.dwn_dw_spatial_fwd(C_.byref(a), L.DWN_BF16, 0, stream()), "dws"))
+    report(f"dws_fwd planes={planes} {Hin}x{Win} C={C} s={stride}", ms, (x.numel() + out.numel()) * 2)
+
+
+def dws_bwd(planes, Hin, Win, C, stride):
+    Hout, Wout = (Hin - 1) // stride + 1, (Win - 1) // stride + 1
+    y1 = torch.randn(planes * Hin * Win, C, device=dev).to(BF)
+    dh2 = torch.randn(planes * Hout * Wout, C, device=dev).to(BF)
+    y2 = torch.randn(planes * Hout * Wout, C, device=dev).to(BF)
+    dh1 = torch.empty_like(y1)
+    coef = torch.rand(4 * C, device=dev) + 0.5
+    abc = torch.randn(3 * C, device=dev)
+    w = torch.randn(9, C, device=dev)
+    dw = torch.zeros(C, 9, device=dev)
+    st = torch.zeros(32 * 2 * C, dtype=torch.float64, device=dev)
+    a = L.DwSpatialBwdArgs()
+    a.dy = desc(dh2, C, q=y2, v1=abc, v2=abc[C:], v3=abc[2 * C:])
+    a.y1 = desc(y1, C, v1=coef, v2=coef[C:], v3=coef[2 * C:], v4=coef[3 * C:])
+    a.w = w.data_ptr(); a.dh1 = dh1.data_ptr(); a.dw = dw.data_ptr(); a.planes = planes; a.Hin = Hin; a.Win = Win
+    a.Hout = Hout; a.Wout = Wout; a.C = C; a.stride = stride; a.ks = 3; a.stats = st.data_ptr(); a.rows_band = 0
+    ms = timeit(lambda: L.check(L.lib.dwn_dw_spatial_bwd(C_.byref(a), L.DWN_BF16, 0, stream()), "dwsb"))
+    report(f"dws_bwd planes={planes} {Hin}x{Win} C={C} s={stride}", ms, (2 * y1.numel() + 2 * y2.numel()) * 2)
+
+
+C_ = C
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["copy", "nn", "tn", "dws"]
+    if "copy" in which:
+        copy(2_100_000_000)
+        copy(528_000_000)
+    if "nn" in which:
+        M0, M1 = 2359296, 589824
+        for kind, st in (("plain", False), ("plain", True), ("pe", True)):
+            gemm_nn(M0, 448, 64, kind, st)
+        gemm_nn(M1, 448, 64, "pe", True, T=32, H=18, W=32)
+        gemm_nn(M1, 64, 448, "plain", False)
+        gemm_nn(M1, 64, 448, "plain", True)
+        gemm_nn(M1, 64, 448, "bnact", True, S=18432)
+        gemm_nn(M1, 64, 448, "gate", True, S=18432)
+        gemm_nn(M1, 448, 64, "plain", False)
+        gemm_nn(M0, 64, 448, "affine2", False)
+    if "tn" in which:
+        gemm_tn(2359296, 448, 64, "plain")
+        gemm_tn(2359296, 448, 64, "affine2")
+        gemm_tn(589824, 64, 448, "plain")
+    if "dws" in which:
+        dws_fwd(1024, 36, 64, 448, 2)
+        dws_fwd(1024, 18, 32, 448, 1)
+        dws_bwd(1024, 36, 64, 448, 2)
+        dws_bwd(1024, 18, 32, 448, 1)
