@@ -50,8 +50,9 @@ __device__ __forceinline__ void bn_silu4(float* v, const float* s, const float* 
 template <typename T, int KS, int ST>
 __global__ __launch_bounds__(256) void dw_spatial_fwd_kernel(const DwSpatialFwd a) {
     constexpr int NCV = SL<T>::NCV, CS = SL<T>::CS, LP = SL<T>::LP, P = KS / 2;
-    const int stride = ST > 0 ? ST : a.stride;
+    constexpr int XB = 4;                              // x-iterations batched per row (loads in flight per thread)
     typedef typename SL<T>::raw_t raw_t;
+    const int stride = ST > 0 ? ST : a.stride;
     __shared__ float lstat[2 * CS];
     const int tid = threadIdx.x;
     const int cv = tid % NCV, pl = tid / NCV;
@@ -84,52 +85,61 @@ __global__ __launch_bounds__(256) void dw_spatial_fwd_kernel(const DwSpatialFwd 
         const int nro = (a.Hout - ho0 < a.rows_band) ? a.Hout - ho0 : a.rows_band;
         const int hi0 = ho0 * stride - P;
         const int rows_in = (nro - 1) * stride + KS;
-        const int nstage = rows_in * Wp;
         const i64 plane_row0 = (i64)plane * a.Hin * a.Win;
-        // stage the activated input rows (zero padded) once; 4 independent loads in flight per thread
-        for (int pix0 = pl; pix0 < nstage; pix0 += 8 * LP) {
-            raw_t raw[8];
-            bool ok[8];
+        // stage the activated input rows (zero padded).  The (row, x) walk is flat and NB loads are issued before
+        // the first one is consumed: a row-by-row loop would serialise one HBM round trip per input row.
+        {
+            constexpr int NB = 12;
+            int r = 0, x = pl;
+            while (x >= Wp) { x -= Wp; ++r; }
+            while (r < rows_in) {
+                raw_t raw[NB];
+                int rr[NB], xx[NB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                int pix = pix0 + u * LP;
-                int wi = pix % Wp - P, hi = hi0 + pix / Wp;
-                ok[u] = chan_ok && pix < nstage && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
-                i64 row = ok[u] ? plane_row0 + (i64)hi * a.Win + wi : 0;
-                raw[u] = ld4_raw<T>(inp + row * a.in.ld + chs);
-            }
+                for (int u = 0; u < NB; ++u) {
+                    rr[u] = r; xx[u] = x;
+                    const int hi = hi0 + r, wi = x - P;
+                    const bool ok = chan_ok && r < rows_in && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
+                    raw[u] = ld4_raw<T>(inp + (plane_row0 + (ok ? (i64)hi * a.Win + wi : 0)) * a.in.ld + chs);
+                    x += LP;
+                    while (x >= Wp) { x -= Wp; ++r; }
+                }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                int pix = pix0 + u * LP;
-                if (pix < nstage) {
-                    float v[4];
-                    V4<T>::unpack(raw[u], v);
-                    bn_silu4(v, bs, bt);
-                    tile[pix * NCV + cv] = ok[u] ? V4<T>::pack(v) : V4<T>::zero();
+                for (int u = 0; u < NB; ++u) {
+                    if (rr[u] < rows_in) {
+                        const int hi = hi0 + rr[u], wi = xx[u] - P;
+                        const bool ok = chan_ok && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
+                        float v[4];
+                        V4<T>::unpack(raw[u], v);
+                        bn_silu4(v, bs, bt);
+                        tile[(rr[u] * Wp + xx[u]) * NCV + cv] = ok ? V4<T>::pack(v) : V4<T>::zero();
+                    }
                 }
             }
         }
         __syncthreads();
-        for (int item = pl; item < nro * a.Wout; item += LP) {
-            int oy = item / a.Wout, ox = item % a.Wout;
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int oy = 0; oy < nro; ++oy) {
+            const i64 orow = ((i64)plane * a.Hout + ho0 + oy) * a.Wout;
+            for (int ox = pl; ox < a.Wout; ox += LP) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                const raw_t* tp = tile + ((oy * stride) * Wp + ox * stride) * NCV + cv;
 #pragma unroll
-            for (int dy = 0; dy < KS; ++dy)
+                for (int dy = 0; dy < KS; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < KS; ++dx) {
-                    int pix = (oy * stride + dy) * Wp + ox * stride + dx;
-                    float v[4];
-                    V4<T>::unpack(tile[pix * NCV + cv], v);
+                    for (int dx = 0; dx < KS; ++dx) {
+                        float v[4];
+                        V4<T>::unpack(tp[(dy * Wp + dx) * NCV], v);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[dy * KS + dx][i], v[i], acc[i]);
-                }
-            if (chan_ok) {
-                st4<T>(outp + (((i64)plane * a.Hout + ho0 + oy) * a.Wout + ox) * a.C + chan, acc);
+                        for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[dy * KS + dx][i], v[i], acc[i]);
+                    }
+                if (chan_ok) {
+                    st4<T>(outp + (orow + ox) * a.C + chan, acc);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float r = round_t<T>(acc[i]);
-                    st0[i] += r;
-                    st1[i] += r * r;
+                    for (int i = 0; i < 4; ++i) {
+                        float r = round_t<T>(acc[i]);
+                        st0[i] += r;
+                        st1[i] += r * r;
+                    }
                 }
             }
         }
@@ -144,9 +154,10 @@ __global__ __launch_bounds__(256) void dw_spatial_fwd_kernel(const DwSpatialFwd 
 template <typename T, int KS, int ST>
 __global__ __launch_bounds__(256) void dw_spatial_bwd_kernel(const DwSpatialBwd a) {
     constexpr int NCV = SL<T>::NCV, CS = SL<T>::CS, LP = SL<T>::LP, P = KS / 2;
+    constexpr int XB = 4;
     typedef typename SL<T>::raw_t raw_t;
     __shared__ float lstat[2 * CS];
-    __shared__ float lw[KS * KS * CS];
+    __shared__ __attribute__((aligned(16))) float lw[KS * KS * CS];      // stencil weights (broadcast reads), later dW
     const int tid = threadIdx.x;
     const int cv = tid % NCV, pl = tid / NCV;
     const int c0 = blockIdx.y * CS;
@@ -154,15 +165,15 @@ __global__ __launch_bounds__(256) void dw_spatial_bwd_kernel(const DwSpatialBwd 
     const bool chan_ok = chan < a.C;
     const int chs = chan_ok ? chan : 0;
     if (tid < 2 * CS) lstat[tid] = 0.f;
-    for (int i = tid; i < KS * KS * CS; i += 256) lw[i] = 0.f;
+    for (int i = tid; i < KS * KS * CS; i += 256) {
+        int k = i / CS, c = c0 + i % CS;
+        lw[i] = c < a.C ? a.w[(i64)k * a.C + c] : 0.f;
+    }
     __syncthreads();
 
-    float w[KS * KS][4], dwacc[KS * KS][4];
+    float dwacc[KS * KS][4];
 #pragma unroll
-    for (int k = 0; k < KS * KS; ++k) {
-        ldc4(a.w + (i64)k * a.C + chs, w[k]);
-        dwacc[k][0] = dwacc[k][1] = dwacc[k][2] = dwacc[k][3] = 0.f;
-    }
+    for (int k = 0; k < KS * KS; ++k) dwacc[k][0] = dwacc[k][1] = dwacc[k][2] = dwacc[k][3] = 0.f;
     float bs[4], bt[4], bm[4], bi[4], a1[4], a2[4], a3[4];
     ldc4(a.y1.v1 + chs, bs); ldc4(a.y1.v2 + chs, bt); ldc4(a.y1.v3 + chs, bm); ldc4(a.y1.v4 + chs, bi);
     ldc4(a.dy.v1 + chs, a1); ldc4(a.dy.v2 + chs, a2); ldc4(a.dy.v3 + chs, a3);
@@ -185,97 +196,108 @@ __global__ __launch_bounds__(256) void dw_spatial_bwd_kernel(const DwSpatialBwd 
         const int lo_num = hi0 + P - (KS - 1);
         const int ho_lo = lo_num >= 0 ? lo_num / s : -((-lo_num + s - 1) / s);
         const int ho_hi = (hi0 + nri - 1 + P) / s;
-        const int nstage = (ho_hi - ho_lo + 1) * Wq;
+        const int rows_q = ho_hi - ho_lo + 1;
         const i64 orow0 = (i64)plane * a.Hout * a.Wout;
-        // stage dL/dy2 = A1*dh2 + A2*y2 + A3 (BatchNorm backward) with zero padding
-        for (int pix0 = pl; pix0 < nstage; pix0 += 4 * LP) {
-            raw_t rp[4], rq[4];
-            bool ok[4];
+        // stage dL/dy2 = A1*dh2 + A2*y2 + A3 (BatchNorm backward) with zero padding; flat walk, 2*NB loads in flight
+        {
+            constexpr int NB = 8;
+            int r = 0, x = pl;
+            while (x >= Wq) { x -= Wq; ++r; }
+            while (r < rows_q) {
+                raw_t rp[NB], rq[NB];
+                int rr[NB], xx[NB];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int pix = pix0 + u * LP;
-                int wo = pix % Wq - 1, ho = ho_lo + pix / Wq;
-                ok[u] = chan_ok && pix < nstage && ho >= 0 && ho < a.Hout && wo >= 0 && wo < a.Wout;
-                i64 row = ok[u] ? orow0 + (i64)ho * a.Wout + wo : 0;
-                rp[u] = ld4_raw<T>(dpp + row * a.dy.ld + chs);
-                rq[u] = ld4_raw<T>(dqp + row * a.dy.ld + chs);
-            }
+                for (int u = 0; u < NB; ++u) {
+                    rr[u] = r; xx[u] = x;
+                    const int ho = ho_lo + r, wo = x - 1;
+                    const bool ok = chan_ok && r < rows_q && ho >= 0 && ho < a.Hout && wo >= 0 && wo < a.Wout;
+                    const i64 off = (orow0 + (ok ? (i64)ho * a.Wout + wo : 0)) * a.dy.ld + chs;
+                    rp[u] = ld4_raw<T>(dpp + off);
+                    rq[u] = ld4_raw<T>(dqp + off);
+                    x += LP;
+                    while (x >= Wq) { x -= Wq; ++r; }
+                }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int pix = pix0 + u * LP;
-                if (pix < nstage) {
-                    float p[4], q[4];
-                    V4<T>::unpack(rp[u], p);
-                    V4<T>::unpack(rq[u], q);
+                for (int u = 0; u < NB; ++u) {
+                    if (rr[u] < rows_q) {
+                        const int ho = ho_lo + rr[u], wo = xx[u] - 1;
+                        const bool ok = chan_ok && ho >= 0 && ho < a.Hout && wo >= 0 && wo < a.Wout;
+                        float p[4], q[4];
+                        V4<T>::unpack(rp[u], p);
+                        V4<T>::unpack(rq[u], q);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) p[i] = fmaf(a1[i], p[i], fmaf(a2[i], q[i], a3[i]));
-                    tile[pix * NCV + cv] = ok[u] ? V4<T>::pack(p) : V4<T>::zero();
+                        for (int i = 0; i < 4; ++i) p[i] = fmaf(a1[i], p[i], fmaf(a2[i], q[i], a3[i]));
+                        tile[(rr[u] * Wq + xx[u]) * NCV + cv] = ok ? V4<T>::pack(p) : V4<T>::zero();
+                    }
                 }
             }
         }
         __syncthreads();
-        const int nitems = nri * a.Win;
-        const i64 irow0 = ((i64)plane * a.Hin + hi0) * a.Win;
-        for (int item0 = pl; item0 < nitems; item0 += 4 * LP) {
-            raw_t ry[4];
+        for (int iy = 0; iy < nri; ++iy) {
+            const int hi = hi0 + iy;
+            const i64 irow = ((i64)plane * a.Hin + hi) * a.Win;
+            for (int xb = pl; xb < a.Win; xb += XB * LP) {
+                raw_t ry[XB];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int item = item0 + u * LP;
-                i64 row = (chan_ok && item < nitems) ? irow0 + item : 0;
-                ry[u] = ld4_raw<T>(y1p + row * a.y1.ld + chs);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int item = item0 + u * LP;
-                if (!chan_ok || item >= nitems) continue;
-                int iy = item / a.Win, wi = item % a.Win;
-                int hi = hi0 + iy;
-                float y[4], z1[4], dsl[4];
-                V4<T>::unpack(ry[u], y);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float h = fmaf(y[i], bs[i], bt[i]);
-                    float sg = sigmoidf_(h);
-                    z1[i] = h * sg;
-                    dsl[i] = sg * (1.0f + h * (1.0f - sg));
+                for (int u = 0; u < XB; ++u) {
+                    const int wi = xb + u * LP;
+                    ry[u] = ld4_raw<T>(y1p + (irow + ((chan_ok && wi < a.Win) ? wi : 0)) * a.y1.ld + chs);
                 }
-                float dz[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int dy = 0; dy < KS; ++dy) {
-                    int nh = hi + P - dy;
-                    if (nh < 0 || nh % s != 0) continue;
-                    int ho = nh / s;
-                    if (ho > ho_hi) continue;
+                for (int u = 0; u < XB; ++u) {
+                    const int wi = xb + u * LP;
+                    if (!chan_ok || wi >= a.Win) continue;
+                    float y[4], z1[4], dsl[4];
+                    V4<T>::unpack(ry[u], y);
 #pragma unroll
-                    for (int dx = 0; dx < KS; ++dx) {
-                        int nw = wi + P - dx;
-                        if (nw < 0 || nw % s != 0) continue;
-                        int wo = nw / s;
-                        if (wo > a.Wout) continue;
-                        float g[4];
-                        V4<T>::unpack(tile[((ho - ho_lo) * Wq + wo + 1) * NCV + cv], g);
+                    for (int i = 0; i < 4; ++i) {
+                        float h = fmaf(y[i], bs[i], bt[i]);
+                        float sg = sigmoidf_(h);
+                        z1[i] = h * sg;
+                        dsl[i] = sg * (1.0f + h * (1.0f - sg));
+                    }
+                    float dz[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            dz[i] = fmaf(w[dy * KS + dx][i], g[i], dz[i]);
-                            dwacc[dy * KS + dx][i] = fmaf(z1[i], g[i], dwacc[dy * KS + dx][i]);
+                    for (int dy = 0; dy < KS; ++dy) {
+                        const int nh = hi + P - dy;
+                        if (nh < 0 || nh % s != 0) continue;
+                        const int ho = nh / s;
+                        if (ho > ho_hi) continue;
+#pragma unroll
+                        for (int dx = 0; dx < KS; ++dx) {
+                            const int nw = wi + P - dx;
+                            if (nw < 0 || nw % s != 0) continue;
+                            const int wo = nw / s;
+                            if (wo > a.Wout) continue;
+                            float g[4], wv[4];
+                            V4<T>::unpack(tile[((ho - ho_lo) * Wq + wo + 1) * NCV + cv], g);
+                            ldc4(&lw[(dy * KS + dx) * CS + cv * 4], wv);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                dz[i] = fmaf(wv[i], g[i], dz[i]);
+                                dwacc[dy * KS + dx][i] = fmaf(z1[i], g[i], dwacc[dy * KS + dx][i]);
+                            }
                         }
                     }
-                }
-                float dh[4];
+                    float dh[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dh[i] = dz[i] * dsl[i];
-                st4<T>(dhp + (irow0 + item) * a.C + chan, dh);
+                    for (int i = 0; i < 4; ++i) dh[i] = dz[i] * dsl[i];
+                    st4<T>(dhp + (irow + wi) * a.C + chan, dh);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float r = round_t<T>(dh[i]);
-                    st0[i] += r;
-                    st1[i] += r * (y[i] - bm[i]) * bi[i];
+                    for (int i = 0; i < 4; ++i) {
+                        float r = round_t<T>(dh[i]);
+                        st0[i] += r;
+                        st1[i] += r * (y[i] - bm[i]) * bi[i];
+                    }
                 }
             }
         }
         __syncthreads();
     }
     // weight gradient: reduce over the threads sharing a channel vector through LDS, then global fp32 atomics
+    __syncthreads();
+    for (int i = tid; i < KS * KS * CS; i += 256) lw[i] = 0.f;
+    __syncthreads();
     if (chan_ok) {
 #pragma unroll
         for (int k = 0; k < KS * KS; ++k)

@@ -573,14 +573,32 @@ __global__ __launch_bounds__(256) void se_pool_kernel(LoadDesc z3, int C, int ro
     float acc[KC];
 #pragma unroll
     for (int i = 0; i < KC; ++i) acc[i] = 0.f;
-    if (chan_ok)
-        for (int r = r_beg + pl; r < r_end; r += 32) {
-            float v[KC];
-            load_op<LD_BNACT, T>(z3, (i64)b * rows_per_sample + r, chan, v);
-            if (z3out) st_vec<T>(z3out + ((i64)b * rows_per_sample + r) * C + chan, v);
+    if (chan_ok) {
+        float sc[KC], sh[KC];
+        ld_coef<KC>(z3.v1 + chan, sc);
+        ld_coef<KC>(z3.v2 + chan, sh);
+        const T* yp = reinterpret_cast<const T*>(z3.p);
+        for (int r0 = r_beg + pl; r0 < r_end; r0 += 4 * 32) {
+            uint4 raw[4];
 #pragma unroll
-            for (int i = 0; i < KC; ++i) acc[i] += round_t<T>(v[i]);
+            for (int u = 0; u < 4; ++u) {
+                int r = r0 + 32 * u;
+                raw[u] = *reinterpret_cast<const uint4*>(yp + ((i64)b * rows_per_sample + (r < r_end ? r : r_beg)) * z3.ld + chan);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int r = r0 + 32 * u;
+                if (r >= r_end) break;
+                float v[KC];
+                unpack16<T>(raw[u], v);
+#pragma unroll
+                for (int i = 0; i < KC; ++i) v[i] = siluf_(fmaf(v[i], sc[i], sh[i]));
+                if (z3out) st_vec<T>(z3out + ((i64)b * rows_per_sample + r) * C + chan, v);
+#pragma unroll
+                for (int i = 0; i < KC; ++i) acc[i] += round_t<T>(v[i]);
+            }
         }
+    }
 #pragma unroll
     for (int i = 0; i < KC; ++i) atomicAdd(&lacc[cv * KC + i], acc[i]);
     __syncthreads();
@@ -669,28 +687,28 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* dg, const 
     }
 }
 
-// parameter grads of the SE MLP: one thread per channel c
-__global__ void se_mlp_wgrad_kernel(const float* dgp, const float* dhp, const float* pmean, const float* hid_pre,
-                                    int B, int C, int R, float* dwr, float* dbr, float* dwe, float* dbe) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+// parameter grads of the SE MLP.  grid.x = ceil(C/256), grid.y = R: thread (c, r) reduces over the batch.
+__global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const float* dgp, const float* dhp, const float* pmean,
+                                                           const float* hid_pre, int B, int C, int R, float* dwr,
+                                                           float* dbr, float* dwe, float* dbe) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
     if (c < C) {
-        float sb = 0.f;
-        for (int b = 0; b < B; ++b) sb += dgp[(i64)b * C + c];
-        dbe[c] = sb;
-        for (int r = 0; r < R; ++r) {
-            float a = 0.f, a2 = 0.f;
-            for (int b = 0; b < B; ++b) {
-                a = fmaf(dgp[(i64)b * C + c], siluf_(hid_pre[(i64)b * R + r]), a);
-                a2 = fmaf(dhp[(i64)b * R + r], pmean[(i64)b * C + c], a2);
-            }
-            dwe[(i64)c * R + r] = a;
-            dwr[(i64)r * C + c] = a2;
+        float a = 0.f, a2 = 0.f, sb = 0.f;
+        for (int b = 0; b < B; ++b) {
+            float g = dgp[(i64)b * C + c];
+            a = fmaf(g, siluf_(hid_pre[(i64)b * R + r]), a);
+            a2 = fmaf(dhp[(i64)b * R + r], pmean[(i64)b * C + c], a2);
+            sb += g;
         }
+        dwe[(i64)c * R + r] = a;
+        dwr[(i64)r * C + c] = a2;
+        if (r == 0) dbe[c] = sb;
     }
-    if (c < R) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         float sb = 0.f;
-        for (int b = 0; b < B; ++b) sb += dhp[(i64)b * R + c];
-        dbr[c] = sb;
+        for (int b = 0; b < B; ++b) sb += dhp[(i64)b * R + r];
+        dbr[r] = sb;
     }
 }
 
@@ -707,8 +725,7 @@ int k_se_mlp_bwd(const float* dg, const float* gate, const float* hid_pre, const
     hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), s, dg, gate, hid_pre, wr, we, C,
                        R, inv_s, dgp, dhp, dps);
     DWN_CHECK_LAUNCH();
-    int n = C > R ? C : R;
-    hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((n + 127) / 128), dim3(128), 0, s, dgp, dhp, pmean, hid_pre, B, C, R,
+    hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 255) / 256, R), dim3(256), 0, s, dgp, dhp, pmean, hid_pre, B, C, R,
                        dwr, dbr, dwe, dbe);
     DWN_CHECK_LAUNCH();
     return 0;
@@ -730,13 +747,40 @@ __global__ __launch_bounds__(256) void bn3_bwd_reduce_kernel(LoadDesc d, const f
         ld_coef<KC>(coef3 + 2 * C + chan, m3);
         ld_coef<KC>(coef3 + 3 * C + chan, i3);
         const T* yp = reinterpret_cast<const T*>(d.q);
-        for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
-            float dh[KC], y[KC];
-            load_op<LD_DY3, T>(d, row, chan, dh);
-            ld_vec<T>(yp + row * d.ld + chan, y);
-            if (dh_out) st_vec<T>(dh_out + row * d.ld + chan, dh);      // may alias d.p (element-wise in place)
+        const T* pp = reinterpret_cast<const T*>(d.p);
+        float sc[KC], sh[KC], g[KC], g2[KC];
+        ld_coef<KC>(d.v4 + chan, sc);
+        ld_coef<KC>(d.v5 + chan, sh);
+        int gb = -1;
+        const i64 stride = (i64)gridDim.x * 32;
+        for (i64 row0 = (i64)blockIdx.x * 32 + pl; row0 < rows; row0 += 2 * stride) {
+            uint4 rp[2], ry[2];
 #pragma unroll
-            for (int i = 0; i < KC; ++i) { float r = round_t<T>(dh[i]); s0[i] += r; s1[i] += r * (y[i] - m3[i]) * i3[i]; }
+            for (int u = 0; u < 2; ++u) {
+                i64 row = row0 + u * stride;
+                if (row >= rows) row = row0;
+                rp[u] = *reinterpret_cast<const uint4*>(pp + row * d.ld + chan);
+                ry[u] = *reinterpret_cast<const uint4*>(yp + row * d.ld + chan);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                i64 row = row0 + u * stride;
+                if (row >= rows) break;
+                int b = (int)((unsigned)row / (unsigned)d.rows_per_sample);
+                if (b != gb) {
+                    gb = b;
+                    ld_coef<KC>(d.gate + (i64)b * d.gate_ld + chan, g);
+                    ld_coef<KC>(d.gate2 + (i64)b * d.gate_ld + chan, g2);
+                }
+                float du[KC], y[KC], dh[KC];
+                unpack16<T>(rp[u], du);
+                unpack16<T>(ry[u], y);
+#pragma unroll
+                for (int i = 0; i < KC; ++i) dh[i] = fmaf(du[i], g[i], g2[i]) * silu_gradf_(fmaf(y[i], sc[i], sh[i]));
+                if (dh_out) st_vec<T>(dh_out + row * d.ld + chan, dh);      // may alias d.p (element-wise in place)
+#pragma unroll
+                for (int i = 0; i < KC; ++i) { float r = round_t<T>(dh[i]); s0[i] += r; s1[i] += r * (y[i] - m3[i]) * i3[i]; }
+            }
         }
     }
     slice_stats_flush<KC>(lstat, s0, s1, cv, c0, C, stats, blockIdx.x % DWN_NREP);

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const GemmNN g) {
     constexpr int A_CH = BM * 8 / 256;
     constexpr int B_CH = BN * 8 / 256;
     constexpr int CROW = BN * (int)sizeof(T) + 16;     // epilogue staging row stride (bytes)
-    constexpr int CROWS = TT<T>::IS_BF16 ? 64 : 32;    // rows staged per epilogue pass
+    constexpr int CROWS = TT<T>::IS_BF16 ? 128 : 32;   // rows staged per epilogue pass (bf16: whole tile, one pass)
     constexpr int NPASS = BM / CROWS;
     constexpr int CPR = BN / KC;                       // 16-byte chunks per output row
     __shared__ __attribute__((aligned(16))) unsigned char sA[BM * ROWB];
@@ -277,7 +277,18 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const GemmNN g) {
             // ---- stage through LDS in passes of CROWS rows; leave as whole 16-byte row segments
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int prow0 = pass * CROWS;            // first tile row of this pass
-                if (wm == prow0 / 64) {
+                const int mp = m0 + prow0;
+                // EPI_DG: fetch this pass's z3 chunks now so they are in flight across the LDS round trip
+                [[maybe_unused]] uint4 zraw[CROWS * CPR / 256];
+                if constexpr (EPI == EPI_DG) {
+#pragma unroll
+                    for (int it = 0; it < CROWS * CPR / 256; ++it) {
+                        const int m = mp + tid / CPR + it * (256 / CPR);
+                        const bool ok = m < g.M && ncol < g.N;
+                        zraw[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(g.y3) + (ok ? (i64)m * g.ldy3 + ncol : 0));
+                    }
+                }
+                if (CROWS >= 64 ? (wm == prow0 / 64 || CROWS == 128) : (wm == prow0 / 64)) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int trow = wm * 64 + i * 16 + lr;
@@ -300,8 +311,9 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const GemmNN g) {
                     }
                 }
                 __syncthreads();
-                const int mp = m0 + prow0;
-                for (int row = tid / CPR; row < CROWS; row += 256 / CPR) {
+#pragma unroll
+                for (int it = 0; it < CROWS * CPR / 256; ++it) {
+                    const int row = tid / CPR + it * (256 / CPR);
                     const int m = mp + row;
                     if (m >= g.M || ncol >= g.N) continue;
                     const uint4 raw = *reinterpret_cast<const uint4*>(sC + row * CROW + ch * 16);
@@ -317,7 +329,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const GemmNN g) {
                         // the minority sample then use direct atomics
                         const int b = m / g.rows_per_sample;
                         float y[KC];
-                        ld_vec<T>(reinterpret_cast<const T*>(g.y3) + (i64)m * g.ldy3 + ncol, y);
+                        unpack16<T>(zraw[it], y);
                         const int b_pass = mp / g.rows_per_sample;
                         if (g.s3) {          // y3 raw: apply bn3 + SiLU here; else `y3` already holds z3
 #pragma unroll

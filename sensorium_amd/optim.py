@@ -28,7 +28,7 @@ def _upload_table(entries: np.ndarray, device) -> torch.Tensor:
 class FusedAdamWEma(torch.optim.Optimizer):
     def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-2, ema_params: Optional[List[torch.Tensor]] = None,
-                 ema_decay: float = 0.999, max_blocks: int = 64):
+                 ema_decay: float = 0.999, max_blocks: int = 1024):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.ema_decay = float(ema_decay)
