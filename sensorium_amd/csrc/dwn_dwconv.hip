@@ -12,8 +12,17 @@
 // Loads are issued in batches of 4 independent 8/16-byte vectors per tensor so that, at 3-5 waves per SIMD,
 // each CU keeps tens of KB in flight (the HBM latency-bandwidth product).
 #include "dwn_internal.h"
+#include <stdlib.h>
 
 extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+
+// LDS tile budgets of the spatial kernels (bytes); tuned on MI355X with tools/microbench.py
+#ifndef DWS_FWD_LDS_BUDGET
+#define DWS_FWD_LDS_BUDGET (a.stride >= 2 ? 80 * 1024 : 48 * 1024)
+#endif
+#ifndef DWS_BWD_LDS_BUDGET
+#define DWS_BWD_LDS_BUDGET (44 * 1024)
+#endif
 
 template <typename T> struct SL {
     static constexpr int NCV = V4<T>::NCV;       // vectors per slice
@@ -37,6 +46,18 @@ __device__ __forceinline__ void block_stats_flush(float* lstat, const float* s0,
         int which = tid / CS, c = c0 + tid % CS;
         if (c < C) stat_add(stats, rep, C, which, c, lstat[tid]);
     }
+}
+
+typedef float f2_t __attribute__((ext_vector_type(2)));
+// two adjacent channels as one register pair: the compiler emits v_pk_fma_f32 / v_pk_mul_f32 without shuffles
+template <typename T> __device__ __forceinline__ void unpack_pairs(const typename V4<T>::raw_t& r, f2_t& lo, f2_t& hi);
+template <> __device__ __forceinline__ void unpack_pairs<bf16_t>(const uint2& r, f2_t& lo, f2_t& hi) {
+    lo = f2_t{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)};
+    hi = f2_t{__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+}
+template <> __device__ __forceinline__ void unpack_pairs<float>(const uint4& r, f2_t& lo, f2_t& hi) {
+    lo = f2_t{__uint_as_float(r.x), __uint_as_float(r.y)};
+    hi = f2_t{__uint_as_float(r.z), __uint_as_float(r.w)};
 }
 
 __device__ __forceinline__ void bn_silu4(float* v, const float* s, const float* t) {
@@ -171,13 +192,16 @@ __global__ __launch_bounds__(256) void dw_spatial_bwd_kernel(const DwSpatialBwd 
     }
     __syncthreads();
 
-    float dwacc[KS * KS][4];
+    f2_t dwp[KS * KS][2];
 #pragma unroll
-    for (int k = 0; k < KS * KS; ++k) dwacc[k][0] = dwacc[k][1] = dwacc[k][2] = dwacc[k][3] = 0.f;
+    for (int k = 0; k < KS * KS; ++k) { dwp[k][0] = f2_t{0.f, 0.f}; dwp[k][1] = f2_t{0.f, 0.f}; }
     float bs[4], bt[4], bm[4], bi[4], a1[4], a2[4], a3[4];
     ldc4(a.y1.v1 + chs, bs); ldc4(a.y1.v2 + chs, bt); ldc4(a.y1.v3 + chs, bm); ldc4(a.y1.v4 + chs, bi);
     ldc4(a.dy.v1 + chs, a1); ldc4(a.dy.v2 + chs, a2); ldc4(a.dy.v3 + chs, a3);
-    float st0[4] = {0.f, 0.f, 0.f, 0.f}, st1[4] = {0.f, 0.f, 0.f, 0.f};
+    const f2_t bs2[2] = {f2_t{bs[0], bs[1]}, f2_t{bs[2], bs[3]}}, bt2[2] = {f2_t{bt[0], bt[1]}, f2_t{bt[2], bt[3]}};
+    const f2_t bi2[2] = {f2_t{bi[0], bi[1]}, f2_t{bi[2], bi[3]}};
+    const f2_t nbm2[2] = {f2_t{-bm[0] * bi[0], -bm[1] * bi[1]}, f2_t{-bm[2] * bi[2], -bm[3] * bi[3]}};   // yhat = y*bi + nbm
+    f2_t sp0[2] = {f2_t{0.f, 0.f}, f2_t{0.f, 0.f}}, sp1[2] = {f2_t{0.f, 0.f}, f2_t{0.f, 0.f}};
 
     const int Wq = a.Wout + 2;                      // staged columns wo = -1 .. Wout
     const int nbands = (a.Hin + a.rows_band - 1) / a.rows_band;
@@ -236,58 +260,128 @@ __global__ __launch_bounds__(256) void dw_spatial_bwd_kernel(const DwSpatialBwd 
         for (int iy = 0; iy < nri; ++iy) {
             const int hi = hi0 + iy;
             const i64 irow = ((i64)plane * a.Hin + hi) * a.Win;
-            for (int xb = pl; xb < a.Win; xb += XB * LP) {
-                raw_t ry[XB];
+            // one tap: g = dL/dy2 at (ho, wo) from the LDS tile; dz += w*g; dW[tap] += z1*g   (channel pairs)
+            auto tap = [&](const int k, const int ho, const int wo, const f2_t* z1, f2_t* dz) {
+                f2_t g0, g1;
+                unpack_pairs<T>(tile[((ho - ho_lo) * Wq + wo + 1) * NCV + cv], g0, g1);
+                const float4 wv = *reinterpret_cast<const float4*>(&lw[k * CS + cv * 4]);
+                dz[0] += f2_t{wv.x, wv.y} * g0;
+                dz[1] += f2_t{wv.z, wv.w} * g1;
+                dwp[k][0] += z1[0] * g0;
+                dwp[k][1] += z1[1] * g1;
+            };
+            // everything after the taps: dh1 = dz * silu'(h1), store, BN-backward sums
+            auto finish = [&](const int wi, const f2_t* y, const f2_t* dsl, const f2_t* dz) {
+                const f2_t d0 = dz[0] * dsl[0], d1 = dz[1] * dsl[1];
+                float dh[4] = {d0.x, d0.y, d1.x, d1.y};
+                const typename V4<T>::raw_t packed = V4<T>::pack(dh);
+                *reinterpret_cast<typename V4<T>::raw_t*>(dhp + (irow + wi) * a.C + chan) = packed;
+                f2_t r0, r1;
+                unpack_pairs<T>(packed, r0, r1);              // statistics of the values as stored
+                sp0[0] += r0; sp0[1] += r1;
+                sp1[0] += r0 * (y[0] * bi2[0] + nbm2[0]);
+                sp1[1] += r1 * (y[1] * bi2[1] + nbm2[1]);
+            };
+            auto activate = [&](const raw_t& raw, f2_t* y, f2_t* z1, f2_t* dsl) {
+                unpack_pairs<T>(raw, y[0], y[1]);
 #pragma unroll
-                for (int u = 0; u < XB; ++u) {
-                    const int wi = xb + u * LP;
-                    ry[u] = ld4_raw<T>(y1p + (irow + ((chan_ok && wi < a.Win) ? wi : 0)) * a.y1.ld + chs);
+                for (int i = 0; i < 2; ++i) {
+                    const f2_t h = y[i] * bs2[i] + bt2[i];
+                    const f2_t sg = f2_t{sigmoidf_(h.x), sigmoidf_(h.y)};
+                    z1[i] = h * sg;
+                    dsl[i] = sg * (1.0f + h * (1.0f - sg));
                 }
+            };
+            if constexpr (ST == 1) {
+                // stride 1: all KS*KS taps are valid for every pixel (the zero halo supplies the borders): branch-free
+                for (int xb = pl; xb < a.Win; xb += XB * LP) {
+                    raw_t ry[XB];
 #pragma unroll
-                for (int u = 0; u < XB; ++u) {
-                    const int wi = xb + u * LP;
-                    if (!chan_ok || wi >= a.Win) continue;
-                    float y[4], z1[4], dsl[4];
-                    V4<T>::unpack(ry[u], y);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float h = fmaf(y[i], bs[i], bt[i]);
-                        float sg = sigmoidf_(h);
-                        z1[i] = h * sg;
-                        dsl[i] = sg * (1.0f + h * (1.0f - sg));
+                    for (int u = 0; u < XB; ++u) {
+                        const int wi = xb + u * LP;
+                        ry[u] = ld4_raw<T>(y1p + (irow + ((chan_ok && wi < a.Win) ? wi : 0)) * a.y1.ld + chs);
                     }
-                    float dz[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int dy = 0; dy < KS; ++dy) {
-                        const int nh = hi + P - dy;
-                        if (nh < 0 || nh % s != 0) continue;
-                        const int ho = nh / s;
-                        if (ho > ho_hi) continue;
+                    for (int u = 0; u < XB; ++u) {
+                        const int wi = xb + u * LP;
+                        if (!chan_ok || wi >= a.Win) continue;
+                        f2_t y[2], z1[2], dsl[2], dz[2] = {f2_t{0.f, 0.f}, f2_t{0.f, 0.f}};
+                        activate(ry[u], y, z1, dsl);
 #pragma unroll
-                        for (int dx = 0; dx < KS; ++dx) {
-                            const int nw = wi + P - dx;
-                            if (nw < 0 || nw % s != 0) continue;
-                            const int wo = nw / s;
-                            if (wo > a.Wout) continue;
-                            float g[4], wv[4];
-                            V4<T>::unpack(tile[((ho - ho_lo) * Wq + wo + 1) * NCV + cv], g);
-                            ldc4(&lw[(dy * KS + dx) * CS + cv * 4], wv);
+                        for (int dy = 0; dy < KS; ++dy)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                dz[i] = fmaf(wv[i], g[i], dz[i]);
-                                dwacc[dy * KS + dx][i] = fmaf(z1[i], g[i], dwacc[dy * KS + dx][i]);
+                            for (int dx = 0; dx < KS; ++dx) tap(dy * KS + dx, hi + P - dy, wi + P - dx, z1, dz);
+                        finish(wi, y, dsl, dz);
+                    }
+                }
+            } else if constexpr (ST == 2 && KS == 3) {
+                // stride 2: an input pixel receives 1, 2, 2 or 4 taps depending on the parity of (hi, wi).  Pixels are
+                // walked by parity class so a wave executes exactly the taps it needs, with compile-time tap indices.
+                const bool h_even = (hi & 1) == 0;
+                const int ho_c = hi >> 1;                  // hi even: dy = 1 -> ho = hi/2
+                const int ho_a = (hi + 1) >> 1;            // hi odd : dy = 0 -> ho = (hi+1)/2
+                const int ho_b = (hi - 1) >> 1;            //          dy = 2 -> ho = (hi-1)/2
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    for (int xb = pl; 2 * xb + px < a.Win; xb += XB * LP) {
+                        raw_t ry[XB];
+#pragma unroll
+                        for (int u = 0; u < XB; ++u) {
+                            const int wi = 2 * (xb + u * LP) + px;
+                            ry[u] = ld4_raw<T>(y1p + (irow + ((chan_ok && wi < a.Win) ? wi : 0)) * a.y1.ld + chs);
+                        }
+#pragma unroll
+                        for (int u = 0; u < XB; ++u) {
+                            const int wi = 2 * (xb + u * LP) + px;
+                            if (!chan_ok || wi >= a.Win) continue;
+                            f2_t y[2], z1[2], dsl[2], dz[2] = {f2_t{0.f, 0.f}, f2_t{0.f, 0.f}};
+                            activate(ry[u], y, z1, dsl);
+                            if (px == 0) {                 // wi even: dx = 1 -> wo = wi/2
+                                const int wo = wi >> 1;
+                                if (h_even) tap(4, ho_c, wo, z1, dz);
+                                else { tap(1, ho_a, wo, z1, dz); tap(7, ho_b, wo, z1, dz); }
+                            } else {                       // wi odd: dx = 0 -> wo = (wi+1)/2 ; dx = 2 -> wo = (wi-1)/2
+                                const int wa = (wi + 1) >> 1, wb = (wi - 1) >> 1;
+                                if (h_even) { tap(3, ho_c, wa, z1, dz); tap(5, ho_c, wb, z1, dz); }
+                                else {
+                                    tap(0, ho_a, wa, z1, dz); tap(2, ho_a, wb, z1, dz);
+                                    tap(6, ho_b, wa, z1, dz); tap(8, ho_b, wb, z1, dz);
+                                }
                             }
+                            finish(wi, y, dsl, dz);
                         }
                     }
-                    float dh[4];
+                }
+            } else {
+                for (int xb = pl; xb < a.Win; xb += XB * LP) {
+                    raw_t ry[XB];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) dh[i] = dz[i] * dsl[i];
-                    st4<T>(dhp + (irow + wi) * a.C + chan, dh);
+                    for (int u = 0; u < XB; ++u) {
+                        const int wi = xb + u * LP;
+                        ry[u] = ld4_raw<T>(y1p + (irow + ((chan_ok && wi < a.Win) ? wi : 0)) * a.y1.ld + chs);
+                    }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float r = round_t<T>(dh[i]);
-                        st0[i] += r;
-                        st1[i] += r * (y[i] - bm[i]) * bi[i];
+                    for (int u = 0; u < XB; ++u) {
+                        const int wi = xb + u * LP;
+                        if (!chan_ok || wi >= a.Win) continue;
+                        f2_t y[2], z1[2], dsl[2], dz[2] = {f2_t{0.f, 0.f}, f2_t{0.f, 0.f}};
+                        activate(ry[u], y, z1, dsl);
+#pragma unroll
+                        for (int dy = 0; dy < KS; ++dy) {
+                            const int nh = hi + P - dy;
+                            if (nh < 0 || nh % s != 0) continue;
+                            const int ho = nh / s;
+                            if (ho > ho_hi) continue;
+#pragma unroll
+                            for (int dx = 0; dx < KS; ++dx) {
+                                const int nw = wi + P - dx;
+                                if (nw < 0 || nw % s != 0) continue;
+                                const int wo = nw / s;
+                                if (wo > a.Wout) continue;
+                                tap(dy * KS + dx, ho, wo, z1, dz);
+                            }
+                        }
+                        finish(wi, y, dsl, dz);
                     }
                 }
             }
@@ -300,15 +394,19 @@ __global__ __launch_bounds__(256) void dw_spatial_bwd_kernel(const DwSpatialBwd 
     __syncthreads();
     if (chan_ok) {
 #pragma unroll
-        for (int k = 0; k < KS * KS; ++k)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) atomicAdd(&lw[k * CS + cv * 4 + i], dwacc[k][i]);
+        for (int k = 0; k < KS * KS; ++k) {
+            atomicAdd(&lw[k * CS + cv * 4 + 0], dwp[k][0].x);
+            atomicAdd(&lw[k * CS + cv * 4 + 1], dwp[k][0].y);
+            atomicAdd(&lw[k * CS + cv * 4 + 2], dwp[k][1].x);
+            atomicAdd(&lw[k * CS + cv * 4 + 3], dwp[k][1].y);
+        }
     }
     __syncthreads();
     for (int i = tid; i < KS * KS * CS; i += 256) {
         int k = i / CS, c = c0 + i % CS;
         if (c < a.C) atomicAdd(a.dw + (i64)c * (KS * KS) + k, lw[i]);
     }
+    const float st0[4] = {sp0[0].x, sp0[0].y, sp0[1].x, sp0[1].y}, st1[4] = {sp1[0].x, sp1[0].y, sp1[1].x, sp1[1].y};
     if (a.stats) block_stats_flush<T>(lstat, st0, st1, cv, c0, a.C, a.stats, blockIdx.x % DWN_NREP);
 }
 
@@ -523,6 +621,22 @@ __global__ __launch_bounds__(256) void dw_temporal_bwd_kernel(const DwTemporalBw
 // launchers
 // ------------------------------------------------------------------------------------------------
 static inline int grid_cap(i64 work, int cap) { return (int)(work < cap ? (work > 0 ? work : 1) : cap); }
+// persistent grids: one full resident wave of workgroups (256 CUs x blocks/CU from the occupancy query), so no
+// ragged second wave; `slices` workgroups share each x index
+template <typename K>
+static int resident_grid_x(K kernel, size_t dyn_lds, int slices, i64 work) {
+    if (dyn_lds > 48 * 1024) {     // opt in to > default dynamic LDS (160 KiB per CU on gfx950, minus the static part)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)dyn_lds) != hipSuccess)
+            (void)hipGetLastError();   // clear: the launch itself reports a too-large tile
+    }
+    int bpc = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kernel, 256, dyn_lds) != hipSuccess || bpc < 1) bpc = 2;
+    static const int mode = getenv("DWN_GRID_MODE") ? atoi(getenv("DWN_GRID_MODE")) : 0;   // tuning knob (microbench)
+    int gx = (256 * bpc * (mode > 0 ? mode : 1)) / slices;
+    if (gx < 1) gx = 1;
+    return grid_cap(work, gx);
+}
 
 template <typename T>
 static int spatial_fwd_t(DwSpatialFwd a, hipStream_t s) {
@@ -530,20 +644,23 @@ static int spatial_fwd_t(DwSpatialFwd a, hipStream_t s) {
     if (a.ks != 3) return dwn_set_error(-4, "dw_spatial: only spatial_kernel=3 is built");
     if (a.C % 8) return dwn_set_error(-2, "dw_spatial: C must be a multiple of 8");
     const int Wp = a.Win + 2;
+    auto tile_bytes = [&](int rb) { return (size_t)((rb - 1) * a.stride + 3) * Wp * 128; };
     if (a.rows_band <= 0) {
+        // largest band whose tile fits the LDS budget: fewer halo rows re-read, fewer barriers per byte
         int rb = 1;
-        while (rb < a.Hout && ((rb) * a.stride + 3) * Wp * 128 <= 40 * 1024) ++rb;
-        a.rows_band = rb;
+        while (rb < a.Hout && tile_bytes(rb + 1) <= (size_t)DWS_FWD_LDS_BUDGET) ++rb;
+        const int nb = (a.Hout + rb - 1) / rb;          // even split: no ragged last band
+        a.rows_band = (a.Hout + nb - 1) / nb;
     }
-    const int rows_in = (a.rows_band - 1) * a.stride + 3;
-    const size_t lds = (size_t)rows_in * Wp * 128;
-    if (lds > 60 * 1024) return dwn_set_error(-5, "dw_spatial: plane too wide for the LDS tile");
+    if (a.rows_band > a.Hout) a.rows_band = a.Hout;
+    const size_t lds = tile_bytes(a.rows_band);
+    if (lds > 156 * 1024) return dwn_set_error(-5, "dw_spatial: plane too wide for the LDS tile");
     const int nbands = (a.Hout + a.rows_band - 1) / a.rows_band;
     const int slices = (a.C + CS - 1) / CS;
-    dim3 grid(grid_cap((i64)a.planes * nbands, (2048 + slices - 1) / slices), slices);
-    if (a.stride == 1) hipLaunchKernelGGL((dw_spatial_fwd_kernel<T, 3, 1>), grid, dim3(256), lds, s, a);
-    else if (a.stride == 2) hipLaunchKernelGGL((dw_spatial_fwd_kernel<T, 3, 2>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((dw_spatial_fwd_kernel<T, 3, 0>), grid, dim3(256), lds, s, a);
+    const i64 work = (i64)a.planes * nbands;
+    if (a.stride == 1) { dim3 grid(resident_grid_x(dw_spatial_fwd_kernel<T, 3, 1>, lds, slices, work), slices); hipLaunchKernelGGL((dw_spatial_fwd_kernel<T, 3, 1>), grid, dim3(256), lds, s, a); }
+    else if (a.stride == 2) { dim3 grid(resident_grid_x(dw_spatial_fwd_kernel<T, 3, 2>, lds, slices, work), slices); hipLaunchKernelGGL((dw_spatial_fwd_kernel<T, 3, 2>), grid, dim3(256), lds, s, a); }
+    else { dim3 grid(resident_grid_x(dw_spatial_fwd_kernel<T, 3, 0>, lds, slices, work), slices); hipLaunchKernelGGL((dw_spatial_fwd_kernel<T, 3, 0>), grid, dim3(256), lds, s, a); }
     DWN_CHECK_LAUNCH();
     return 0;
 }
@@ -560,17 +677,19 @@ static int spatial_bwd_t(DwSpatialBwd a, hipStream_t s) {
     auto rows_q = [&](int rb) { return (rb - 1 + 2) / a.stride + 2; };   // upper bound on staged output rows
     if (a.rows_band <= 0) {
         int rb = 1;
-        while (rb < a.Hin && rows_q(rb + 1) * Wq * 128 <= 40 * 1024) ++rb;
-        a.rows_band = rb;
+        while (rb < a.Hin && (size_t)rows_q(rb + 1) * Wq * 128 <= (size_t)DWS_BWD_LDS_BUDGET) ++rb;
+        const int nb = (a.Hin + rb - 1) / rb;
+        a.rows_band = (a.Hin + nb - 1) / nb;
     }
+    if (a.rows_band > a.Hin) a.rows_band = a.Hin;
     const size_t lds = (size_t)rows_q(a.rows_band) * Wq * 128;
-    if (lds > 56 * 1024) return dwn_set_error(-5, "dw_spatial_bwd: plane too wide for the LDS tile");
+    if (lds > 150 * 1024) return dwn_set_error(-5, "dw_spatial_bwd: plane too wide for the LDS tile");
     const int nbands = (a.Hin + a.rows_band - 1) / a.rows_band;
     const int slices = (a.C + CS - 1) / CS;
-    dim3 grid(grid_cap((i64)a.planes * nbands, (2048 + slices - 1) / slices), slices);
-    if (a.stride == 1) hipLaunchKernelGGL((dw_spatial_bwd_kernel<T, 3, 1>), grid, dim3(256), lds, s, a);
-    else if (a.stride == 2) hipLaunchKernelGGL((dw_spatial_bwd_kernel<T, 3, 2>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((dw_spatial_bwd_kernel<T, 3, 0>), grid, dim3(256), lds, s, a);
+    const i64 work = (i64)a.planes * nbands;
+    if (a.stride == 1) { dim3 grid(resident_grid_x(dw_spatial_bwd_kernel<T, 3, 1>, lds, slices, work), slices); hipLaunchKernelGGL((dw_spatial_bwd_kernel<T, 3, 1>), grid, dim3(256), lds, s, a); }
+    else if (a.stride == 2) { dim3 grid(resident_grid_x(dw_spatial_bwd_kernel<T, 3, 2>, lds, slices, work), slices); hipLaunchKernelGGL((dw_spatial_bwd_kernel<T, 3, 2>), grid, dim3(256), lds, s, a); }
+    else { dim3 grid(resident_grid_x(dw_spatial_bwd_kernel<T, 3, 0>, lds, slices, work), slices); hipLaunchKernelGGL((dw_spatial_bwd_kernel<T, 3, 0>), grid, dim3(256), lds, s, a); }
     DWN_CHECK_LAUNCH();
     return 0;
 }

@@ -59,7 +59,7 @@ __device__ __forceinline__ uint4 load_op_packed(const LoadDesc& d, i64 row, int 
 //     the memory side (MI355X_MICROARCH.md § Global float atomics, "contention").
 // ------------------------------------------------------------------------------------------------
 template <typename T, int ALD, int EPI, int BN>
-__global__ __launch_bounds__(256) void gemm_nn_kernel(const GemmNN g) {
+__global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     constexpr int KC = TT<T>::KC;
     constexpr int BM = 128;
     constexpr int ROWB = 128;                          // bytes per tile row per k-step
@@ -391,10 +391,16 @@ static int launch_nn_t(const GemmNN& g, hipStream_t s) {
     const int ntm = (g.M + BM - 1) / BM;
     const int BNv = g.N <= 64 ? 64 : 128;
     const int ntn = (g.N + BNv - 1) / BNv;
-    // ~3 resident workgroups per CU; every workgroup gets a contiguous range of M-tiles
-    int nranges = (768 + ntn * g.groups - 1) / (ntn * g.groups);
+    // persistent grid = exactly the resident workgroups (256 CUs x blocks/CU from the occupancy query: the unified
+    // VGPR+AGPR budget decides, not the arch-VGPR count); every workgroup gets a contiguous range of M-tiles
+    int bpc = 0;
+    hipError_t oe = (BNv == 64)
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, gemm_nn_kernel<T, ALD, EPI, 64>, 256, 0)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, gemm_nn_kernel<T, ALD, EPI, 128>, 256, 0);
+    if (oe != hipSuccess || bpc < 1) { (void)hipGetLastError(); bpc = 1; }
+    int nranges = (256 * bpc) / (ntn * g.groups);
     if (nranges > ntm) nranges = ntm;
-    if (nranges < 1) nranges = 1;
+    if (nranges < 8) nranges = ntm < 8 ? ntm : 8;
     nranges = (nranges + 7) / 8 * 8;
     dim3 grid(nranges * ntn, g.groups);
     if (BNv == 64) hipLaunchKernelGGL((gemm_nn_kernel<T, ALD, EPI, 64>), grid, dim3(256), 0, s, g);
@@ -439,7 +445,7 @@ template <> struct TnCfg<bf16_t> { static constexpr int PAD = 32; };   // 8 rows
 template <> struct TnCfg<float>  { static constexpr int PAD = 64; };   // 16-bank shift between the two rows of a half-wave
 
 template <typename T, int PLD, int QLD>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN g) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN g) {
     constexpr int KC = TT<T>::KC;
     constexpr int BR = 128, BC = 128, BMK = TT<T>::IS_BF16 ? 64 : 32;   // M rows per step
     constexpr int RS = BR * (int)sizeof(T) + TnCfg<T>::PAD;      // LDS row stride (bytes), both tiles

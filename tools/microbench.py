@@ -106,7 +106,7 @@ def copy(nbytes):
     report(f"torch copy {nbytes/1e6:.0f} MB (read+write)", ms, 2 * nbytes)
 
 
-def dws_fwd(planes, Hin, Win, C, stride):
+def dws_fwd(planes, Hin, Win, C, stride, rows_band=0):
     Hout, Wout = (Hin - 1) // stride + 1, (Win - 1) // stride + 1
     x = torch.randn(planes * Hin * Win, C, device=dev).to(BF)
     out = torch.empty(planes * Hout * Wout, C, dtype=BF, device=dev)
@@ -116,12 +116,12 @@ def dws_fwd(planes, Hin, Win, C, stride):
     a = L.DwSpatialFwdArgs()
     a.inp = desc(x, C, v1=sc, v2=sh, act=1)
     a.w = w.data_ptr(); a.out = out.data_ptr(); a.planes = planes; a.Hin = Hin; a.Win = Win; a.Hout = Hout
-    a.Wout = Wout; a.C = C; a.stride = stride; a.ks = 3; a.stats = st.data_ptr(); a.rows_band = 0
+    a.Wout = Wout; a.C = C; a.stride = stride; a.ks = 3; a.stats = st.data_ptr(); a.rows_band = rows_band
     ms = timeit(lambda: L.check(L.lib.dwn_dw_spatial_fwd(C_.byref(a), L.DWN_BF16, 0, stream()), "dws"))
-    report(f"dws_fwd planes={planes} {Hin}x{Win} C={C} s={stride}", ms, (x.numel() + out.numel()) * 2)
+    report(f"dws_fwd planes={planes} {Hin}x{Win} C={C} s={stride} band={rows_band}", ms, (x.numel() + out.numel()) * 2)
 
 
-def dws_bwd(planes, Hin, Win, C, stride):
+def dws_bwd(planes, Hin, Win, C, stride, rows_band=0):
     Hout, Wout = (Hin - 1) // stride + 1, (Win - 1) // stride + 1
     y1 = torch.randn(planes * Hin * Win, C, device=dev).to(BF)
     dh2 = torch.randn(planes * Hout * Wout, C, device=dev).to(BF)
@@ -136,9 +136,9 @@ def dws_bwd(planes, Hin, Win, C, stride):
     a.dy = desc(dh2, C, q=y2, v1=abc, v2=abc[C:], v3=abc[2 * C:])
     a.y1 = desc(y1, C, v1=coef, v2=coef[C:], v3=coef[2 * C:], v4=coef[3 * C:])
     a.w = w.data_ptr(); a.dh1 = dh1.data_ptr(); a.dw = dw.data_ptr(); a.planes = planes; a.Hin = Hin; a.Win = Win
-    a.Hout = Hout; a.Wout = Wout; a.C = C; a.stride = stride; a.ks = 3; a.stats = st.data_ptr(); a.rows_band = 0
+    a.Hout = Hout; a.Wout = Wout; a.C = C; a.stride = stride; a.ks = 3; a.stats = st.data_ptr(); a.rows_band = rows_band
     ms = timeit(lambda: L.check(L.lib.dwn_dw_spatial_bwd(C_.byref(a), L.DWN_BF16, 0, stream()), "dwsb"))
-    report(f"dws_bwd planes={planes} {Hin}x{Win} C={C} s={stride}", ms, (2 * y1.numel() + 2 * y2.numel()) * 2)
+    report(f"dws_bwd planes={planes} {Hin}x{Win} C={C} s={stride} band={rows_band}", ms, (2 * y1.numel() + 2 * y2.numel()) * 2)
 
 
 C_ = C
@@ -163,6 +163,34 @@ if __name__ == "__main__":
         gemm_tn(2359296, 448, 64, "plain")
         gemm_tn(2359296, 448, 64, "affine2")
         gemm_tn(589824, 64, 448, "plain")
+    if "dwsfx" in which:
+        for rb in (2, 3, 4):
+            dws_fwd(1024, 36, 64, 448, 2, rb)
+        for rb in (4, 7, 9, 18):
+            dws_fwd(1024, 18, 32, 448, 1, rb)
+        for rb in (4, 6, 8, 12):
+            dws_bwd(1024, 36, 64, 448, 2, rb)
+        for rb in (3, 6, 9, 18):
+            dws_bwd(1024, 18, 32, 448, 1, rb)
+    if "nn1" in which:
+        gemm_nn(2359296, 448, 64, "plain", True)
+    if "nn2" in which:
+        gemm_nn(2359296, 64, 448, "affine2", False)
+    if "tn1" in which:
+        gemm_tn(2359296, 448, 64, "affine2")
+    if "deep" in which:
+        dws_fwd(1024, 18, 32, 896, 2)
+        dws_fwd(1024, 9, 16, 896, 1)
+        dws_fwd(1024, 9, 16, 1792, 2)
+        dws_fwd(1024, 5, 8, 1792, 1)
+        dws_bwd(1024, 18, 32, 896, 2)
+        dws_bwd(1024, 9, 16, 896, 1)
+        dws_bwd(1024, 9, 16, 1792, 2)
+        dws_bwd(1024, 5, 8, 1792, 1)
+    if "dwsb1" in which:
+        dws_bwd(1024, 18, 32, 448, 1)
+    if "dwsf1" in which:
+        dws_fwd(1024, 18, 32, 448, 1)
     if "dws" in which:
         dws_fwd(1024, 36, 64, 448, 2)
         dws_fwd(1024, 18, 32, 448, 1)
