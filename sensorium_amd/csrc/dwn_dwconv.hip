@@ -13,6 +13,7 @@
 // each CU keeps tens of KB in flight (the HBM latency-bandwidth product).
 #include "dwn_internal.h"
 #include <stdlib.h>
+#include <type_traits>
 
 extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
 
@@ -69,7 +70,7 @@ __device__ __forceinline__ void bn_silu4(float* v, const float* s, const float* 
 // spatial forward
 // ------------------------------------------------------------------------------------------------
 template <typename T, int KS, int ST>
-__global__ __launch_bounds__(256) void dw_spatial_fwd_kernel(const DwSpatialFwd a) {
+__global__ __launch_bounds__(256, 4) void dw_spatial_fwd_kernel(const DwSpatialFwd a) {
     constexpr int NCV = SL<T>::NCV, CS = SL<T>::CS, LP = SL<T>::LP, P = KS / 2;
     constexpr int XB = 4;                              // x-iterations batched per row (loads in flight per thread)
     typedef typename SL<T>::raw_t raw_t;
@@ -139,28 +140,30 @@ __global__ __launch_bounds__(256) void dw_spatial_fwd_kernel(const DwSpatialFwd 
             }
         }
         __syncthreads();
-        for (int oy = 0; oy < nro; ++oy) {
-            const i64 orow = ((i64)plane * a.Hout + ho0 + oy) * a.Wout;
-            for (int ox = pl; ox < a.Wout; ox += LP) {
-                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        {
+            const int total = nro * a.Wout;                 // flat walk: narrow planes still fill every pixel lane
+            const i64 orow0 = ((i64)plane * a.Hout + ho0) * a.Wout;
+            for (int i = pl; i < total; i += LP) {
+                const int oy = i / a.Wout, ox = i - oy * a.Wout;
+                f2_t acc0 = f2_t{0.f, 0.f}, acc1 = f2_t{0.f, 0.f};
                 const raw_t* tp = tile + ((oy * stride) * Wp + ox * stride) * NCV + cv;
 #pragma unroll
                 for (int dy = 0; dy < KS; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < KS; ++dx) {
-                        float v[4];
-                        V4<T>::unpack(tp[(dy * Wp + dx) * NCV], v);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[dy * KS + dx][i], v[i], acc[i]);
+                        f2_t v0, v1;
+                        unpack_pairs<T>(tp[(dy * Wp + dx) * NCV], v0, v1);
+                        acc0 += f2_t{w[dy * KS + dx][0], w[dy * KS + dx][1]} * v0;
+                        acc1 += f2_t{w[dy * KS + dx][2], w[dy * KS + dx][3]} * v1;
                     }
                 if (chan_ok) {
-                    st4<T>(outp + (orow + ox) * a.C + chan, acc);
+                    const float acc[4] = {acc0.x, acc0.y, acc1.x, acc1.y};
+                    const raw_t packed = V4<T>::pack(acc);
+                    *reinterpret_cast<raw_t*>(outp + (orow0 + i) * a.C + chan) = packed;
+                    float r[4];
+                    V4<T>::unpack(packed, r);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float r = round_t<T>(acc[i]);
-                        st0[i] += r;
-                        st1[i] += r * r;
-                    }
+                    for (int q = 0; q < 4; ++q) { st0[q] += r[q]; st1[q] += r[q] * r[q]; }
                 }
             }
         }
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256) void dw_spatial_fwd_kernel(const DwSpatialFwd 
 // spatial backward: dh1 = (dwS^T dy2) * silu'(h1), dW, Σdh1, Σdh1·ŷ1
 // ------------------------------------------------------------------------------------------------
 template <typename T, int KS, int ST>
-__global__ __launch_bounds__(256) void dw_spatial_bwd_kernel(const DwSpatialBwd a) {
+__global__ __launch_bounds__(256, 3) void dw_spatial_bwd_kernel(const DwSpatialBwd a) {
     constexpr int NCV = SL<T>::NCV, CS = SL<T>::CS, LP = SL<T>::LP, P = KS / 2;
     constexpr int XB = 4;
     typedef typename SL<T>::raw_t raw_t;
@@ -257,9 +260,8 @@ __global__ __launch_bounds__(256) void dw_spatial_bwd_kernel(const DwSpatialBwd 
             }
         }
         __syncthreads();
-        for (int iy = 0; iy < nri; ++iy) {
-            const int hi = hi0 + iy;
-            const i64 irow = ((i64)plane * a.Hin + hi) * a.Win;
+        {
+            const i64 prow0 = (i64)plane * a.Hin * a.Win;
             // one tap: g = dL/dy2 at (ho, wo) from the LDS tile; dz += w*g; dW[tap] += z1*g   (channel pairs)
             auto tap = [&](const int k, const int ho, const int wo, const f2_t* z1, f2_t* dz) {
                 f2_t g0, g1;
@@ -271,11 +273,11 @@ __global__ __launch_bounds__(256) void dw_spatial_bwd_kernel(const DwSpatialBwd 
                 dwp[k][1] += z1[1] * g1;
             };
             // everything after the taps: dh1 = dz * silu'(h1), store, BN-backward sums
-            auto finish = [&](const int wi, const f2_t* y, const f2_t* dsl, const f2_t* dz) {
+            auto finish = [&](const int hi, const int wi, const f2_t* y, const f2_t* dsl, const f2_t* dz) {
                 const f2_t d0 = dz[0] * dsl[0], d1 = dz[1] * dsl[1];
                 float dh[4] = {d0.x, d0.y, d1.x, d1.y};
                 const typename V4<T>::raw_t packed = V4<T>::pack(dh);
-                *reinterpret_cast<typename V4<T>::raw_t*>(dhp + (irow + wi) * a.C + chan) = packed;
+                *reinterpret_cast<typename V4<T>::raw_t*>(dhp + (prow0 + (i64)hi * a.Win + wi) * a.C + chan) = packed;
                 f2_t r0, r1;
                 unpack_pairs<T>(packed, r0, r1);              // statistics of the values as stored
                 sp0[0] += r0; sp0[1] += r1;
@@ -292,96 +294,97 @@ __global__ __launch_bounds__(256) void dw_spatial_bwd_kernel(const DwSpatialBwd 
                     dsl[i] = sg * (1.0f + h * (1.0f - sg));
                 }
             };
-            if constexpr (ST == 1) {
-                // stride 1: all KS*KS taps are valid for every pixel (the zero halo supplies the borders): branch-free
-                for (int xb = pl; xb < a.Win; xb += XB * LP) {
-                    raw_t ry[XB];
-#pragma unroll
-                    for (int u = 0; u < XB; ++u) {
-                        const int wi = xb + u * LP;
-                        ry[u] = ld4_raw<T>(y1p + (irow + ((chan_ok && wi < a.Win) ? wi : 0)) * a.y1.ld + chs);
-                    }
-#pragma unroll
-                    for (int u = 0; u < XB; ++u) {
-                        const int wi = xb + u * LP;
-                        if (!chan_ok || wi >= a.Win) continue;
-                        f2_t y[2], z1[2], dsl[2], dz[2] = {f2_t{0.f, 0.f}, f2_t{0.f, 0.f}};
-                        activate(ry[u], y, z1, dsl);
-#pragma unroll
-                        for (int dy = 0; dy < KS; ++dy)
-#pragma unroll
-                            for (int dx = 0; dx < KS; ++dx) tap(dy * KS + dx, hi + P - dy, wi + P - dx, z1, dz);
-                        finish(wi, y, dsl, dz);
-                    }
-                }
-            } else if constexpr (ST == 2 && KS == 3) {
-                // stride 2: an input pixel receives 1, 2, 2 or 4 taps depending on the parity of (hi, wi).  Pixels are
-                // walked by parity class so a wave executes exactly the taps it needs, with compile-time tap indices.
-                const bool h_even = (hi & 1) == 0;
-                const int ho_c = hi >> 1;                  // hi even: dy = 1 -> ho = hi/2
-                const int ho_a = (hi + 1) >> 1;            // hi odd : dy = 0 -> ho = (hi+1)/2
-                const int ho_b = (hi - 1) >> 1;            //          dy = 2 -> ho = (hi-1)/2
-#pragma unroll
-                for (int px = 0; px < 2; ++px) {
-                    for (int xb = pl; 2 * xb + px < a.Win; xb += XB * LP) {
+            // Pixels are walked as ONE flat index space (rows x columns of the band / of a parity class), XB loads in
+            // flight per thread, so narrow planes (W = 8..16) still fill all pixel lanes and every load batch.
+            if constexpr (ST == 2 && KS == 3) {
+                // stride 2: an input pixel receives 1, 2, 2 or 4 taps depending on the parity of (hi, wi): one pass per
+                // parity class, taps known at compile time.
+                auto run_class = [&](auto hp_c, auto px_c) {
+                    constexpr int HP = decltype(hp_c)::value, PX = decltype(px_c)::value;
+                    const int hfirst = hi0 + (((hi0 & 1) == HP) ? 0 : 1);
+                    const int nr = (hi0 + nri - hfirst + 1) >> 1;
+                    const int nc = (a.Win - PX + 1) >> 1;
+                    const int total = nr > 0 ? nr * nc : 0;
+                    for (int i0 = pl; i0 < total; i0 += XB * LP) {
                         raw_t ry[XB];
+                        int hh[XB], ww[XB];
 #pragma unroll
                         for (int u = 0; u < XB; ++u) {
-                            const int wi = 2 * (xb + u * LP) + px;
-                            ry[u] = ld4_raw<T>(y1p + (irow + ((chan_ok && wi < a.Win) ? wi : 0)) * a.y1.ld + chs);
+                            const int i = i0 + u * LP;
+                            const bool ok = chan_ok && i < total;
+                            const int k = ok ? i / nc : 0;
+                            hh[u] = hfirst + 2 * k;
+                            ww[u] = PX + 2 * ((ok ? i : 0) - k * nc);
+                            ry[u] = ld4_raw<T>(y1p + (ok ? prow0 + (i64)hh[u] * a.Win + ww[u] : 0) * a.y1.ld + chs);
                         }
 #pragma unroll
                         for (int u = 0; u < XB; ++u) {
-                            const int wi = 2 * (xb + u * LP) + px;
-                            if (!chan_ok || wi >= a.Win) continue;
+                            if (!chan_ok || i0 + u * LP >= total) continue;
+                            const int hi = hh[u], wi = ww[u];
                             f2_t y[2], z1[2], dsl[2], dz[2] = {f2_t{0.f, 0.f}, f2_t{0.f, 0.f}};
                             activate(ry[u], y, z1, dsl);
-                            if (px == 0) {                 // wi even: dx = 1 -> wo = wi/2
-                                const int wo = wi >> 1;
-                                if (h_even) tap(4, ho_c, wo, z1, dz);
-                                else { tap(1, ho_a, wo, z1, dz); tap(7, ho_b, wo, z1, dz); }
-                            } else {                       // wi odd: dx = 0 -> wo = (wi+1)/2 ; dx = 2 -> wo = (wi-1)/2
-                                const int wa = (wi + 1) >> 1, wb = (wi - 1) >> 1;
-                                if (h_even) { tap(3, ho_c, wa, z1, dz); tap(5, ho_c, wb, z1, dz); }
-                                else {
-                                    tap(0, ho_a, wa, z1, dz); tap(2, ho_a, wb, z1, dz);
-                                    tap(6, ho_b, wa, z1, dz); tap(8, ho_b, wb, z1, dz);
-                                }
+                            if constexpr (HP == 0 && PX == 0) {
+                                tap(4, hi >> 1, wi >> 1, z1, dz);
+                            } else if constexpr (HP == 0 && PX == 1) {
+                                tap(3, hi >> 1, (wi + 1) >> 1, z1, dz); tap(5, hi >> 1, (wi - 1) >> 1, z1, dz);
+                            } else if constexpr (HP == 1 && PX == 0) {
+                                tap(1, (hi + 1) >> 1, wi >> 1, z1, dz); tap(7, (hi - 1) >> 1, wi >> 1, z1, dz);
+                            } else {
+                                tap(0, (hi + 1) >> 1, (wi + 1) >> 1, z1, dz); tap(2, (hi + 1) >> 1, (wi - 1) >> 1, z1, dz);
+                                tap(6, (hi - 1) >> 1, (wi + 1) >> 1, z1, dz); tap(8, (hi - 1) >> 1, (wi - 1) >> 1, z1, dz);
                             }
-                            finish(wi, y, dsl, dz);
+                            finish(hi, wi, y, dsl, dz);
                         }
                     }
-                }
+                };
+                run_class(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                run_class(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+                run_class(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+                run_class(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
             } else {
-                for (int xb = pl; xb < a.Win; xb += XB * LP) {
+                const int total = nri * a.Win;
+                for (int i0 = pl; i0 < total; i0 += XB * LP) {
                     raw_t ry[XB];
+                    int hh[XB], ww[XB];
 #pragma unroll
                     for (int u = 0; u < XB; ++u) {
-                        const int wi = xb + u * LP;
-                        ry[u] = ld4_raw<T>(y1p + (irow + ((chan_ok && wi < a.Win) ? wi : 0)) * a.y1.ld + chs);
+                        const int i = i0 + u * LP;
+                        const bool ok = chan_ok && i < total;
+                        const int iy = ok ? i / a.Win : 0;
+                        hh[u] = hi0 + iy;
+                        ww[u] = (ok ? i : 0) - iy * a.Win;
+                        ry[u] = ld4_raw<T>(y1p + (ok ? prow0 + (i64)hh[u] * a.Win + ww[u] : 0) * a.y1.ld + chs);
                     }
 #pragma unroll
                     for (int u = 0; u < XB; ++u) {
-                        const int wi = xb + u * LP;
-                        if (!chan_ok || wi >= a.Win) continue;
+                        if (!chan_ok || i0 + u * LP >= total) continue;
+                        const int hi = hh[u], wi = ww[u];
                         f2_t y[2], z1[2], dsl[2], dz[2] = {f2_t{0.f, 0.f}, f2_t{0.f, 0.f}};
                         activate(ry[u], y, z1, dsl);
+                        if constexpr (ST == 1) {
+                            // stride 1: every tap is valid (the zero halo supplies the borders): branch-free
 #pragma unroll
-                        for (int dy = 0; dy < KS; ++dy) {
-                            const int nh = hi + P - dy;
-                            if (nh < 0 || nh % s != 0) continue;
-                            const int ho = nh / s;
-                            if (ho > ho_hi) continue;
+                            for (int dy = 0; dy < KS; ++dy)
 #pragma unroll
-                            for (int dx = 0; dx < KS; ++dx) {
-                                const int nw = wi + P - dx;
-                                if (nw < 0 || nw % s != 0) continue;
-                                const int wo = nw / s;
-                                if (wo > a.Wout) continue;
-                                tap(dy * KS + dx, ho, wo, z1, dz);
+                                for (int dx = 0; dx < KS; ++dx) tap(dy * KS + dx, hi + P - dy, wi + P - dx, z1, dz);
+                        } else {
+#pragma unroll
+                            for (int dy = 0; dy < KS; ++dy) {
+                                const int nh = hi + P - dy;
+                                if (nh < 0 || nh % s != 0) continue;
+                                const int ho = nh / s;
+                                if (ho > ho_hi) continue;
+#pragma unroll
+                                for (int dx = 0; dx < KS; ++dx) {
+                                    const int nw = wi + P - dx;
+                                    if (nw < 0 || nw % s != 0) continue;
+                                    const int wo = nw / s;
+                                    if (wo > a.Wout) continue;
+                                    tap(dy * KS + dx, ho, wo, z1, dz);
+                                }
                             }
                         }
-                        finish(wi, y, dsl, dz);
+                        finish(hi, wi, y, dsl, dz);
                     }
                 }
             }
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFw
 // backward affine — DYK = LD_AFFINE2 from (dh3, y3).
 // ------------------------------------------------------------------------------------------------
 template <typename T, int KT, int DYK>
-__global__ __launch_bounds__(256) void dw_temporal_bwd_kernel(const DwTemporalBwd a) {
+__global__ __launch_bounds__(256, 3) void dw_temporal_bwd_kernel(const DwTemporalBwd a) {
     constexpr int NCV = SL<T>::NCV, CS = SL<T>::CS, LP = SL<T>::LP, P = KT / 2;
     typedef typename SL<T>::raw_t raw_t;
     __shared__ float lstat[2 * CS];
