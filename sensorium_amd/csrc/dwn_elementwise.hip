@@ -205,24 +205,31 @@ template <typename T>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const float* w, T* y, int B, int Cin, i64 S,
                                                        int C0, double* stats) {
     SLICE_SETUP(C0)
+    constexpr int MAXCIN = 8;
     __shared__ float lstat[2 * NCV * KC];
     if (tid < 2 * NCV * KC) lstat[tid] = 0.f;
     __syncthreads();
-    float s0[KC], s1[KC];
+    float s0[KC], s1[KC], wr[MAXCIN][KC];
 #pragma unroll
     for (int i = 0; i < KC; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < MAXCIN; ++c)
+#pragma unroll
+        for (int i = 0; i < KC; ++i) wr[c][i] = (chan_ok && c < Cin) ? w[(chan + i) * Cin + c] : 0.f;
     const i64 rows = (i64)B * S;
     if (chan_ok)
         for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
-            i64 b = row / S, sp = row % S;
+            i64 b = row / S, sp = row - b * S;
+            float xv[MAXCIN];
+#pragma unroll
+            for (int c = 0; c < MAXCIN; ++c) xv[c] = c < Cin ? x[(b * Cin + c) * S + sp] : 0.f;
             float acc[KC];
 #pragma unroll
             for (int i = 0; i < KC; ++i) acc[i] = 0.f;
-            for (int c = 0; c < Cin; ++c) {
-                float xv = x[(b * Cin + c) * S + sp];
 #pragma unroll
-                for (int i = 0; i < KC; ++i) acc[i] = fmaf(w[(chan + i) * Cin + c], xv, acc[i]);
-            }
+            for (int c = 0; c < MAXCIN; ++c)
+#pragma unroll
+                for (int i = 0; i < KC; ++i) acc[i] = fmaf(wr[c][i], xv[c], acc[i]);
             st_vec<T>(y + row * C0 + chan, acc);
 #pragma unroll
             for (int i = 0; i < KC; ++i) {
@@ -315,6 +322,7 @@ int k_stem_bn_pe(const void* y0, const float* coef, const float* pe_t, const flo
 
 int k_stem_fwd(const float* x, const float* w, void* y, int B, int Cin, i64 S, int C0, double* stats, int dtype,
                hipStream_t s) {
+    if (Cin > 8) return dwn_set_error(-4, "stem: in_channels > 8 not built");
     if (dtype == DWN_BF16) {
         dim3 grid = slice_grid((i64)B * S, C0, 8);
         hipLaunchKernelGGL((stem_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, x, w, (bf16_t*)y, B, Cin, S, C0, stats);
@@ -620,7 +628,8 @@ int k_se_pool(const LoadDesc& z3, int B, int C, int rows_per_sample, float* pool
     return 0;
 }
 
-// one workgroup per sample: p = pooled/S; hid_pre = Wr p + br; hid = silu; gate = sigmoid(We hid + be)
+// SE MLP forward.  grid = (B, SPLIT): every workgroup recomputes the tiny hidden layer (R x C MACs) of its sample
+// and produces a 1/SPLIT slice of the C gates, so the launch fills the chip instead of B = 32 workgroups.
 __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* pooled_sum, float inv_s, const float* wr,
                                                          const float* br, const float* we, const float* be, int C,
                                                          int R, float* pmean, float* hid_pre, float* gate) {
@@ -628,10 +637,11 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* pooled_sum
     float* pm = sh;
     float* hid = sh + C;
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int split = gridDim.y, part = blockIdx.y;
     for (int c = tid; c < C; c += 256) {
         float v = pooled_sum[(i64)b * C + c] * inv_s;
         pm[c] = v;
-        pmean[(i64)b * C + c] = v;
+        if (part == 0) pmean[(i64)b * C + c] = v;
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
@@ -641,19 +651,22 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* pooled_sum
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
         if (lane == 0) {
             float h = acc + br[r];
-            hid_pre[(i64)b * R + r] = h;
+            if (part == 0) hid_pre[(i64)b * R + r] = h;
             hid[r] = siluf_(h);
         }
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+    const int per = (C + split - 1) / split;
+    const int c_end = (part + 1) * per < C ? (part + 1) * per : C;
+    for (int c = part * per + tid; c < c_end; c += 256) {
         float acc = be[c];
         for (int r = 0; r < R; ++r) acc = fmaf(we[(i64)c * R + r], hid[r], acc);
         gate[(i64)b * C + c] = sigmoidf_(acc);
     }
 }
 
-// per sample: dgp = dg*g*(1-g); dhid = We^T dgp; dhp = dhid*silu'(hid_pre); dpS = (Wr^T dhp)/S
+// SE MLP backward, data path.  grid = (B, SPLIT): dgp = dg*g*(1-g); dhid = We^T dgp (recomputed per workgroup);
+// dhp = dhid*silu'(hid_pre); dpS = (Wr^T dhp)/S for a 1/SPLIT slice of the channels.
 __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* dg, const float* gate, const float* hid_pre,
                                                          const float* wr, const float* we, int C, int R, float inv_s,
                                                          float* dgp_out, float* dhp_out, float* dps) {
@@ -661,11 +674,12 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* dg, const 
     float* dgp = sh;
     float* dhp = sh + C;
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int split = gridDim.y, part = blockIdx.y;
     for (int c = tid; c < C; c += 256) {
         float g = gate[(i64)b * C + c];
         float v = dg[(i64)b * C + c] * g * (1.f - g);
         dgp[c] = v;
-        dgp_out[(i64)b * C + c] = v;
+        if (part == 0) dgp_out[(i64)b * C + c] = v;
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
@@ -676,11 +690,13 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* dg, const 
         if (lane == 0) {
             float v = acc * silu_gradf_(hid_pre[(i64)b * R + r]);
             dhp[r] = v;
-            dhp_out[(i64)b * R + r] = v;
+            if (part == 0) dhp_out[(i64)b * R + r] = v;
         }
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+    const int per = (C + split - 1) / split;
+    const int c_end = (part + 1) * per < C ? (part + 1) * per : C;
+    for (int c = part * per + tid; c < c_end; c += 256) {
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc = fmaf(wr[(i64)r * C + c], dhp[r], acc);
         dps[(i64)b * C + c] = acc * inv_s;
@@ -714,7 +730,7 @@ __global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const float* dgp, con
 
 int k_se_mlp_fwd(const float* pooled_sum, float inv_s, const float* wr, const float* br, const float* we,
                  const float* be, int B, int C, int R, float* pmean, float* hid_pre, float* gate, hipStream_t s) {
-    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), s, pooled_sum, inv_s, wr, br, we,
+    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(B, 8), dim3(256), (C + R) * sizeof(float), s, pooled_sum, inv_s, wr, br, we,
                        be, C, R, pmean, hid_pre, gate);
     DWN_CHECK_LAUNCH();
     return 0;
@@ -722,7 +738,7 @@ int k_se_mlp_fwd(const float* pooled_sum, float inv_s, const float* wr, const fl
 int k_se_mlp_bwd(const float* dg, const float* gate, const float* hid_pre, const float* pmean, const float* wr,
                  const float* we, int B, int C, int R, float inv_s, float* dgp, float* dhp, float* dps, float* dwr,
                  float* dbr, float* dwe, float* dbe, hipStream_t s) {
-    hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), s, dg, gate, hid_pre, wr, we, C,
+    hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(B, 8), dim3(256), (C + R) * sizeof(float), s, dg, gate, hid_pre, wr, we, C,
                        R, inv_s, dgp, dhp, dps);
     DWN_CHECK_LAUNCH();
     hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 255) / 256, R), dim3(256), 0, s, dgp, dhp, pmean, hid_pre, B, C, R,

@@ -138,7 +138,7 @@ class StemFn(torch.autograd.Function):
         B, Cin, T, H, W = x.shape
         C0 = weight.shape[0]
         dout = dout.contiguous()
-        dw = torch.zeros(C0, Cin, dtype=torch.float32, device=dev)
+        dw = torch.zeros_like(weight, dtype=torch.float32)
         dgamma = torch.empty(C0, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C0, dtype=torch.float32, device=dev)
         a = L.StemArgs()
@@ -149,7 +149,7 @@ class StemFn(torch.autograd.Function):
         ws = _ws(L.lib.dwn_stem_workspace_bytes(C.byref(a)), dev)
         a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
         L.check(L.lib.dwn_stem_backward(C.byref(a), dev.index, _stream(dev)), "dwn_stem_backward")
-        return None, dw.view_as(weight), dgamma, dbeta, None, None, None
+        return None, dw, dgamma, dbeta, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -270,12 +270,14 @@ class BlockFn(torch.autograd.Function):
         da0 = torch.empty(m_in * Cin, dtype=dtype, device=dev)
         dx = torch.empty_like(x)
         R = blk.se.conv_reduce.out_channels
-        dw_pw = torch.zeros(Cmid, Cin, **f32)
-        dw_dws = torch.zeros(Cmid, blk.spatial_kernel * blk.spatial_kernel, **f32)
-        dw_dwt = torch.zeros(Cmid, blk.temporal_kernel, **f32)
-        dw_pwl = torch.zeros(Cout, Cmid, **f32)
-        dse_wr = torch.empty(R, Cmid, **f32); dse_br = torch.empty(R, **f32)
-        dse_we = torch.empty(Cmid, R, **f32); dse_be = torch.empty(Cmid, **f32)
+        # gradients are allocated in the parameters' own shapes (same memory layout as the kernels' 2-D views) so
+        # that autograd can take ownership instead of cloning a view
+        dw_pw = torch.zeros_like(blk.conv_pw[0].weight, dtype=torch.float32)
+        dw_dws = torch.zeros_like(blk.spat_covn_dw[0].weight, dtype=torch.float32)
+        dw_dwt = torch.zeros_like(blk.temp_covn_dw[0].weight, dtype=torch.float32)
+        dw_pwl = torch.zeros_like(blk.conv_pwl[0].weight, dtype=torch.float32)
+        dse_wr = torch.empty_like(blk.se.conv_reduce.weight, dtype=torch.float32); dse_br = torch.empty(R, **f32)
+        dse_we = torch.empty_like(blk.se.conv_expand.weight, dtype=torch.float32); dse_be = torch.empty(Cmid, **f32)
         a.dout = dout.data_ptr(); a.dx = dx.data_ptr()
         a.buf_a = buf_a.data_ptr(); a.buf_b = buf_b.data_ptr(); a.dy4 = dy4.data_ptr(); a.da0 = da0.data_ptr()
         a.dw_pw = dw_pw.data_ptr(); a.dw_dws = dw_dws.data_ptr(); a.dw_dwt = dw_dwt.data_ptr()
@@ -285,12 +287,8 @@ class BlockFn(torch.autograd.Function):
         ws = _ws(L.lib.dwn_block_workspace_bytes(C.byref(a), 1), dev)
         a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
         L.check(L.lib.dwn_block_backward(C.byref(a), dev.index, _stream(dev)), "dwn_block_backward")
-        grads = (dw_pw.view_as(blk.conv_pw[0].weight), dg[0], db[0],
-                 dw_dws.view_as(blk.spat_covn_dw[0].weight), dg[1], db[1],
-                 dw_dwt.view_as(blk.temp_covn_dw[0].weight), dg[2], db[2],
-                 dse_wr.view_as(blk.se.conv_reduce.weight), dse_br,
-                 dse_we.view_as(blk.se.conv_expand.weight), dse_be,
-                 dw_pwl.view_as(blk.conv_pwl[0].weight), dg[3], db[3], dg[4], db[4])
+        grads = (dw_pw, dg[0], db[0], dw_dws, dg[1], db[1], dw_dwt, dg[2], db[2], dse_wr, dse_br, dse_we, dse_be,
+                 dw_pwl, dg[3], db[3], dg[4], db[4])
         return (dx, None, None, None, None, None, None) + grads
 
 
@@ -373,7 +371,7 @@ class CortexFn(torch.autograd.Function):
         bn, bnsc = layer.bn.bn, layer.bn_sc.bn
         f32 = dict(dtype=torch.float32, device=dev)
         dgm, dbm, dgs, dbs = (torch.empty(Cc, **f32) for _ in range(4))
-        dw = torch.zeros(Cc, Cin // layer.groups, **f32)
+        dw = torch.zeros_like(weight, dtype=torch.float32)
         dx = torch.empty_like(x)
         a = L.CortexArgs()
         a.dtype = _DT[dtype]; a.training = 1; a.B = B; a.T = T; a.Cin = Cin; a.C = Cc
@@ -385,7 +383,7 @@ class CortexFn(torch.autograd.Function):
         ws = _ws(L.lib.dwn_cortex_workspace_bytes(C.byref(a), 1), dev)
         a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
         L.check(L.lib.dwn_cortex_backward(C.byref(a), dev.index, _stream(dev)), "dwn_cortex_backward")
-        return dx, None, None, None, dw.view_as(weight), dgm, dbm, dgs, dbs
+        return dx, None, None, None, dw, dgm, dbm, dgs, dbs
 
 
 # ------------------------------------------------------------------------------------------------
@@ -429,7 +427,7 @@ class ReadoutFn(torch.autograd.Function):
         B, T, Cin = x.shape
         n = mod.out_features
         dx = torch.empty_like(x)
-        dw = torch.zeros(weight.shape[0], weight.shape[1], dtype=torch.float32, device=dev)
+        dw = torch.zeros_like(weight, dtype=torch.float32)
         db = torch.zeros(bias.shape[0], dtype=torch.float32, device=dev)
         a = L.ReadoutArgs()
         a.dtype = _DT[x.dtype]; a.B = B; a.T = T; a.Cin = Cin; a.groups = mod.groups; a.n_out = n
@@ -440,7 +438,7 @@ class ReadoutFn(torch.autograd.Function):
         ws = _ws(L.lib.dwn_readout_workspace_bytes(C.byref(a), 1), dev)
         a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
         L.check(L.lib.dwn_readout_backward(C.byref(a), dev.index, _stream(dev)), "dwn_readout_backward")
-        return dx, None, None, dw.view_as(weight), db
+        return dx, None, None, dw, db
 
 
 # ------------------------------------------------------------------------------------------------
