@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--roofline-family", default="dws_bwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel family (adds event overhead)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU testing)")
+    ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,10 +133,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import sensorium_amd._lib as L
     from sensorium_amd.argus_models import MouseModel
@@ -211,7 +218,9 @@ def main():
                     "launches_per_step": launches_per_step, "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_bytes_per_launch": int(bytes_per_launch)}
         out = {
-            "metric": "training clips/sec (DwiseNeuro fwd+bwd+optimizer, B=32 T=32 36x64 per GPU)",
+            "metric": "training clips/sec/GPU (DwiseNeuro fwd+bwd, B=32 T=32 36x64) at 1/2/4/8 GPUs",
+            "value_is": "whole-job aggregate clips/s over all n_gpus (per-GPU figure: clips_per_s_per_gpu); a step "
+                        "includes loss, optimizer (fused AdamW), EMA and, for n_gpus > 1, the gradient all-reduce",
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

@@ -57,6 +57,20 @@ def deep_chunk(obj, chunks: int):
     raise TypeError(type(obj))
 
 
+@torch.no_grad()
+def fill_distill_targets(distill_prediction, target, distill_ratio: float):
+    """In-place soft-label fill of argus_models.py:35-41: every (sample, mouse) pair with weight 0 gets the
+    teacher's prediction as target and the weight ``r/(1-r) * sum(w) / #zeros``.  Vectorised with ``where``
+    (the reference loops over ``argwhere`` in python, ~288 iterations per step)."""
+    target_tensors, mice_weights = target
+    distill_mask = mice_weights == 0.0
+    distill_weight = distill_ratio / (1.0 - distill_ratio) * mice_weights.sum() / distill_mask.sum()
+    for m, pred in enumerate(distill_prediction):
+        sel = distill_mask[:, m]
+        target_tensors[m].copy_(torch.where(sel[:, None, None], pred.to(target_tensors[m].dtype), target_tensors[m]))
+    mice_weights.copy_(torch.where(distill_mask, distill_weight.to(mice_weights.dtype), mice_weights))
+
+
 class MouseModel:
     nn_module = {"dwiseneuro": DwiseNeuro}
     loss = {"mice_poisson": MicePoissonLoss}
@@ -111,15 +125,7 @@ class MouseModel:
     def add_distill_predictions(self, input, target):
         if self.distill_model is None or not self.distill_ratio:
             return
-        distill_prediction = self.distill_model(input)
-        target_tensors, mice_weights = target
-        distill_mask = mice_weights == 0.0
-        distill_weight = (self.distill_ratio / (1.0 - self.distill_ratio) * mice_weights.sum() / distill_mask.sum())
-        for m, pred in enumerate(distill_prediction):
-            sel = distill_mask[:, m]
-            target_tensors[m].copy_(torch.where(sel[:, None, None], pred.to(target_tensors[m].dtype),
-                                                target_tensors[m]))
-        mice_weights.copy_(torch.where(distill_mask, distill_weight.to(mice_weights.dtype), mice_weights))
+        fill_distill_targets(self.distill_model(input), target, self.distill_ratio)
 
     # -- argus_models.py:43-71 -----------------------------------------------------------------------------
     def train_step(self, batch, state=None, sync_loss: bool = True) -> dict:

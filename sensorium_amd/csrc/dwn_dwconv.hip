@@ -17,6 +17,10 @@
 
 extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
 
+#ifndef DWS_THREADS
+#define DWS_THREADS 512      // threads per workgroup of the spatial forward kernel (more waves per LDS tile)
+#endif
+#define DWS_BWD_THREADS 256
 // LDS tile budgets of the spatial kernels (bytes); tuned on MI355X with tools/microbench.py
 #ifndef DWS_FWD_LDS_BUDGET
 #define DWS_FWD_LDS_BUDGET (a.stride >= 2 ? 80 * 1024 : 48 * 1024)
@@ -69,9 +73,9 @@ __device__ __forceinline__ void bn_silu4(float* v, const float* s, const float* 
 // ------------------------------------------------------------------------------------------------
 // spatial forward
 // ------------------------------------------------------------------------------------------------
-template <typename T, int KS, int ST>
-__global__ __launch_bounds__(256, 4) void dw_spatial_fwd_kernel(const DwSpatialFwd a) {
-    constexpr int NCV = SL<T>::NCV, CS = SL<T>::CS, LP = SL<T>::LP, P = KS / 2;
+template <typename T, int KS, int ST, int NT>
+__global__ __launch_bounds__(NT, 4) void dw_spatial_fwd_kernel(const DwSpatialFwd a) {
+    constexpr int NCV = SL<T>::NCV, CS = SL<T>::CS, LP = NT / NCV, P = KS / 2;
     constexpr int XB = 4;                              // x-iterations batched per row (loads in flight per thread)
     typedef typename SL<T>::raw_t raw_t;
     const int stride = ST > 0 ? ST : a.stride;
@@ -176,8 +180,9 @@ __global__ __launch_bounds__(256, 4) void dw_spatial_fwd_kernel(const DwSpatialF
 // spatial backward: dh1 = (dwS^T dy2) * silu'(h1), dW, Σdh1, Σdh1·ŷ1
 // ------------------------------------------------------------------------------------------------
 template <typename T, int KS, int ST>
-__global__ __launch_bounds__(256, 3) void dw_spatial_bwd_kernel(const DwSpatialBwd a) {
-    constexpr int NCV = SL<T>::NCV, CS = SL<T>::CS, LP = SL<T>::LP, P = KS / 2;
+__global__ __launch_bounds__(DWS_BWD_THREADS, 3) void dw_spatial_bwd_kernel(const DwSpatialBwd a) {
+    constexpr int NT = DWS_BWD_THREADS;
+    constexpr int NCV = SL<T>::NCV, CS = SL<T>::CS, LP = NT / NCV, P = KS / 2;
     constexpr int XB = 4;
     typedef typename SL<T>::raw_t raw_t;
     __shared__ float lstat[2 * CS];
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(256, 3) void dw_spatial_bwd_kernel(const DwSpatialB
     const bool chan_ok = chan < a.C;
     const int chs = chan_ok ? chan : 0;
     if (tid < 2 * CS) lstat[tid] = 0.f;
-    for (int i = tid; i < KS * KS * CS; i += 256) {
+    for (int i = tid; i < KS * KS * CS; i += NT) {
         int k = i / CS, c = c0 + i % CS;
         lw[i] = c < a.C ? a.w[(i64)k * a.C + c] : 0.f;
     }
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(256, 3) void dw_spatial_bwd_kernel(const DwSpatialB
     }
     // weight gradient: reduce over the threads sharing a channel vector through LDS, then global fp32 atomics
     __syncthreads();
-    for (int i = tid; i < KS * KS * CS; i += 256) lw[i] = 0.f;
+    for (int i = tid; i < KS * KS * CS; i += NT) lw[i] = 0.f;
     __syncthreads();
     if (chan_ok) {
 #pragma unroll
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(256, 3) void dw_spatial_bwd_kernel(const DwSpatialB
         }
     }
     __syncthreads();
-    for (int i = tid; i < KS * KS * CS; i += 256) {
+    for (int i = tid; i < KS * KS * CS; i += NT) {
         int k = i / CS, c = c0 + i % CS;
         if (c < a.C) atomicAdd(a.dw + (i64)c * (KS * KS) + k, lw[i]);
     }
@@ -627,16 +632,16 @@ static inline int grid_cap(i64 work, int cap) { return (int)(work < cap ? (work 
 // persistent grids: one full resident wave of workgroups (256 CUs x blocks/CU from the occupancy query), so no
 // ragged second wave; `slices` workgroups share each x index
 template <typename K>
-static int resident_grid_x(K kernel, size_t dyn_lds, int slices, i64 work) {
+static int resident_grid_x(K kernel, size_t dyn_lds, int slices, i64 work, int threads = 256) {
     if (dyn_lds > 48 * 1024) {     // opt in to > default dynamic LDS (160 KiB per CU on gfx950, minus the static part)
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)dyn_lds) != hipSuccess)
             (void)hipGetLastError();   // clear: the launch itself reports a too-large tile
     }
     int bpc = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kernel, 256, dyn_lds) != hipSuccess || bpc < 1) bpc = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kernel, threads, dyn_lds) != hipSuccess || bpc < 1) bpc = 2;
     static const int mode = getenv("DWN_GRID_MODE") ? atoi(getenv("DWN_GRID_MODE")) : 0;   // tuning knob (microbench)
-    int gx = (256 * bpc * (mode > 0 ? mode : 1)) / slices;
+    int gx = (256 * bpc * (mode > 0 ? mode : 1)) / slices;     // 256 CUs
     if (gx < 1) gx = 1;
     return grid_cap(work, gx);
 }
@@ -661,9 +666,15 @@ static int spatial_fwd_t(DwSpatialFwd a, hipStream_t s) {
     const int nbands = (a.Hout + a.rows_band - 1) / a.rows_band;
     const int slices = (a.C + CS - 1) / CS;
     const i64 work = (i64)a.planes * nbands;
-    if (a.stride == 1) { dim3 grid(resident_grid_x(dw_spatial_fwd_kernel<T, 3, 1>, lds, slices, work), slices); hipLaunchKernelGGL((dw_spatial_fwd_kernel<T, 3, 1>), grid, dim3(256), lds, s, a); }
-    else if (a.stride == 2) { dim3 grid(resident_grid_x(dw_spatial_fwd_kernel<T, 3, 2>, lds, slices, work), slices); hipLaunchKernelGGL((dw_spatial_fwd_kernel<T, 3, 2>), grid, dim3(256), lds, s, a); }
-    else { dim3 grid(resident_grid_x(dw_spatial_fwd_kernel<T, 3, 0>, lds, slices, work), slices); hipLaunchKernelGGL((dw_spatial_fwd_kernel<T, 3, 0>), grid, dim3(256), lds, s, a); }
+    // 512-thread workgroups (twice the waves per LDS tile) pay off on large planes; tiny planes prefer 256
+    const bool big = a.Hin * a.Win >= 512;
+#define DWS_FWD_LAUNCH(ST_, NT_) do { \
+        dim3 grid(resident_grid_x(dw_spatial_fwd_kernel<T, 3, ST_, NT_>, lds, slices, work, NT_), slices); \
+        hipLaunchKernelGGL((dw_spatial_fwd_kernel<T, 3, ST_, NT_>), grid, dim3(NT_), lds, s, a); } while (0)
+    if (a.stride == 1) { if (big) DWS_FWD_LAUNCH(1, 512); else DWS_FWD_LAUNCH(1, 256); }
+    else if (a.stride == 2) { if (big) DWS_FWD_LAUNCH(2, 512); else DWS_FWD_LAUNCH(2, 256); }
+    else DWS_FWD_LAUNCH(0, 256);
+#undef DWS_FWD_LAUNCH
     DWN_CHECK_LAUNCH();
     return 0;
 }
@@ -690,9 +701,9 @@ static int spatial_bwd_t(DwSpatialBwd a, hipStream_t s) {
     const int nbands = (a.Hin + a.rows_band - 1) / a.rows_band;
     const int slices = (a.C + CS - 1) / CS;
     const i64 work = (i64)a.planes * nbands;
-    if (a.stride == 1) { dim3 grid(resident_grid_x(dw_spatial_bwd_kernel<T, 3, 1>, lds, slices, work), slices); hipLaunchKernelGGL((dw_spatial_bwd_kernel<T, 3, 1>), grid, dim3(256), lds, s, a); }
-    else if (a.stride == 2) { dim3 grid(resident_grid_x(dw_spatial_bwd_kernel<T, 3, 2>, lds, slices, work), slices); hipLaunchKernelGGL((dw_spatial_bwd_kernel<T, 3, 2>), grid, dim3(256), lds, s, a); }
-    else { dim3 grid(resident_grid_x(dw_spatial_bwd_kernel<T, 3, 0>, lds, slices, work), slices); hipLaunchKernelGGL((dw_spatial_bwd_kernel<T, 3, 0>), grid, dim3(256), lds, s, a); }
+    if (a.stride == 1) { dim3 grid(resident_grid_x(dw_spatial_bwd_kernel<T, 3, 1>, lds, slices, work, DWS_BWD_THREADS), slices); hipLaunchKernelGGL((dw_spatial_bwd_kernel<T, 3, 1>), grid, dim3(DWS_BWD_THREADS), lds, s, a); }
+    else if (a.stride == 2) { dim3 grid(resident_grid_x(dw_spatial_bwd_kernel<T, 3, 2>, lds, slices, work, DWS_BWD_THREADS), slices); hipLaunchKernelGGL((dw_spatial_bwd_kernel<T, 3, 2>), grid, dim3(DWS_BWD_THREADS), lds, s, a); }
+    else { dim3 grid(resident_grid_x(dw_spatial_bwd_kernel<T, 3, 0>, lds, slices, work, DWS_BWD_THREADS), slices); hipLaunchKernelGGL((dw_spatial_bwd_kernel<T, 3, 0>), grid, dim3(DWS_BWD_THREADS), lds, s, a); }
     DWN_CHECK_LAUNCH();
     return 0;
 }

@@ -114,3 +114,39 @@ def test_deep_chunk_and_synthetic_batch():
     assert float(targets[0][1].abs().sum()) == 0.0          # sample 1 belongs to mouse 1: zero target for mouse 0
     chunks = deep_chunk([x, [targets, w]], 2)
     assert len(chunks) == 2 and chunks[0][0].shape[0] == 2 and chunks[1][1][0][1].shape == (2, 10, 6)
+
+
+def test_fill_distill_targets_matches_reference_loop():
+    """argus_models.py:31-41 restated literally (python loop over argwhere) vs the vectorised product code."""
+    from sensorium_amd.argus_models import fill_distill_targets
+    g = torch.Generator().manual_seed(0)
+    b, mice, t, ratio = 6, 3, 4, 0.36
+    sizes = (5, 7, 4)
+    weights = torch.zeros(b, mice)
+    weights[torch.arange(b), torch.arange(b) % mice] = 1.0
+    targets = [torch.rand(b, n, t, generator=g) * weights[:, m][:, None, None] for m, n in enumerate(sizes)]
+    teacher = [torch.rand(b, n, t, generator=g) + 1.0 for n in sizes]
+    # literal restatement of the reference loop
+    ref_t = [x.clone() for x in targets]
+    ref_w = weights.clone()
+    mask = ref_w == 0.0
+    dw = ratio / (1.0 - ratio) * ref_w.sum() / mask.sum()
+    for bi, mi in torch.argwhere(mask):
+        ref_t[mi][bi] = teacher[mi][bi]
+        ref_w[bi, mi] = dw
+    mine_t = [x.clone() for x in targets]
+    mine_w = weights.clone()
+    fill_distill_targets(teacher, (mine_t, mine_w), ratio)
+    assert torch.equal(mine_w, ref_w)
+    for a, b_ in zip(mine_t, ref_t):
+        assert torch.equal(a, b_)
+
+
+def test_corr_and_window_indexes(golden_dir):
+    from sensorium_amd.metrics import corr
+    from sensorium_amd.predictors import IndexesGenerator
+    z = np.load(golden_dir / "corr.npz")
+    assert np.array_equal(corr(z["a"], z["b"], axis=0), z["corr"])
+    gen = IndexesGenerator(16, 2, "last")
+    assert (gen.behind, gen.ahead, gen.width) == (30, 0, 31)
+    assert gen.make_indexes(30) == list(range(0, 31, 2)) == orc.window_indexes(30, 16, 2)
