@@ -21,6 +21,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
 #define DWS_THREADS 512      // threads per workgroup of the spatial forward kernel (more waves per LDS tile)
 #endif
 #define DWS_BWD_THREADS 256
+#ifndef DWT_BWD_TB
+#define DWT_BWD_TB 4          // timesteps of loads in flight per thread in the temporal backward (4 or 8)
+#endif
 // LDS tile budgets of the spatial kernels (bytes); tuned on MI355X with tools/microbench.py
 #ifndef DWS_FWD_LDS_BUDGET
 #define DWS_FWD_LDS_BUDGET (a.stride >= 2 ? 80 * 1024 : 48 * 1024)
@@ -499,8 +502,8 @@ __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFw
 // dy3 is never materialised: DYK = LD_DY3 rebuilds it from (du, y3) — SE gate/gradient, SiLU' and the bn3
 // backward affine — DYK = LD_AFFINE2 from (dh3, y3).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int KT, int DYK>
-__global__ __launch_bounds__(256, 3) void dw_temporal_bwd_kernel(const DwTemporalBwd a) {
+template <typename T, int KT, int DYK, int TB>
+__global__ __launch_bounds__(256, TB >= 8 ? 2 : 3) void dw_temporal_bwd_kernel(const DwTemporalBwd a) {
     constexpr int NCV = SL<T>::NCV, CS = SL<T>::CS, LP = SL<T>::LP, P = KT / 2;
     typedef typename SL<T>::raw_t raw_t;
     __shared__ float lstat[2 * CS];
@@ -565,10 +568,10 @@ __global__ __launch_bounds__(256, 3) void dw_temporal_bwd_kernel(const DwTempora
                 if (t >= 0 && t < a.T) make_dy(ld4_raw<T>(dpp + e0 + t * tstride), ld4_raw<T>(dqp + e0 + t * tstride), g, g2, win[k]);
                 else { win[k][0] = win[k][1] = win[k][2] = win[k][3] = 0.f; }
             }
-            for (int t0 = 0; t0 < a.T; t0 += 4) {
-                raw_t rp[4], rq[4], ry[4];
+            for (int t0 = 0; t0 < a.T; t0 += TB) {
+                raw_t rp[TB], rq[TB], ry[TB];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < TB; ++u) {
                     int tl = t0 + u + P;
                     i64 off = e0 + (tl < a.T ? tl : 0) * tstride;
                     rp[u] = ld4_raw<T>(dpp + off);
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(256, 3) void dw_temporal_bwd_kernel(const DwTempora
                     ry[u] = ld4_raw<T>(y2p + e0 + (ty < a.T ? ty : 0) * tstride);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < TB; ++u) {
                     int t = t0 + u;
                     if (t >= a.T) break;
                     if (t + P < a.T) make_dy(rp[u], rq[u], g, g2, win[KT - 1]);
@@ -717,9 +720,9 @@ static int temporal_fwd_t(const DwTemporalFwd& a, hipStream_t s) {
     if (a.C % 8) return dwn_set_error(-2, "dw_temporal: C must be a multiple of 8");
     const int slices = (a.C + CS - 1) / CS;
     const i64 npos = (i64)a.B * a.HW;
-    dim3 grid(grid_cap((npos + LP - 1) / LP, (4096 + slices - 1) / slices), slices);
-    if (a.kt == 5) hipLaunchKernelGGL((dw_temporal_fwd_kernel<T, 5>), grid, dim3(256), 0, s, a);
-    else if (a.kt == 3) hipLaunchKernelGGL((dw_temporal_fwd_kernel<T, 3>), grid, dim3(256), 0, s, a);
+    const i64 work = (npos + LP - 1) / LP;
+    if (a.kt == 5) { dim3 grid(resident_grid_x(dw_temporal_fwd_kernel<T, 5>, 0, slices, work), slices); hipLaunchKernelGGL((dw_temporal_fwd_kernel<T, 5>), grid, dim3(256), 0, s, a); }
+    else if (a.kt == 3) { dim3 grid(resident_grid_x(dw_temporal_fwd_kernel<T, 3>, 0, slices, work), slices); hipLaunchKernelGGL((dw_temporal_fwd_kernel<T, 3>), grid, dim3(256), 0, s, a); }
     else return dwn_set_error(-4, "dw_temporal: only temporal_kernel 3 or 5 is built");
     DWN_CHECK_LAUNCH();
     return 0;
@@ -734,15 +737,18 @@ static int temporal_bwd_t(const DwTemporalBwd& a, hipStream_t s) {
     if (a.C % 8) return dwn_set_error(-2, "dw_temporal: C must be a multiple of 8");
     const int slices = (a.C + CS - 1) / CS;
     const i64 npos = (i64)a.B * a.HW;
-    dim3 grid(grid_cap((npos + LP - 1) / LP, (4096 + slices - 1) / slices), slices);
+    const i64 work = (npos + LP - 1) / LP;
     const bool dy3 = a.dy_kind == LD_DY3;
+    dim3 grid(resident_grid_x(dw_temporal_bwd_kernel<T, 5, LD_AFFINE2, 4>, 0, slices, work), slices);
     if (!dy3 && a.dy_kind != LD_AFFINE2) return dwn_set_error(-3, "dw_temporal_bwd: unsupported dy loader");
+    static const int tb8 = getenv("DWN_DWT_TB") ? atoi(getenv("DWN_DWT_TB")) == 8 : (DWT_BWD_TB == 8);
     if (a.kt == 5) {
-        if (dy3) hipLaunchKernelGGL((dw_temporal_bwd_kernel<T, 5, LD_DY3>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((dw_temporal_bwd_kernel<T, 5, LD_AFFINE2>), grid, dim3(256), 0, s, a);
+        if (dy3) hipLaunchKernelGGL((dw_temporal_bwd_kernel<T, 5, LD_DY3, 4>), grid, dim3(256), 0, s, a);
+        else if (tb8) hipLaunchKernelGGL((dw_temporal_bwd_kernel<T, 5, LD_AFFINE2, 8>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((dw_temporal_bwd_kernel<T, 5, LD_AFFINE2, 4>), grid, dim3(256), 0, s, a);
     } else if (a.kt == 3) {
-        if (dy3) hipLaunchKernelGGL((dw_temporal_bwd_kernel<T, 3, LD_DY3>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((dw_temporal_bwd_kernel<T, 3, LD_AFFINE2>), grid, dim3(256), 0, s, a);
+        if (dy3) hipLaunchKernelGGL((dw_temporal_bwd_kernel<T, 3, LD_DY3, 4>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((dw_temporal_bwd_kernel<T, 3, LD_AFFINE2, 4>), grid, dim3(256), 0, s, a);
     } else return dwn_set_error(-4, "dw_temporal: only temporal_kernel 3 or 5 is built");
     DWN_CHECK_LAUNCH();
     return 0;

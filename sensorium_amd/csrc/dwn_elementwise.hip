@@ -34,6 +34,20 @@ __device__ __forceinline__ void slice_stats_flush(float* lstat, const float* s0,
     }
 }
 
+// persistent sizing for the streaming kernels that keep per-workgroup accumulators: exactly one resident wave of
+// workgroups (occupancy query), so start-up / flush costs are paid once per CU slot and there is no ragged tail
+template <typename K>
+static dim3 resident_slice_grid(K kernel, i64 rows, int C, int KC) {
+    int slices = (C + NCV * KC - 1) / (NCV * KC);
+    int bpc = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kernel, 256, 0) != hipSuccess || bpc < 1) { (void)hipGetLastError(); bpc = 4; }
+    i64 bx = (256 * (i64)bpc) / slices;
+    i64 need = (rows + 31) / 32;
+    if (bx > need) bx = need;
+    if (bx < 1) bx = 1;
+    return dim3((unsigned)bx, (unsigned)slices);
+}
+
 static inline dim3 slice_grid(i64 rows, int C, int KC, int cap = 2048) {
     int slices = (C + NCV * KC - 1) / (NCV * KC);
     i64 bx = (rows + 31) / 32;
@@ -519,8 +533,8 @@ __global__ __launch_bounds__(256) void residual_bwd_dx_kernel(LoadDesc xin, cons
 int k_shortcut_stats(const LoadDesc& xin, const ResGeom& gm, double* stats, int dtype, hipStream_t s) {
     i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL((shortcut_stats_kernel<bf16_t>), slice_grid(rows, gm.Cin, 8, 1024), dim3(256), 0, s, xin, gm, stats),
-        hipLaunchKernelGGL((shortcut_stats_kernel<float>), slice_grid(rows, gm.Cin, 4, 1024), dim3(256), 0, s, xin, gm, stats));
+        hipLaunchKernelGGL((shortcut_stats_kernel<bf16_t>), resident_slice_grid(shortcut_stats_kernel<bf16_t>, rows, gm.Cin, 8), dim3(256), 0, s, xin, gm, stats),
+        hipLaunchKernelGGL((shortcut_stats_kernel<float>), resident_slice_grid(shortcut_stats_kernel<float>, rows, gm.Cin, 4), dim3(256), 0, s, xin, gm, stats));
     DWN_CHECK_LAUNCH();
     return 0;
 }
@@ -539,8 +553,8 @@ int k_residual_bwd_reduce(const LoadDesc& xin, const void* y4, const void* dout,
                           double* statssc, int dtype, hipStream_t s) {
     i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL((residual_bwd_reduce_kernel<bf16_t>), slice_grid(rows, gm.Cout, 8, 1024), dim3(256), 0, s, xin, (const bf16_t*)y4, (const bf16_t*)dout, coef4, coefsc, dscale, gm, stats4, statssc),
-        hipLaunchKernelGGL((residual_bwd_reduce_kernel<float>), slice_grid(rows, gm.Cout, 4, 1024), dim3(256), 0, s, xin, (const float*)y4, (const float*)dout, coef4, coefsc, dscale, gm, stats4, statssc));
+        hipLaunchKernelGGL((residual_bwd_reduce_kernel<bf16_t>), resident_slice_grid(residual_bwd_reduce_kernel<bf16_t>, rows, gm.Cout, 8), dim3(256), 0, s, xin, (const bf16_t*)y4, (const bf16_t*)dout, coef4, coefsc, dscale, gm, stats4, statssc),
+        hipLaunchKernelGGL((residual_bwd_reduce_kernel<float>), resident_slice_grid(residual_bwd_reduce_kernel<float>, rows, gm.Cout, 4), dim3(256), 0, s, xin, (const float*)y4, (const float*)dout, coef4, coefsc, dscale, gm, stats4, statssc));
     DWN_CHECK_LAUNCH();
     return 0;
 }
@@ -803,8 +817,8 @@ __global__ __launch_bounds__(256) void bn3_bwd_reduce_kernel(LoadDesc d, const f
 }
 int k_bn3_bwd_reduce(const LoadDesc& d, const float* coef3, i64 rows, int C, double* stats, void* dh_out, int dtype, hipStream_t s) {
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL((bn3_bwd_reduce_kernel<bf16_t>), slice_grid(rows, C, 8, 2048), dim3(256), 0, s, d, coef3, rows, C, stats, (bf16_t*)dh_out),
-        hipLaunchKernelGGL((bn3_bwd_reduce_kernel<float>), slice_grid(rows, C, 4, 2048), dim3(256), 0, s, d, coef3, rows, C, stats, (float*)dh_out));
+        hipLaunchKernelGGL((bn3_bwd_reduce_kernel<bf16_t>), resident_slice_grid(bn3_bwd_reduce_kernel<bf16_t>, rows, C, 8), dim3(256), 0, s, d, coef3, rows, C, stats, (bf16_t*)dh_out),
+        hipLaunchKernelGGL((bn3_bwd_reduce_kernel<float>), resident_slice_grid(bn3_bwd_reduce_kernel<float>, rows, C, 4), dim3(256), 0, s, d, coef3, rows, C, stats, (float*)dh_out));
     DWN_CHECK_LAUNCH();
     return 0;
 }
@@ -1242,8 +1256,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_plain_kernel(const T* g, co
 int k_bn_bwd_reduce_plain(const void* g, const void* y, const float* coef, i64 rows, int C, double* stats, int dtype,
                           hipStream_t s) {
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL((bn_bwd_reduce_plain_kernel<bf16_t>), slice_grid(rows, C, 8, 1024), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, coef, rows, C, stats),
-        hipLaunchKernelGGL((bn_bwd_reduce_plain_kernel<float>), slice_grid(rows, C, 4, 1024), dim3(256), 0, s, (const float*)g, (const float*)y, coef, rows, C, stats));
+        hipLaunchKernelGGL((bn_bwd_reduce_plain_kernel<bf16_t>), resident_slice_grid(bn_bwd_reduce_plain_kernel<bf16_t>, rows, C, 8), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, coef, rows, C, stats),
+        hipLaunchKernelGGL((bn_bwd_reduce_plain_kernel<float>), resident_slice_grid(bn_bwd_reduce_plain_kernel<float>, rows, C, 4), dim3(256), 0, s, (const float*)g, (const float*)y, coef, rows, C, stats));
     DWN_CHECK_LAUNCH();
     return 0;
 }

@@ -143,6 +143,41 @@ def dws_bwd(planes, Hin, Win, C, stride, rows_band=0):
 
 C_ = C
 
+
+def dwt_bwd(B, T, HW, C):
+    M = B * T * HW
+    dh3 = torch.randn(M, C, device=dev).to(BF)
+    y3 = torch.randn(M, C, device=dev).to(BF)
+    y2 = torch.randn(M, C, device=dev).to(BF)
+    dh2 = torch.empty_like(y2)
+    coef = torch.rand(4 * C, device=dev) + 0.5
+    abc = torch.randn(3 * C, device=dev)
+    w = torch.randn(5, C, device=dev)
+    dw = torch.zeros(C, 5, device=dev)
+    st = torch.zeros(32 * 2 * C, dtype=torch.float64, device=dev)
+    a = L.DwTemporalBwdArgs()
+    a.dy = desc(dh3, C, q=y3, v1=abc, v2=abc[C:], v3=abc[2 * C:])
+    a.dy_kind = L.LD_AFFINE2
+    a.y2 = desc(y2, C, v1=coef, v2=coef[C:], v3=coef[2 * C:], v4=coef[3 * C:])
+    a.w = w.data_ptr(); a.dh2 = dh2.data_ptr(); a.dw = dw.data_ptr(); a.B = B; a.T = T; a.HW = HW; a.C = C; a.kt = 5
+    a.stats = st.data_ptr()
+    ms = timeit(lambda: L.check(L.lib.dwn_dw_temporal_bwd(C_.byref(a), L.DWN_BF16, 0, stream()), "dwtb"))
+    report(f"dwt_bwd B={B} T={T} HW={HW} C={C}", ms, 4 * M * C * 2)
+
+
+def dwt_fwd(B, T, HW, C):
+    M = B * T * HW
+    y2 = torch.randn(M, C, device=dev).to(BF)
+    y3 = torch.empty_like(y2)
+    coef = torch.rand(4 * C, device=dev) + 0.5
+    w = torch.randn(5, C, device=dev)
+    st = torch.zeros(32 * 2 * C, dtype=torch.float64, device=dev)
+    a = L.DwTemporalFwdArgs()
+    a.inp = desc(y2, C, v1=coef, v2=coef[C:], act=1)
+    a.w = w.data_ptr(); a.out = y3.data_ptr(); a.B = B; a.T = T; a.HW = HW; a.C = C; a.kt = 5; a.stats = st.data_ptr()
+    ms = timeit(lambda: L.check(L.lib.dwn_dw_temporal_fwd(C_.byref(a), L.DWN_BF16, 0, stream()), "dwtf"))
+    report(f"dwt_fwd B={B} T={T} HW={HW} C={C}", ms, 2 * M * C * 2)
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["copy", "nn", "tn", "dws"]
     if "copy" in which:
@@ -172,6 +207,13 @@ if __name__ == "__main__":
             dws_bwd(1024, 36, 64, 448, 2, rb)
         for rb in (3, 6, 9, 18):
             dws_bwd(1024, 18, 32, 448, 1, rb)
+    if "dwt" in which:
+        dwt_fwd(32, 32, 18 * 32, 448)
+        dwt_bwd(32, 32, 18 * 32, 448)
+        dwt_bwd(32, 32, 9 * 16, 896)
+        dwt_bwd(32, 32, 5 * 8, 1792)
+    if "dwtb1" in which:
+        dwt_bwd(32, 32, 18 * 32, 448)
     if "nn1" in which:
         gemm_nn(2359296, 448, 64, "plain", True)
     if "nn2" in which:
