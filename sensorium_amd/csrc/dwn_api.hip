@@ -267,7 +267,7 @@ int dwn_stem_forward(const dwn_stem_args* a, int device, void* stream) {
     double* st = c.take<double>(nstat(a->C0));
     if (!c.ok()) return dwn_set_error(-6, "stem: workspace too small");
     const i64 M = (i64)a->B * a->S;
-    if (a->training) HIP_TRY(hipMemsetAsync(st, 0, nstat(a->C0) * sizeof(double), s));
+    if (a->training) TRY(k_zero(st, nstat(a->C0) * sizeof(double), s));
     TRY(k_stem_fwd(a->x, a->w, a->y0, a->B, a->Cin, a->S, a->C0, a->training ? st : nullptr, a->dtype, s));
     TRY(bn_finalize(st, a->C0, (double)M, a->bn, a->C0, a->training, a->momentum, a->eps, s));
     if (a->pe_t && (i64)a->T * a->H * a->W != a->S) return dwn_set_error(-2, "stem: T*H*W != S");
@@ -281,7 +281,7 @@ int dwn_stem_backward(const dwn_stem_args* a, int device, void* stream) {
     float* abc = c.take<float>(3 * (size_t)a->C0);
     if (!c.ok()) return dwn_set_error(-6, "stem: workspace too small");
     const i64 M = (i64)a->B * a->S;
-    HIP_TRY(hipMemsetAsync(st, 0, nstat(a->C0) * sizeof(double), s));
+    TRY(k_zero(st, nstat(a->C0) * sizeof(double), s));
     TRY(k_bn_bwd_reduce_plain(a->dout, a->y0, a->bn.coef, M, a->C0, st, a->dtype, s));
     TRY(k_bn_bwd_finalize(st, (double)M, a->bn.coef, a->bn.dgamma, a->bn.dbeta, abc, a->C0, s));
     LoadDesc dy = ld_affine2(a->dout, a->y0, a->C0, abc, a->C0);
@@ -303,7 +303,7 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     const int dt = a.dtype, tr = a.training;
     const i64 Min = (i64)a.B * a.T * a.Hin * a.Win, Mout = (i64)a.B * a.T * a.Hout * a.Wout;
     const int S_out = a.T * a.Hout * a.Wout;
-    HIP_TRY(hipMemsetAsync(w.zero_beg, 0, (size_t)(w.zero_end - w.zero_beg), s));
+    TRY(k_zero(w.zero_beg, ((size_t)(w.zero_end - w.zero_beg) + 15) & ~(size_t)15, s));
     TRY(k_pack_weight(a.w_pw, w.wpw, 1, a.Cmid, a.Cin, 0, a.Cmid, a.Cin, dt, s));
     TRY(k_pack_weight(a.w_pwl, w.wpwl, 1, a.Cout, a.Cmid, 0, a.Cout, a.Cmid, dt, s));
     TRY(k_pack_dw(a.w_dws, w.wdws, a.Cmid, a.ks * a.ks, s));
@@ -378,13 +378,13 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     const i64 Min = (i64)a.B * a.T * a.Hin * a.Win, Mout = (i64)a.B * a.T * a.Hout * a.Wout;
     const int S_out = a.T * a.Hout * a.Wout;
     float* dg = w.pooled;
-    HIP_TRY(hipMemsetAsync(w.zero_beg, 0, (size_t)(w.zero_end - w.zero_beg), s));
+    TRY(k_zero(w.zero_beg, ((size_t)(w.zero_end - w.zero_beg) + 15) & ~(size_t)15, s));
     TRY(k_pack_weight(a.w_pw, w.wpw, 1, a.Cmid, a.Cin, 1, a.Cin, a.Cmid, dt, s));      // W1^T [Cin][Cmid]
     TRY(k_pack_weight(a.w_pwl, w.wpwl, 1, a.Cout, a.Cmid, 1, a.Cmid, a.Cout, dt, s));  // W2^T [Cmid][Cout]
     TRY(k_pack_dw(a.w_dws, w.wdws, a.Cmid, a.ks * a.ks, s));
     TRY(k_pack_dw(a.w_dwt, w.wdwt, a.Cmid, a.kt, s));
     TRY(k_fill_f32(w.ident3, 1.0f, a.Cmid, s));
-    HIP_TRY(hipMemsetAsync(w.ident3 + a.Cmid, 0, 2 * (size_t)a.Cmid * sizeof(float), s));
+    TRY(k_fill_f32(w.ident3 + a.Cmid, 0.0f, 2 * a.Cmid, s));
 
     LoadDesc xin = ld_plain(a.x_has_pe ? a.x : a.a0, a.Cin);     // block input including its positional encoding
     ResGeom gm = geom_of(a);
@@ -501,7 +501,7 @@ int dwn_cortex_forward(const dwn_cortex_args* ap, int device, void* stream) {
     CortexWs w = carve_cortex(a, 0, a.ws, a.ws_bytes);
     if (w.bytes > a.ws_bytes) return dwn_set_error(-6, "cortex_forward: workspace too small");
     const int M = a.B * a.T, Kg = a.Cin / a.groups, Ng = a.C / a.groups, dt = a.dtype, tr = a.training;
-    HIP_TRY(hipMemsetAsync(w.zb, 0, (size_t)(w.ze - w.zb), s));
+    TRY(k_zero(w.zb, ((size_t)(w.ze - w.zb) + 15) & ~(size_t)15, s));
     TRY(k_pack_weight(a.w, w.wp, 1, a.C, Kg, 0, a.C, Kg, dt, s));
     GemmNN g = nn_base(ld_plain(a.x, a.Cin), LD_PLAIN, w.wp, Kg, a.y, a.C, M, Ng, Kg, a.groups);
     g.stats = tr ? w.st : nullptr; g.stat_nchan = a.C;
@@ -520,7 +520,7 @@ int dwn_cortex_backward(const dwn_cortex_args* ap, int device, void* stream) {
     CortexWs w = carve_cortex(a, 1, a.ws, a.ws_bytes);
     if (w.bytes > a.ws_bytes) return dwn_set_error(-6, "cortex_backward: workspace too small");
     const int M = a.B * a.T, Kg = a.Cin / a.groups, Ng = a.C / a.groups, dt = a.dtype;
-    HIP_TRY(hipMemsetAsync(w.zb, 0, (size_t)(w.ze - w.zb), s));
+    TRY(k_zero(w.zb, ((size_t)(w.ze - w.zb) + 15) & ~(size_t)15, s));
     TRY(k_pack_weight(a.w, w.wp, a.groups, Ng, Kg, 1, Kg, Ng, dt, s));     // per group W^T [Kg][Ng]
     TRY(k_cortex_bwd_reduce(a.y, a.x, a.dout, a.dout_mask, a.dout_mask_ld, a.bn.coef, a.bnsc.coef, a.drop_scale, M, a.T,
                             a.Cin, a.C, a.groups, w.st, w.stsc, dt, s));
@@ -576,7 +576,7 @@ int dwn_readout_forward(const dwn_readout_args* ap, int device, void* stream) {
     int kind = LD_PLAIN;
     if (a.drop_mask) {
         TRY(k_fill_f32(w.ones, 1.0f, a.Cin, s));
-        HIP_TRY(hipMemsetAsync(w.zeros, 0, (size_t)a.Cin * sizeof(float), s));
+        TRY(k_fill_f32(w.zeros, 0.0f, a.Cin, s));
         x.v1 = w.ones; x.v2 = w.zeros; x.act = 0; x.gate = a.drop_mask; x.gate_ld = a.Cin; x.rows_per_sample = a.T;
         kind = LD_BNACT;
     }
@@ -602,7 +602,7 @@ int dwn_readout_backward(const dwn_readout_args* ap, int device, void* stream) {
     int kind = LD_PLAIN;
     if (a.drop_mask) {
         TRY(k_fill_f32(w.ones, 1.0f, a.Cin, s));
-        HIP_TRY(hipMemsetAsync(w.zeros, 0, (size_t)a.Cin * sizeof(float), s));
+        TRY(k_fill_f32(w.zeros, 0.0f, a.Cin, s));
         x.v1 = w.ones; x.v2 = w.zeros; x.act = 0; x.gate = a.drop_mask; x.gate_ld = a.Cin; x.rows_per_sample = a.T;
         kind = LD_BNACT;
         // grad wrt the un-dropped input: dx *= mask (in place)

@@ -1218,6 +1218,21 @@ int k_ema_lerp(const TensorListEntry* list, int ntensors, int max_blocks, float 
 // ------------------------------------------------------------------------------------------------
 // small utilities
 // ------------------------------------------------------------------------------------------------
+// zero-fill as a kernel (not hipMemsetAsync): always replayed by a captured hipGraph, 16 bytes per lane
+__global__ __launch_bounds__(256) void zero_bytes_kernel(uint4* p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0, 0, 0, 0);
+}
+int k_zero(void* p, size_t nbytes, hipStream_t s) {
+    if (nbytes == 0) return 0;
+    if (((size_t)p & 15) || (nbytes & 15)) return dwn_set_error(-2, "k_zero: pointer and size must be 16-byte aligned");
+    size_t n16 = nbytes / 16;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(zero_bytes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint4*)p, n16);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
 __global__ void fill_f32_kernel(float* p, float v, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;

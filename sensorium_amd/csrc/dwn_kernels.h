@@ -71,3 +71,4 @@ int k_ema_lerp(const TensorListEntry* list, int ntensors, int max_blocks, float 
 int k_fill_f32(float* p, float v, int n, hipStream_t s);
 int k_bn_bwd_reduce_plain(const void* g, const void* y, const float* coef, i64 rows, int C, double* stats, int dtype,
                           hipStream_t s);
+int k_zero(void* p, size_t nbytes, hipStream_t s);

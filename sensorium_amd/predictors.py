@@ -38,9 +38,14 @@ class IndexesGenerator:
 
 class Predictor:
     def __init__(self, model, frame_stack_size: int = 16, frame_stack_step: int = 2, position: str = "last",
-                 windows_per_batch: int = 16):
-        """``model``: a ``sensorium_amd.argus_models.MouseModel`` (``predict(input, mouse_index)``)."""
+                 windows_per_batch: int = 16, use_graph: bool = False):
+        """``model``: a ``sensorium_amd.argus_models.MouseModel`` (``predict(input, mouse_index)``).
+        ``use_graph``: capture the eval forward of one full window batch into a hipGraph (torch.cuda.CUDAGraph) per
+        (mouse, shape) and replay it — the C-ABI neither allocates nor synchronises, so the ~500 launches of one
+        forward collapse into one graph launch (~270 tiny forwards per trial per model)."""
         self.model = model
+        self.use_graph = bool(use_graph)
+        self._graphs: dict = {}
         self.indexes_generator = IndexesGenerator(frame_stack_size, frame_stack_step, position)
         self.blend_weights = np.ones(frame_stack_size, dtype=np.float32)        # get_blend_weights("ones")
         self.windows_per_batch = max(1, int(windows_per_batch))
@@ -58,8 +63,11 @@ class Predictor:
         for i in range(0, len(ends), self.windows_per_batch):
             chunk = ends[i:i + self.windows_per_batch]
             idx = torch.tensor([gen.make_indexes(e) for e in chunk], device=device)          # [nw, size]
-            windows = inputs[:, idx]                                                         # (5, nw, size, H, W)
-            pred = self.model.predict(windows.permute(1, 0, 2, 3, 4).contiguous(), mouse_index)   # (nw, N, size)
+            windows = inputs[:, idx].permute(1, 0, 2, 3, 4).contiguous()                     # (nw, 5, size, H, W)
+            if self.use_graph and len(chunk) == self.windows_per_batch:
+                pred = self._graph_forward(windows, mouse_index)
+            else:
+                pred = self.model.predict(windows, mouse_index)                              # (nw, N, size)
             if responses is None:
                 responses = torch.zeros(pred.shape[1], length, dtype=torch.float32, device=device)
             flat_idx = idx.reshape(-1)
@@ -70,6 +78,27 @@ class Predictor:
             return np.zeros((n, length), dtype=np.float32)
         responses /= counts.clamp(min=1.0)
         return responses.cpu().numpy()
+
+
+    def _graph_forward(self, windows: torch.Tensor, mouse_index: int) -> torch.Tensor:
+        key = (mouse_index, tuple(windows.shape), windows.dtype)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_in = windows.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                      # warm-up outside the capture (allocator, lazy loads)
+                self.model.predict(static_in, mouse_index)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self.model.predict(static_in, mouse_index)
+            entry = (graph, static_in, static_out)
+            self._graphs[key] = entry
+        graph, static_in, static_out = entry
+        static_in.copy_(windows)
+        graph.replay()
+        return static_out
 
 
 def ensemble_predict_trial(predictors: Sequence[Predictor], inputs: torch.Tensor, mouse_index: int) -> np.ndarray:

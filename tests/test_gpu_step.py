@@ -87,8 +87,8 @@ def test_val_step_and_predict(golden_dir):
     assert not model.nn_module.training
 
 
-@pytest.mark.parametrize("windows_per_batch", [1, 4])
-def test_predict_trial_matches_reference(golden_dir, windows_per_batch):
+@pytest.mark.parametrize("windows_per_batch,use_graph", [(1, False), (4, False), (4, True)])
+def test_predict_trial_matches_reference(golden_dir, windows_per_batch, use_graph):
     """Sliding-window blend (predictors.py:37-55) against the fixture produced by the reference loop."""
     from sensorium_amd.argus_models import MouseModel
     from sensorium_amd.predictors import Predictor, ensemble_predict_trial
@@ -97,7 +97,7 @@ def test_predict_trial_matches_reference(golden_dir, windows_per_batch):
     model = MouseModel(tiny_params())
     model.nn_module.load_state_dict(sd, strict=True)
     pred = Predictor(model, frame_stack_size=int(z["size"]), frame_stack_step=int(z["step"]),
-                     windows_per_batch=windows_per_batch)
+                     windows_per_batch=windows_per_batch, use_graph=use_graph)
     out = pred.predict_trial(torch.from_numpy(z["inputs"]), 1)
     assert out.shape == z["responses"].shape and out.dtype == np.float32
     assert rel(torch.from_numpy(out), torch.from_numpy(z["responses"])) < 1e-3
@@ -124,3 +124,41 @@ def test_distillation_step_runs_and_uses_teacher(golden_dir):
     expect_w = 0.36 / 0.64 * float(w.sum()) / float((w == 0).sum())
     assert torch.allclose(tw[w == 0], torch.full_like(tw[w == 0], expect_w))
     assert math.isfinite(out["loss"]) and abs(out["loss"] - float(z["loss"])) > 1e-6     # soft labels changed the loss
+
+
+def test_eval_forward_is_hipgraph_capturable(golden_dir):
+    """The C-ABI never allocates or synchronises, so a whole eval forward can be captured into a hipGraph
+    (torch.cuda.CUDAGraph) and replayed on new inputs — the launch pattern of the sliding-window predictor."""
+    from sensorium_amd import DwiseNeuro
+    z, sd = golden_sd(golden_dir, "tiny_model_eval.npz")
+    model = DwiseNeuro(**TINY_KW)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev()).eval()
+    x = torch.from_numpy(z["x"]).to(dev())
+    static_in = x.clone()
+    with torch.no_grad():
+        for _ in range(2):                       # warm-up on a side stream (allocator, lazy kernel loading)
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                model(static_in, 1)
+            torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = model(static_in, 1)
+        ref = torch.from_numpy(z["pred_1"])
+        graph.replay()
+        torch.cuda.synchronize()
+        assert rel(static_out, ref) < 1e-3
+        # new input through the same captured graph
+        x2 = torch.flip(x, dims=[0]).contiguous()
+        static_in.copy_(x2)
+        graph.replay()
+        torch.cuda.synchronize()
+        ref2 = torch.flip(ref, dims=[0])         # eval mode: samples are independent
+        eager = model(x2, 1)
+        assert rel(eager, ref2) < 1e-3, "eager forward on the flipped batch"
+        assert rel(static_out, ref2) < 1e-3, "graph replay on the flipped batch"
+        graph.replay()                            # replays must be idempotent (all workspaces re-zeroed inside the graph)
+        torch.cuda.synchronize()
+        assert rel(static_out, eager) < 1e-5
