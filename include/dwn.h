@@ -65,6 +65,7 @@ typedef struct dwn_load_desc {
 #define DWN_EPI_STORE 0
 #define DWN_EPI_READOUT 1
 #define DWN_EPI_DG 2
+#define DWN_EPI_STORE_CAT 3   /* DWN_EPI_STORE + K-concatenated second A operand (a2, K1) + fp32 bias[N] */
 
 /* C[M][N] = load(A)[M][K] . B[N][K]^T  (+ BN statistics / readout / SE-grad epilogues).
  * Replaces nn.Conv3d 1x1x1 (dwiseneuro.py:91,118) and grouped nn.Conv1d k=1 (:207,276). */
@@ -79,6 +80,9 @@ typedef struct dwn_gemm_nn_args {
     int epi;
     const float* bias; float sp_beta; float* out_nct; int Tn; int n_valid;
     const void* y3; long long ldy3; const float* s3; const float* t3; float* dg; int dg_ld; int rows_per_sample;
+    /* optional K-concatenation: columns k >= K1 of the A operand come from a2[m][k - K1] (plain loads);
+     * only with epi == DWN_EPI_STORE_CAT, which also adds `bias` (fp32 [N]) before rounding. */
+    const void* a2; long long a2_ld; int K1;
 } dwn_gemm_nn_args;
 
 /* dW[R][Cc] += sum_m load(P)[m][r] * load(Q)[m][c]   (fp32 atomics; dW must be zeroed by the caller) */

@@ -119,6 +119,7 @@ struct BlockWs {
     float* pooled;               // forward: SE pooled sums; backward: dg
     float *abc1, *abc2, *abc3, *abc4, *abcsc, *ident3;
     float *dgp, *dhp, *dps;
+    void* bp; float* r3; float* gacc;                      // conv_pw data-gradient folding (see dwn_elementwise.hip)
     char* zero_beg; char* zero_end;
     size_t bytes;
 };
@@ -149,6 +150,9 @@ BlockWs carve_block(const dwn_block_args& a, int backward, void* base, size_t ca
         w.dgp = c.take<float>((size_t)a.B * a.Cmid);
         w.dhp = c.take<float>((size_t)a.B * a.se_r);
         w.dps = c.take<float>((size_t)a.B * a.Cmid);
+        w.bp = c.take<char>((size_t)a.Cin * (a.Cmid + a.Cin) * ts);
+        w.r3 = c.take<float>((size_t)a.Cin);
+        w.gacc = c.take<float>((size_t)a.Cin * a.Cin);
     }
     w.bytes = c.off + 256;
     if (base) { w.zero_beg = (char*)base + z0; w.zero_end = (char*)base + z1; }
@@ -379,7 +383,6 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     const int S_out = a.T * a.Hout * a.Wout;
     float* dg = w.pooled;
     TRY(k_zero(w.zero_beg, ((size_t)(w.zero_end - w.zero_beg) + 15) & ~(size_t)15, s));
-    TRY(k_pack_weight(a.w_pw, w.wpw, 1, a.Cmid, a.Cin, 1, a.Cin, a.Cmid, dt, s));      // W1^T [Cin][Cmid]
     TRY(k_pack_weight(a.w_pwl, w.wpwl, 1, a.Cout, a.Cmid, 1, a.Cmid, a.Cout, dt, s));  // W2^T [Cmid][Cout]
     TRY(k_pack_dw(a.w_dws, w.wdws, a.Cmid, a.ks * a.ks, s));
     TRY(k_pack_dw(a.w_dwt, w.wdwt, a.Cmid, a.kt, s));
@@ -439,13 +442,17 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
         PROF(DWN_FAM_DWS_BWD, launch_dw_spatial_bwd(d, dt, s));
     }
     TRY(k_bn_bwd_finalize(w.st1, (double)Min, a.bn1.coef, a.bn1.dgamma, a.bn1.dbeta, w.abc1, a.Cmid, s));
-    // conv_pw backward
-    LoadDesc dy1 = ld_affine2(dh1, a.y1, a.Cmid, w.abc1, a.Cmid);
+    // conv_pw backward.  Data gradient: dy1 = A1*dh1 + A2*y1 + A3 with y1 = a0.W1^T, so the y1 term folds into a
+    // Cin x Cin matrix and the GEMM reads dh1 (+ the small a0) only:  da0 = [dh1 | a0] . [diag(A1) W1 ; G] + r3
+    TRY(k_pw_bwd_prep(a.w_pw, w.abc1, a.Cmid, a.Cin, w.bp, w.gacc, w.r3, dt, s));
     {
-        GemmNN g = nn_base(dy1, LD_AFFINE2, w.wpw, a.Cmid, a.da0, a.Cin, (int)Min, a.Cin, a.Cmid, 1);
+        GemmNN g = nn_base(ld_plain(dh1, a.Cmid), LD_PLAIN, w.bp, (i64)a.Cmid + a.Cin, a.da0, a.Cin, (int)Min, a.Cin,
+                           a.Cmid + a.Cin, 1);
+        g.epi = EPI_STORE_CAT; g.a2 = xin.p; g.a2_ld = a.Cin; g.K1 = a.Cmid; g.bias = w.r3;
         PROF(DWN_FAM_PW_DGRAD, launch_gemm_nn(g, dt, s));
     }
-    {
+    {   // weight gradient: dW1 = dy1^T a0 with the BatchNorm-backward affine applied while loading (dh1, y1)
+        LoadDesc dy1 = ld_affine2(dh1, a.y1, a.Cmid, w.abc1, a.Cmid);
         GemmTN g = tn_base(dy1, LD_AFFINE2, xin, LD_PLAIN, (int)Min, a.Cmid, a.Cin, a.dw_pw, a.Cin, 1);
         PROF(DWN_FAM_PW_WGRAD, launch_gemm_tn(g, dt, s));
     }

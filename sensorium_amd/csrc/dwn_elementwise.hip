@@ -1276,3 +1276,72 @@ int k_bn_bwd_reduce_plain(const void* g, const void* y, const float* coef, i64 r
     DWN_CHECK_LAUNCH();
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// conv_pw data-gradient without re-reading y1.  The BatchNorm-backward affine dy1 = A1*dh1 + A2*y1 + A3 is linear and
+// y1 = a0 . W1^T, so the A2*y1 term folds into a Cin x Cin matrix (reference math: backward of dwiseneuro.py:90-93):
+//   da0 = dh1 . (diag(A1) W1) + a0 . G + r3,    G = W1^T diag(A2) W1,    r3 = A3 . W1
+// The GEMM then reads dh1 (and the small a0) only: half the HBM traffic of reading (dh1, y1).
+// Bp[n][k] (T, ld = E + C): k < E: A1[k]*W1[k][n];  k = E + c': G[c'][n].   W1 is used as rounded to T (forward's values).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pw_bwd_scale_kernel(const float* w1, const float* abc, int E, int C, T* bp) {
+    const i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
+    const i64 ld = (i64)E + C;
+    if (idx < (i64)E * C) {
+        const int k = (int)(idx / C), n = (int)(idx % C);
+        bp[n * ld + k] = from_f<T>(abc[k] * round_t<T>(w1[idx]));
+    }
+}
+// partial sums over one 64-row chunk of E (blockIdx.z), accumulated with fp32 atomics into gacc[C][C] and r3[C]:
+//   gacc[c'][c] += sum_e A2[e] W1[e][c'] W1[e][c]        r3[c] += sum_e A3[e] W1[e][c]
+template <typename T>
+__global__ __launch_bounds__(256) void pw_bwd_gram_kernel(const float* w1, const float* abc, int E, int C, float* gacc,
+                                                          float* r3) {
+    const int cp = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int c = blockIdx.y * 16 + (threadIdx.x & 15);
+    const int e0 = blockIdx.z * 64;
+    const int e1 = e0 + 64 < E ? e0 + 64 : E;
+    if (cp >= C || c >= C) return;
+    const float* A2 = abc + E;
+    const float* A3 = abc + 2 * E;
+    float acc = 0.f, acc3 = 0.f;
+    for (int e = e0; e < e1; ++e) {
+        const float wc = round_t<T>(w1[(i64)e * C + c]);
+        acc = fmaf(A2[e] * round_t<T>(w1[(i64)e * C + cp]), wc, acc);
+        acc3 = fmaf(A3[e], wc, acc3);
+    }
+    atomicAdd(gacc + (i64)cp * C + c, acc);
+    if (blockIdx.x == 0 && (threadIdx.x >> 4) == 0) atomicAdd(r3 + c, acc3);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pw_bwd_gram_store_kernel(const float* gacc, int E, int C, T* bp) {
+    const i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (i64)C * C) return;
+    const int cp = (int)(idx / C), c = (int)(idx % C);
+    bp[(i64)c * ((i64)E + C) + E + cp] = from_f<T>(gacc[idx]);       // Bp[n = c][E + c'] = G[c'][c]
+}
+// gacc: [C*C] fp32 scratch, r3: [C] fp32 — both zeroed here
+int k_pw_bwd_prep(const float* w1, const float* abc, int E, int C, void* bp, float* gacc, float* r3, int dtype,
+                  hipStream_t s) {
+    int rc = k_fill_f32(gacc, 0.f, C * C, s);
+    if (rc) return rc;
+    rc = k_fill_f32(r3, 0.f, C, s);
+    if (rc) return rc;
+    dim3 g1((unsigned)(((i64)E * C + 255) / 256)), g2((C + 15) / 16, (C + 15) / 16, (E + 63) / 64);
+    dim3 g3((unsigned)(((i64)C * C + 255) / 256));
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((pw_bwd_scale_kernel<bf16_t>), g1, dim3(256), 0, s, w1, abc, E, C, (bf16_t*)bp),
+        hipLaunchKernelGGL((pw_bwd_scale_kernel<float>), g1, dim3(256), 0, s, w1, abc, E, C, (float*)bp));
+    DWN_CHECK_LAUNCH();
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((pw_bwd_gram_kernel<bf16_t>), g2, dim3(256), 0, s, w1, abc, E, C, gacc, r3),
+        hipLaunchKernelGGL((pw_bwd_gram_kernel<float>), g2, dim3(256), 0, s, w1, abc, E, C, gacc, r3));
+    DWN_CHECK_LAUNCH();
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((pw_bwd_gram_store_kernel<bf16_t>), g3, dim3(256), 0, s, gacc, E, C, (bf16_t*)bp),
+        hipLaunchKernelGGL((pw_bwd_gram_store_kernel<float>), g3, dim3(256), 0, s, gacc, E, C, (float*)bp));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}

@@ -115,6 +115,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                 int m = m0 + (tid >> 3) + 32 * i;
                 ra[i] = (m < g.M && kok) ? load_op_packed<LD_PE, T>(g.a, (i64)m, acol0 + k) : make_uint4(0, 0, 0, 0);
             }
+        } else if (EPI == EPI_STORE_CAT && k >= g.K1) {
+            // K-concatenated second operand (plain): A[m][k] = a2[m][k - K1]
+            const T* A2p = reinterpret_cast<const T*>(g.a2);
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                int m = m0 + (tid >> 3) + 32 * i;
+                ra[i] = (m < g.M && kok) ? *reinterpret_cast<const uint4*>(A2p + (i64)m * g.a2_ld + (k - g.K1))
+                                         : make_uint4(0, 0, 0, 0);
+            }
         } else {
             if (kok && k != cf_k) { cf.load(g.a, acol0 + k); cf_k = k; }
             uint4 rp[A_CH], rq[A_CH];
@@ -297,6 +306,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                             for (int j = 0; j < NJ; ++j) {
                                 const int col = wn * (BN / 2) + j * 16 + lg * 4;
                                 unsigned char* dst = sC + (trow - prow0) * CROW + col * (int)sizeof(T);
+                                if (EPI == EPI_STORE_CAT && n0 + col < g.N) {
+                                    const float4 bv = *reinterpret_cast<const float4*>(g.bias + ccol0 + n0 + col);
+                                    acc[i][j][0] += bv.x; acc[i][j][1] += bv.y; acc[i][j][2] += bv.z; acc[i][j][3] += bv.w;
+                                }
                                 if constexpr (TT<T>::IS_BF16) {
                                     uint2 v;
                                     v.x = (uint32_t)f2bf(acc[i][j][0]) | ((uint32_t)f2bf(acc[i][j][1]) << 16);
@@ -421,6 +434,11 @@ static int launch_nn_d(const GemmNN& g, hipStream_t s) {
     if (g.epi == EPI_DG) {
         if (g.a_kind == LD_PLAIN && g.groups == 1) return launch_nn_t<T, LD_PLAIN, EPI_DG>(g, s);
         return dwn_set_error(-3, "gemm_nn: unsupported loader for dg epilogue");
+    }
+    if (g.epi == EPI_STORE_CAT) {
+        if (g.a_kind != LD_PLAIN || g.groups != 1 || g.K1 <= 0 || g.K1 % TT<T>::KC || !g.a2 || !g.bias)
+            return dwn_set_error(-3, "gemm_nn: K-concat epilogue needs a plain loader, groups == 1, a2, bias and K1 % vector == 0");
+        return launch_nn_t<T, LD_PLAIN, EPI_STORE_CAT>(g, s);
     }
     switch (g.a_kind) {
         case LD_PLAIN: return launch_nn_t<T, LD_PLAIN, EPI_STORE>(g, s);

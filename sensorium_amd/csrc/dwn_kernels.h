@@ -72,3 +72,5 @@ int k_fill_f32(float* p, float v, int n, hipStream_t s);
 int k_bn_bwd_reduce_plain(const void* g, const void* y, const float* coef, i64 rows, int C, double* stats, int dtype,
                           hipStream_t s);
 int k_zero(void* p, size_t nbytes, hipStream_t s);
+int k_pw_bwd_prep(const float* w1, const float* abc, int E, int C, void* bp, float* gacc, float* r3, int dtype,
+                  hipStream_t s);

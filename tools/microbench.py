@@ -231,6 +231,10 @@ if __name__ == "__main__":
         dws_bwd(1024, 5, 8, 1792, 1)
     if "dwsb1" in which:
         dws_bwd(1024, 18, 32, 448, 1)
+    if "dwsf0" in which:
+        dws_fwd(1024, 36, 64, 448, 2)
+    if "dwsb0" in which:
+        dws_bwd(1024, 36, 64, 448, 2)
     if "dwsf1" in which:
         dws_fwd(1024, 18, 32, 448, 1)
     if "dws" in which:
