@@ -79,17 +79,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     const int tid = threadIdx.x;
     const int ntn = (g.N + BN - 1) / BN;
     const int ntm = (g.M + BM - 1) / BM;
-    // XCD-aware order: blocks b and b+8 share an XCD's L2, so the N-tiles of one M-range (which re-read the same
-    // A rows) are placed 8 apart.
+    // XCD-aware order (gridDim.x is a multiple of 8; blocks b and b+8 share an XCD's L2): the N-tiles of one
+    // M-range re-read the same A rows, so they get consecutive slots of one XCD.  M-ranges interleave over the XCDs
+    // when their count allows it, and the M-tiles are split evenly (range sizes differ by at most one tile).
     const int bid = blockIdx.x;
-    const int xcd = bid & 7;
-    const int jj = bid >> 3;
-    const int nt = jj % ntn;
-    const int mr = (jj / ntn) * 8 + xcd;
     const int nranges = (int)(gridDim.x / ntn);
-    const int tpr = (ntm + nranges - 1) / nranges;
-    const int mt_beg = mr * tpr;
-    const int mt_end = (mt_beg + tpr < ntm) ? mt_beg + tpr : ntm;
+    int nt, mr;
+    if ((nranges & 7) == 0) {
+        const int jj = bid >> 3;
+        nt = jj % ntn;
+        mr = (jj / ntn) * 8 + (bid & 7);
+    } else {
+        const int lid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+        nt = lid % ntn;
+        mr = lid / ntn;
+    }
+    const int mt_beg = (int)((i64)mr * ntm / nranges);
+    const int mt_end = (int)((i64)(mr + 1) * ntm / nranges);
     if (mt_beg >= mt_end) return;
     const int grp = blockIdx.y;
     const int n0 = nt * BN;
@@ -411,10 +417,13 @@ static int launch_nn_t(const GemmNN& g, hipStream_t s) {
         ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, gemm_nn_kernel<T, ALD, EPI, 64>, 256, 0)
         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, gemm_nn_kernel<T, ALD, EPI, 128>, 256, 0);
     if (oe != hipSuccess || bpc < 1) { (void)hipGetLastError(); bpc = 1; }
+    // never more workgroups than resident slots (a second partial wave of persistent workgroups doubles the
+    // kernel time); nranges * ntn must be a multiple of 8 for the XCD-major logical id
     int nranges = (256 * bpc) / (ntn * g.groups);
     if (nranges > ntm) nranges = ntm;
-    if (nranges < 8) nranges = ntm < 8 ? ntm : 8;
-    nranges = (nranges + 7) / 8 * 8;
+    if (nranges < 1) nranges = 1;
+    while (nranges > 1 && (nranges * ntn) % 8 != 0) --nranges;
+    if ((nranges * ntn) % 8 != 0) nranges = 8;
     dim3 grid(nranges * ntn, g.groups);
     if (BNv == 64) hipLaunchKernelGGL((gemm_nn_kernel<T, ALD, EPI, 64>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_nn_kernel<T, ALD, EPI, 128>), grid, dim3(256), 0, s, g);

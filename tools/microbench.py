@@ -214,6 +214,14 @@ if __name__ == "__main__":
         dwt_bwd(32, 32, 5 * 8, 1792)
     if "dwtb1" in which:
         dwt_bwd(32, 32, 18 * 32, 448)
+    if "nndeep" in which:
+        gemm_nn(589824, 896, 128, "plain", True)
+        gemm_nn(589824, 896, 128, "plain", False)
+        gemm_nn(147456, 1792, 256, "plain", True)
+        gemm_nn(147456, 896, 128, "plain", True)
+        gemm_nn(589824, 448, 64, "plain", True)
+        gemm_nn(589824, 128, 896, "plain", True)
+        gemm_nn(147456, 256, 1792, "plain", True)
     if "nn1" in which:
         gemm_nn(2359296, 448, 64, "plain", True)
     if "nn2" in which:
