@@ -631,7 +631,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN g) {
 }
 
 template <typename T, int PLD, int QLD>
-static int launch_tn_t(const GemmTN& g, hipStream_t s) {
+static int launch_tn_t(const GemmTN& g_in, hipStream_t s) {
+    GemmTN g = g_in;
+    if (g.nsplit <= 0) {
+        // one resident round: tiles x splits = the workgroups the chip holds at once (a partial second round costs a
+        // whole workgroup duration, and every split adds 64 KB of fp32 atomics per tile)
+        int bpc = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, gemm_tn_kernel<T, PLD, QLD>, 256, 0) != hipSuccess || bpc < 1) {
+            (void)hipGetLastError();
+            bpc = 1;
+        }
+        const int tiles = ((g.R + 127) / 128) * ((g.Cc + 127) / 128) * g.groups;
+        int want = (256 * bpc) / tiles;
+        const int maxsplit = (int)((g.M + 511) / 512);
+        if (want > maxsplit) want = maxsplit;
+        if (want < 1) want = 1;
+        i64 rows = (g.M + want - 1) / want;
+        rows = (rows + 63) / 64 * 64;
+        g.rows_per_split = (int)rows;
+        g.nsplit = (int)((g.M + rows - 1) / rows);
+    }
     dim3 grid(((g.R + 127) / 128) * ((g.Cc + 127) / 128), g.nsplit, g.groups);
     hipLaunchKernelGGL((gemm_tn_kernel<T, PLD, QLD>), grid, dim3(256), 0, s, g);
     DWN_CHECK_LAUNCH();
@@ -654,17 +673,6 @@ static int launch_tn_d(const GemmTN& g, hipStream_t s) {
 
 int launch_gemm_tn(const GemmTN& g_in, int dtype, hipStream_t s) {
     if (g_in.M <= 0 || g_in.R <= 0 || g_in.Cc <= 0) return 0;
-    GemmTN g = g_in;
-    if (g.nsplit <= 0) {
-        int tiles = ((g.R + 127) / 128) * ((g.Cc + 127) / 128) * g.groups;
-        int want = (1024 + tiles - 1) / tiles;
-        int maxsplit = (g.M + 511) / 512;
-        if (want > maxsplit) want = maxsplit;
-        if (want < 1) want = 1;
-        int rows = (g.M + want - 1) / want;
-        rows = (rows + 63) / 64 * 64;
-        g.rows_per_split = rows;
-        g.nsplit = (g.M + rows - 1) / rows;
-    }
+    const GemmTN& g = g_in;
     return dtype == DWN_BF16 ? launch_tn_d<bf16_t>(g, s) : launch_tn_d<float>(g, s);
 }
