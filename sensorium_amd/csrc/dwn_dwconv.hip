@@ -103,6 +103,7 @@ __global__ __launch_bounds__(NT, 4) void dw_spatial_fwd_kernel(const DwSpatialFw
     float st0[4] = {0.f, 0.f, 0.f, 0.f}, st1[4] = {0.f, 0.f, 0.f, 0.f};
 
     const int Wp = a.Win + 2 * P;
+    const FastDiv dvp(Wp), dvo(a.Wout);
     const int nbands = (a.Hout + a.rows_band - 1) / a.rows_band;
     const int ntiles = a.planes * nbands;
     const T* inp = reinterpret_cast<const T*>(a.in.p);
@@ -117,6 +118,8 @@ __global__ __launch_bounds__(NT, 4) void dw_spatial_fwd_kernel(const DwSpatialFw
         const i64 plane_row0 = (i64)plane * a.Hin * a.Win;
         // stage the activated input rows (zero padded).  The (row, x) walk is flat and NB loads are issued before
         // the first one is consumed: a row-by-row loop would serialise one HBM round trip per input row.
+        const int total_st = rows_in * Wp;                  // flat (row, column) walk: flat index == tile index
+        const T* in0 = inp + plane_row0 * a.in.ld;
         if constexpr (TT<T>::IS_BF16) {
             // bf16: stage 8 channels (16 B) per thread — halves the per-vector address/predicate/LDS-store overhead of
             // this VALU-bound pass; the tile keeps the [pixel][64 ch] layout the 4-channel compute lanes read
@@ -125,62 +128,66 @@ __global__ __launch_bounds__(NT, 4) void dw_spatial_fwd_kernel(const DwSpatialFw
             const int sch = c0 + scv * 8;
             const bool sch_ok = sch < a.C;                        // C % 8 == 0: a vector is all-valid or all-invalid
             const int schs = sch_ok ? sch : 0;
-            float s8[8], t8[8];
-            ldc4(a.in.v1 + schs, s8); ldc4(a.in.v1 + schs + 4, s8 + 4);
-            ldc4(a.in.v2 + schs, t8); ldc4(a.in.v2 + schs + 4, t8 + 4);
+            f2_t s8[4], t8[4];
+            {
+                float sf[8], tf[8];
+                ldc4(a.in.v1 + schs, sf); ldc4(a.in.v1 + schs + 4, sf + 4);
+                ldc4(a.in.v2 + schs, tf); ldc4(a.in.v2 + schs + 4, tf + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { s8[i] = f2_t{sf[2 * i], sf[2 * i + 1]}; t8[i] = f2_t{tf[2 * i], tf[2 * i + 1]}; }
+            }
             uint4* tile16 = reinterpret_cast<uint4*>(dyn_smem);
-            int r = 0, x = spl;
-            while (x >= Wp) { x -= Wp; ++r; }
-            while (r < rows_in) {
+            for (int f0 = spl; f0 < total_st; f0 += NB * LPS) {
                 uint4 raw[NB];
-                int rr[NB], xx[NB];
+                bool okv[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    rr[u] = r; xx[u] = x;
-                    const int hi = hi0 + r, wi = x - P;
-                    const bool ok = sch_ok && r < rows_in && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
-                    raw[u] = *reinterpret_cast<const uint4*>(inp + (plane_row0 + (ok ? (i64)hi * a.Win + wi : 0)) * a.in.ld + schs);
-                    x += LPS;
-                    while (x >= Wp) { x -= Wp; ++r; }
+                    const int f = f0 + u * LPS;
+                    const int r = dvp.div(f);
+                    const int hi = hi0 + r, wi = dvp.rem(f, r) - P;
+                    okv[u] = sch_ok && f < total_st && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
+                    const unsigned off = okv[u] ? __umul24(__mul24(hi, a.Win) + wi, (unsigned)a.in.ld) : 0u;
+                    raw[u] = *reinterpret_cast<const uint4*>(in0 + off + schs);
                 }
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    if (rr[u] < rows_in) {
-                        const int hi = hi0 + rr[u], wi = xx[u] - P;
-                        const bool ok = sch_ok && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
-                        float v[8];
-                        unpack16<T>(raw[u], v);
+                    const int f = f0 + u * LPS;
+                    if (f < total_st) {
+                        const unsigned rw[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+                        unsigned o[4];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) v[i] = siluf_(fmaf(v[i], s8[i], t8[i]));
-                        tile16[(rr[u] * Wp + xx[u]) * SV + scv] = ok ? pack16<T>(v) : make_uint4(0, 0, 0, 0);
+                        for (int i = 0; i < 4; ++i) {
+                            const f2_t y = f2_t{__uint_as_float(rw[i] << 16), __uint_as_float(rw[i] & 0xffff0000u)};
+                            const f2_t h = y * s8[i] + t8[i];
+                            const f2_t z = h * f2_t{sigmoidf_(h.x), sigmoidf_(h.y)};
+                            o[i] = (uint32_t)f2bf(z.x) | ((uint32_t)f2bf(z.y) << 16);
+                        }
+                        tile16[f * SV + scv] = okv[u] ? make_uint4(o[0], o[1], o[2], o[3]) : make_uint4(0, 0, 0, 0);
                     }
                 }
             }
         } else {
             constexpr int NB = 12;
-            int r = 0, x = pl;
-            while (x >= Wp) { x -= Wp; ++r; }
-            while (r < rows_in) {
+            for (int f0 = pl; f0 < total_st; f0 += NB * LP) {
                 raw_t raw[NB];
-                int rr[NB], xx[NB];
+                bool okv[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    rr[u] = r; xx[u] = x;
-                    const int hi = hi0 + r, wi = x - P;
-                    const bool ok = chan_ok && r < rows_in && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
-                    raw[u] = ld4_raw<T>(inp + (plane_row0 + (ok ? (i64)hi * a.Win + wi : 0)) * a.in.ld + chs);
-                    x += LP;
-                    while (x >= Wp) { x -= Wp; ++r; }
+                    const int f = f0 + u * LP;
+                    const int r = dvp.div(f);
+                    const int hi = hi0 + r, wi = dvp.rem(f, r) - P;
+                    okv[u] = chan_ok && f < total_st && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
+                    const unsigned off = okv[u] ? __umul24(__mul24(hi, a.Win) + wi, (unsigned)a.in.ld) : 0u;
+                    raw[u] = ld4_raw<T>(in0 + off + chs);
                 }
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    if (rr[u] < rows_in) {
-                        const int hi = hi0 + rr[u], wi = xx[u] - P;
-                        const bool ok = chan_ok && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
+                    const int f = f0 + u * LP;
+                    if (f < total_st) {
                         float v[4];
                         V4<T>::unpack(raw[u], v);
                         bn_silu4(v, bs, bt);
-                        tile[(rr[u] * Wp + xx[u]) * NCV + cv] = ok ? V4<T>::pack(v) : V4<T>::zero();
+                        tile[f * NCV + cv] = okv[u] ? V4<T>::pack(v) : V4<T>::zero();
                     }
                 }
             }
@@ -189,10 +196,12 @@ __global__ __launch_bounds__(NT, 4) void dw_spatial_fwd_kernel(const DwSpatialFw
         {
             const int total = nro * a.Wout;                 // flat walk: narrow planes still fill every pixel lane
             const i64 orow0 = ((i64)plane * a.Hout + ho0) * a.Wout;
+            T* out0 = outp + orow0 * a.C + chan;
+            const int wdiff = stride * Wp - stride * a.Wout;   // tile index of output i = (i*stride + oy*wdiff) (+ taps)
             for (int i = pl; i < total; i += LP) {
-                const int oy = i / a.Wout, ox = i - oy * a.Wout;
+                const int oy = dvo.div(i);
                 f2_t acc0 = f2_t{0.f, 0.f}, acc1 = f2_t{0.f, 0.f};
-                const raw_t* tp = tile + ((oy * stride) * Wp + ox * stride) * NCV + cv;
+                const raw_t* tp = tile + (i * stride + __mul24(oy, wdiff)) * NCV + cv;
 #pragma unroll
                 for (int dy = 0; dy < KS; ++dy)
 #pragma unroll
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(NT, 4) void dw_spatial_fwd_kernel(const DwSpatialFw
                 if (chan_ok) {
                     const float acc[4] = {acc0.x, acc0.y, acc1.x, acc1.y};
                     const raw_t packed = V4<T>::pack(acc);
-                    *reinterpret_cast<raw_t*>(outp + (orow0 + i) * a.C + chan) = packed;
+                    *reinterpret_cast<raw_t*>(out0 + __umul24((unsigned)i, (unsigned)a.C)) = packed;
                     float r[4];
                     V4<T>::unpack(packed, r);
 #pragma unroll
@@ -254,6 +263,9 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, 3) void dw_spatial_bwd_kernel(cons
     f2_t sp0[2] = {f2_t{0.f, 0.f}, f2_t{0.f, 0.f}}, sp1[2] = {f2_t{0.f, 0.f}, f2_t{0.f, 0.f}};
 
     const int Wq = a.Wout + 2;                      // staged columns wo = -1 .. Wout
+    const FastDiv dvq(Wq), dvw(a.Win);
+    const f2_t a1v[2] = {f2_t{a1[0], a1[1]}, f2_t{a1[2], a1[3]}}, a2v[2] = {f2_t{a2[0], a2[1]}, f2_t{a2[2], a2[3]}};
+    const f2_t a3v[2] = {f2_t{a3[0], a3[1]}, f2_t{a3[2], a3[3]}};
     const int nbands = (a.Hin + a.rows_band - 1) / a.rows_band;
     const int ntiles = a.planes * nbands;
     const int s = ST > 0 ? ST : a.stride;
@@ -272,36 +284,37 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, 3) void dw_spatial_bwd_kernel(cons
         const int ho_hi = (hi0 + nri - 1 + P) / s;
         const int rows_q = ho_hi - ho_lo + 1;
         const i64 orow0 = (i64)plane * a.Hout * a.Wout;
-        // stage dL/dy2 = A1*dh2 + A2*y2 + A3 (BatchNorm backward) with zero padding; flat walk, 2*NB loads in flight
+        // stage dL/dy2 = A1*dh2 + A2*y2 + A3 (BatchNorm backward) with zero padding; flat walk over the (row, column)
+        // entries of the tile (flat index == tile index), 2*NB loads in flight per thread
         {
             constexpr int NB = 8;
-            int r = 0, x = pl;
-            while (x >= Wq) { x -= Wq; ++r; }
-            while (r < rows_q) {
+            const int total_st = rows_q * Wq;
+            const T* dp0 = dpp + orow0 * a.dy.ld + chs;
+            const T* dq0 = dqp + orow0 * a.dy.ld + chs;
+            for (int f0 = pl; f0 < total_st; f0 += NB * LP) {
                 raw_t rp[NB], rq[NB];
-                int rr[NB], xx[NB];
+                bool okv[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    rr[u] = r; xx[u] = x;
-                    const int ho = ho_lo + r, wo = x - 1;
-                    const bool ok = chan_ok && r < rows_q && ho >= 0 && ho < a.Hout && wo >= 0 && wo < a.Wout;
-                    const i64 off = (orow0 + (ok ? (i64)ho * a.Wout + wo : 0)) * a.dy.ld + chs;
-                    rp[u] = ld4_raw<T>(dpp + off);
-                    rq[u] = ld4_raw<T>(dqp + off);
-                    x += LP;
-                    while (x >= Wq) { x -= Wq; ++r; }
+                    const int f = f0 + u * LP;
+                    const int r = dvq.div(f);
+                    const int ho = ho_lo + r, wo = dvq.rem(f, r) - 1;
+                    okv[u] = chan_ok && f < total_st && (unsigned)ho < (unsigned)a.Hout && (unsigned)wo < (unsigned)a.Wout;
+                    const unsigned off = okv[u] ? __umul24(__mul24(ho, a.Wout) + wo, (unsigned)a.dy.ld) : 0u;
+                    rp[u] = ld4_raw<T>(dp0 + off);
+                    rq[u] = ld4_raw<T>(dq0 + off);
                 }
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    if (rr[u] < rows_q) {
-                        const int ho = ho_lo + rr[u], wo = xx[u] - 1;
-                        const bool ok = chan_ok && ho >= 0 && ho < a.Hout && wo >= 0 && wo < a.Wout;
-                        float p[4], q[4];
-                        V4<T>::unpack(rp[u], p);
-                        V4<T>::unpack(rq[u], q);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) p[i] = fmaf(a1[i], p[i], fmaf(a2[i], q[i], a3[i]));
-                        tile[(rr[u] * Wq + xx[u]) * NCV + cv] = ok ? V4<T>::pack(p) : V4<T>::zero();
+                    const int f = f0 + u * LP;
+                    if (f < total_st) {
+                        f2_t p0, p1, q0, q1;
+                        unpack_pairs<T>(rp[u], p0, p1);
+                        unpack_pairs<T>(rq[u], q0, q1);
+                        p0 = a1v[0] * p0 + (a2v[0] * q0 + a3v[0]);
+                        p1 = a1v[1] * p1 + (a2v[1] * q1 + a3v[1]);
+                        const float p[4] = {p0.x, p0.y, p1.x, p1.y};
+                        tile[f * NCV + cv] = okv[u] ? V4<T>::pack(p) : V4<T>::zero();
                     }
                 }
             }
@@ -310,26 +323,35 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, 3) void dw_spatial_bwd_kernel(cons
         {
             const i64 prow0 = (i64)plane * a.Hin * a.Win;
             // one tap: g = dL/dy2 at (ho, wo) from the LDS tile; dz += w*g; dW[tap] += z1*g   (channel pairs)
-            auto tap = [&](const int k, const int ho, const int wo, const f2_t* z1, f2_t* dz) {
+            auto tap_at = [&](const int k, const raw_t* tp, const f2_t* z1, f2_t* dz) {
                 f2_t g0, g1;
-                unpack_pairs<T>(tile[((ho - ho_lo) * Wq + wo + 1) * NCV + cv], g0, g1);
+                unpack_pairs<T>(*tp, g0, g1);
                 const float4 wv = *reinterpret_cast<const float4*>(&lw[k * CS + cv * 4]);
                 dz[0] += f2_t{wv.x, wv.y} * g0;
                 dz[1] += f2_t{wv.z, wv.w} * g1;
                 dwp[k][0] += z1[0] * g0;
                 dwp[k][1] += z1[1] * g1;
             };
+            auto tap = [&](const int k, const int ho, const int wo, const f2_t* z1, f2_t* dz) {
+                tap_at(k, tile + ((ho - ho_lo) * Wq + wo + 1) * NCV + cv, z1, dz);
+            };
             // everything after the taps: dh1 = dz * silu'(h1), store, BN-backward sums
-            auto finish = [&](const int hi, const int wi, const f2_t* y, const f2_t* dsl, const f2_t* dz) {
+            // per-plane base pointers + 32-bit in-plane offsets (24-bit multiplies): no 64-bit VALU address math
+            T* dh0 = dhp + prow0 * a.C + chan;
+            const T* y10 = y1p + prow0 * a.y1.ld + chs;
+            auto finish_at = [&](const int pix, const f2_t* y, const f2_t* dsl, const f2_t* dz) {
                 const f2_t d0 = dz[0] * dsl[0], d1 = dz[1] * dsl[1];
                 float dh[4] = {d0.x, d0.y, d1.x, d1.y};
                 const typename V4<T>::raw_t packed = V4<T>::pack(dh);
-                *reinterpret_cast<typename V4<T>::raw_t*>(dhp + (prow0 + (i64)hi * a.Win + wi) * a.C + chan) = packed;
+                *reinterpret_cast<typename V4<T>::raw_t*>(dh0 + __umul24((unsigned)pix, (unsigned)a.C)) = packed;
                 f2_t r0, r1;
                 unpack_pairs<T>(packed, r0, r1);              // statistics of the values as stored
                 sp0[0] += r0; sp0[1] += r1;
                 sp1[0] += r0 * (y[0] * bi2[0] + nbm2[0]);
                 sp1[1] += r1 * (y[1] * bi2[1] + nbm2[1]);
+            };
+            auto finish = [&](const int hi, const int wi, const f2_t* y, const f2_t* dsl, const f2_t* dz) {
+                finish_at(hi * a.Win + wi, y, dsl, dz);
             };
             auto activate = [&](const raw_t& raw, f2_t* y, f2_t* z1, f2_t* dsl) {
                 unpack_pairs<T>(raw, y[0], y[1]);
@@ -352,35 +374,46 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, 3) void dw_spatial_bwd_kernel(cons
                     const int nr = (hi0 + nri - hfirst + 1) >> 1;
                     const int nc = (a.Win - PX + 1) >> 1;
                     const int total = nr > 0 ? nr * nc : 0;
+                    // pixel (k, j) of the class: hi = hfirst + 2k, wi = PX + 2j.  Its taps read tile entries at
+                    // workgroup-uniform offsets from entry (k, j): one index per pixel, uniform offsets per tap.
+                    const int wdiff = Wq - nc;
+                    const FastDiv dvc(nc > 0 ? nc : 1);
+                    const int r_dn = ((hfirst + HP) >> 1) - ho_lo;          // row of (hi + HP) >> 1 at k = 0
+                    const int o00 = (r_dn * Wq + 1) * NCV;                  // (hi+HP)>>1, (wi-PX)>>1 ... column j
+                    const int o01 = o00 + NCV;                              // column j + 1
+                    const int o10 = o00 - Wq * NCV, o11 = o01 - Wq * NCV;   // row (hi-1)>>1 (odd rows only)
                     for (int i0 = pl; i0 < total; i0 += XB * LP) {
                         raw_t ry[XB];
-                        int hh[XB], ww[XB];
+                        int ti[XB];
+                        int gg[XB];
 #pragma unroll
                         for (int u = 0; u < XB; ++u) {
                             const int i = i0 + u * LP;
                             const bool ok = chan_ok && i < total;
-                            const int k = ok ? i / nc : 0;
-                            hh[u] = hfirst + 2 * k;
-                            ww[u] = PX + 2 * ((ok ? i : 0) - k * nc);
-                            ry[u] = ld4_raw<T>(y1p + (ok ? prow0 + (i64)hh[u] * a.Win + ww[u] : 0) * a.y1.ld + chs);
+                            const int iv = ok ? i : 0;
+                            const int k = dvc.div(iv);
+                            const int j = dvc.rem(iv, k);
+                            ti[u] = (iv + __mul24(k, wdiff)) * NCV + cv;
+                            gg[u] = __mul24(hfirst + 2 * k, a.Win) + (PX + 2 * j);
+                            ry[u] = ld4_raw<T>(y10 + __umul24((unsigned)gg[u], (unsigned)a.y1.ld));
                         }
 #pragma unroll
                         for (int u = 0; u < XB; ++u) {
                             if (!chan_ok || i0 + u * LP >= total) continue;
-                            const int hi = hh[u], wi = ww[u];
                             f2_t y[2], z1[2], dsl[2], dz[2] = {f2_t{0.f, 0.f}, f2_t{0.f, 0.f}};
                             activate(ry[u], y, z1, dsl);
+                            const raw_t* tp = tile + ti[u];
                             if constexpr (HP == 0 && PX == 0) {
-                                tap(4, hi >> 1, wi >> 1, z1, dz);
+                                tap_at(4, tp + o00, z1, dz);
                             } else if constexpr (HP == 0 && PX == 1) {
-                                tap(3, hi >> 1, (wi + 1) >> 1, z1, dz); tap(5, hi >> 1, (wi - 1) >> 1, z1, dz);
+                                tap_at(3, tp + o01, z1, dz); tap_at(5, tp + o00, z1, dz);
                             } else if constexpr (HP == 1 && PX == 0) {
-                                tap(1, (hi + 1) >> 1, wi >> 1, z1, dz); tap(7, (hi - 1) >> 1, wi >> 1, z1, dz);
+                                tap_at(1, tp + o00, z1, dz); tap_at(7, tp + o10, z1, dz);
                             } else {
-                                tap(0, (hi + 1) >> 1, (wi + 1) >> 1, z1, dz); tap(2, (hi + 1) >> 1, (wi - 1) >> 1, z1, dz);
-                                tap(6, (hi - 1) >> 1, (wi + 1) >> 1, z1, dz); tap(8, (hi - 1) >> 1, (wi - 1) >> 1, z1, dz);
+                                tap_at(0, tp + o01, z1, dz); tap_at(2, tp + o00, z1, dz);
+                                tap_at(6, tp + o11, z1, dz); tap_at(8, tp + o10, z1, dz);
                             }
-                            finish(hi, wi, y, dsl, dz);
+                            finish_at(gg[u], y, dsl, dz);
                         }
                     }
                 };
@@ -390,6 +423,40 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, 3) void dw_spatial_bwd_kernel(cons
                 run_class(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
             } else {
                 const int total = nri * a.Win;
+                if constexpr (ST == 1) {
+                    // stride 1: every tap is valid (the zero halo supplies the borders): branch-free.  The tile entry of
+                    // tap (dy, dx) sits at a fixed offset from the pixel's own entry: one index per pixel, not per tap.
+                    const int wdiff = Wq - a.Win;                // staged row is wider than the input row
+                    const int rowstep = Wq * NCV;
+                    const int grow0 = hi0 * a.Win;
+                    for (int i0 = pl; i0 < total; i0 += XB * LP) {
+                        raw_t ry[XB];
+                        int ii[XB], ti[XB];
+#pragma unroll
+                        for (int u = 0; u < XB; ++u) {
+                            const int i = i0 + u * LP;
+                            const bool ok = chan_ok && i < total;
+                            ii[u] = ok ? i : 0;
+                            const int iy = dvw.div(ii[u]);
+                            ti[u] = (ii[u] + __mul24(iy, wdiff) + (P + 2 - KS)) * NCV + cv;
+                            ry[u] = ld4_raw<T>(y10 + __umul24((unsigned)(grow0 + ii[u]), (unsigned)a.y1.ld));
+                        }
+#pragma unroll
+                        for (int u = 0; u < XB; ++u) {
+                            if (!chan_ok || i0 + u * LP >= total) continue;
+                            f2_t y[2], z1[2], dsl[2], dz[2] = {f2_t{0.f, 0.f}, f2_t{0.f, 0.f}};
+                            activate(ry[u], y, z1, dsl);
+                            const raw_t* tp = tile + ti[u];
+#pragma unroll
+                            for (int dy = 0; dy < KS; ++dy) {
+                                const raw_t* tr = tp + (KS - 1 - dy) * rowstep;
+#pragma unroll
+                                for (int dx = 0; dx < KS; ++dx) tap_at(dy * KS + dx, tr + (KS - 1 - dx) * NCV, z1, dz);
+                            }
+                            finish_at(grow0 + ii[u], y, dsl, dz);
+                        }
+                    }
+                } else {
                 for (int i0 = pl; i0 < total; i0 += XB * LP) {
                     raw_t ry[XB];
                     int hh[XB], ww[XB];
@@ -400,7 +467,7 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, 3) void dw_spatial_bwd_kernel(cons
                         const int iy = ok ? i / a.Win : 0;
                         hh[u] = hi0 + iy;
                         ww[u] = (ok ? i : 0) - iy * a.Win;
-                        ry[u] = ld4_raw<T>(y1p + (ok ? prow0 + (i64)hh[u] * a.Win + ww[u] : 0) * a.y1.ld + chs);
+                        ry[u] = ld4_raw<T>(y10 + (ok ? (i64)hh[u] * a.Win + ww[u] : 0) * a.y1.ld);
                     }
 #pragma unroll
                     for (int u = 0; u < XB; ++u) {
@@ -408,31 +475,24 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, 3) void dw_spatial_bwd_kernel(cons
                         const int hi = hh[u], wi = ww[u];
                         f2_t y[2], z1[2], dsl[2], dz[2] = {f2_t{0.f, 0.f}, f2_t{0.f, 0.f}};
                         activate(ry[u], y, z1, dsl);
-                        if constexpr (ST == 1) {
-                            // stride 1: every tap is valid (the zero halo supplies the borders): branch-free
 #pragma unroll
-                            for (int dy = 0; dy < KS; ++dy)
+                        for (int dy = 0; dy < KS; ++dy) {
+                            const int nh = hi + P - dy;
+                            if (nh < 0 || nh % s != 0) continue;
+                            const int ho = nh / s;
+                            if (ho > ho_hi) continue;
 #pragma unroll
-                                for (int dx = 0; dx < KS; ++dx) tap(dy * KS + dx, hi + P - dy, wi + P - dx, z1, dz);
-                        } else {
-#pragma unroll
-                            for (int dy = 0; dy < KS; ++dy) {
-                                const int nh = hi + P - dy;
-                                if (nh < 0 || nh % s != 0) continue;
-                                const int ho = nh / s;
-                                if (ho > ho_hi) continue;
-#pragma unroll
-                                for (int dx = 0; dx < KS; ++dx) {
-                                    const int nw = wi + P - dx;
-                                    if (nw < 0 || nw % s != 0) continue;
-                                    const int wo = nw / s;
-                                    if (wo > a.Wout) continue;
-                                    tap(dy * KS + dx, ho, wo, z1, dz);
-                                }
+                            for (int dx = 0; dx < KS; ++dx) {
+                                const int nw = wi + P - dx;
+                                if (nw < 0 || nw % s != 0) continue;
+                                const int wo = nw / s;
+                                if (wo > a.Wout) continue;
+                                tap(dy * KS + dx, ho, wo, z1, dz);
                             }
                         }
                         finish(hi, wi, y, dsl, dz);
                     }
+                }
                 }
             }
         }
