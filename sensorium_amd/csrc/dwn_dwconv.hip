@@ -21,6 +21,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
 #define DWS_THREADS 512      // threads per workgroup of the spatial forward kernel (more waves per LDS tile)
 #endif
 #define DWS_BWD_THREADS 256
+#ifndef DWS_BWD_MINB1
+#define DWS_BWD_MINB1 3          // resident workgroups per CU the stride-1 spatial backward is compiled for
+#endif
 #ifndef DWT_BWD_TB
 #define DWT_BWD_TB 4          // timesteps of loads in flight per thread in the temporal backward (4 or 8)
 #endif
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(NT, 4) void dw_spatial_fwd_kernel(const DwSpatialFw
 // spatial backward: dh1 = (dwS^T dy2) * silu'(h1), dW, Σdh1, Σdh1·ŷ1
 // ------------------------------------------------------------------------------------------------
 template <typename T, int KS, int ST>
-__global__ __launch_bounds__(DWS_BWD_THREADS, 3) void dw_spatial_bwd_kernel(const DwSpatialBwd a) {
+__global__ __launch_bounds__(DWS_BWD_THREADS, (ST == 1 ? DWS_BWD_MINB1 : 3)) void dw_spatial_bwd_kernel(const DwSpatialBwd a) {
     constexpr int NT = DWS_BWD_THREADS;
     constexpr int NCV = SL<T>::NCV, CS = SL<T>::CS, LP = NT / NCV, P = KS / 2;
     constexpr int XB = 4;
@@ -254,9 +257,8 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, 3) void dw_spatial_bwd_kernel(cons
     f2_t dwp[KS * KS][2];
 #pragma unroll
     for (int k = 0; k < KS * KS; ++k) { dwp[k][0] = f2_t{0.f, 0.f}; dwp[k][1] = f2_t{0.f, 0.f}; }
-    float bs[4], bt[4], bm[4], bi[4], a1[4], a2[4], a3[4];
+    float bs[4], bt[4], bm[4], bi[4];
     ldc4(a.y1.v1 + chs, bs); ldc4(a.y1.v2 + chs, bt); ldc4(a.y1.v3 + chs, bm); ldc4(a.y1.v4 + chs, bi);
-    ldc4(a.dy.v1 + chs, a1); ldc4(a.dy.v2 + chs, a2); ldc4(a.dy.v3 + chs, a3);
     const f2_t bs2[2] = {f2_t{bs[0], bs[1]}, f2_t{bs[2], bs[3]}}, bt2[2] = {f2_t{bt[0], bt[1]}, f2_t{bt[2], bt[3]}};
     const f2_t bi2[2] = {f2_t{bi[0], bi[1]}, f2_t{bi[2], bi[3]}};
     const f2_t nbm2[2] = {f2_t{-bm[0] * bi[0], -bm[1] * bi[1]}, f2_t{-bm[2] * bi[2], -bm[3] * bi[3]}};   // yhat = y*bi + nbm
@@ -264,8 +266,6 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, 3) void dw_spatial_bwd_kernel(cons
 
     const int Wq = a.Wout + 2;                      // staged columns wo = -1 .. Wout
     const FastDiv dvq(Wq), dvw(a.Win);
-    const f2_t a1v[2] = {f2_t{a1[0], a1[1]}, f2_t{a1[2], a1[3]}}, a2v[2] = {f2_t{a2[0], a2[1]}, f2_t{a2[2], a2[3]}};
-    const f2_t a3v[2] = {f2_t{a3[0], a3[1]}, f2_t{a3[2], a3[3]}};
     const int nbands = (a.Hin + a.rows_band - 1) / a.rows_band;
     const int ntiles = a.planes * nbands;
     const int s = ST > 0 ? ST : a.stride;
@@ -289,6 +289,11 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, 3) void dw_spatial_bwd_kernel(cons
         {
             constexpr int NB = 8;
             const int total_st = rows_q * Wq;
+            // BN-backward coefficients: (re)loaded per tile so they do not occupy registers during the tap phase
+            float a1[4], a2[4], a3[4];
+            ldc4(a.dy.v1 + chs, a1); ldc4(a.dy.v2 + chs, a2); ldc4(a.dy.v3 + chs, a3);
+            const f2_t a1v[2] = {f2_t{a1[0], a1[1]}, f2_t{a1[2], a1[3]}}, a2v[2] = {f2_t{a2[0], a2[1]}, f2_t{a2[2], a2[3]}};
+            const f2_t a3v[2] = {f2_t{a3[0], a3[1]}, f2_t{a3[2], a3[3]}};
             const T* dp0 = dpp + orow0 * a.dy.ld + chs;
             const T* dq0 = dqp + orow0 * a.dy.ld + chs;
             for (int f0 = pl; f0 < total_st; f0 += NB * LP) {

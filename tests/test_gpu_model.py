@@ -67,7 +67,11 @@ def test_tiny_model_train_step_matches_reference(golden_dir, dtype):
         assert rel(preds[m], torch.from_numpy(z[f"pred_{m}"])) < ft
     ref_loss = float(z["loss"])
     scale = sum(float(np.abs(z[f"pred_{m}"]).sum()) for m in range(2)) / preds[0].shape[0]
-    assert abs(float(loss.detach()) - ref_loss) <= ft * max(abs(ref_loss), 1e-3 * scale), (float(loss.detach()), ref_loss)
+    # the Poisson loss is a cancelling sum (pred - target*log(pred)): its error scales with sum|pred| per sample, not
+    # with the net value; fp32 is held to 1e-3 of that sum, bf16 (whose BN statistics see fp32-atomic ordering noise
+    # amplified by 8-bit mantissas) to 1e-2 of it
+    floor = (1e-3 if dtype == torch.float32 else 1e-2) * scale
+    assert abs(float(loss.detach()) - ref_loss) <= ft * max(abs(ref_loss), floor), (float(loss.detach()), ref_loss)
     grads = {k[5:]: z[k] for k in z.files if k.startswith("grad:")}
     gnorm = math.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values()))
     named = dict(model.named_parameters())
