@@ -13,6 +13,7 @@
 // mode, bit-exact fp32 FMA chain).  Operand maps (cdna_hip_programming.md §3): lane l holds
 // A[row l&15][k = 8*(l>>4)+j], B[k = 8*(l>>4)+j][col l&15]; C/D: col = l&15, row = 4*(l>>4)+reg.
 #include "dwn_internal.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -58,7 +59,7 @@ __device__ __forceinline__ uint4 load_op_packed(const LoadDesc& d, i64 row, int 
 //     flushed once per workgroup — per-tile global atomics on the same few hundred addresses serialise at
 //     the memory side (MI355X_MICROARCH.md § Global float atomics, "contention").
 // ------------------------------------------------------------------------------------------------
-template <typename T, int ALD, int EPI, int BN>
+template <typename T, int ALD, int EPI, int BN, bool SINGLE>
 __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     constexpr int KC = TT<T>::KC;
     constexpr int BM = 128;
@@ -102,9 +103,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     const int acol0 = grp * g.K;
     const T* Bp = reinterpret_cast<const T*>(g.b) + (i64)grp * g.N * g.ldb;
     const int ccol0 = grp * g.N;
-    const bool single = g.K <= BK;
+    // SINGLE (K <= one k-tile) is a separate instantiation: sharing one loop nest between the resident-B and the
+    // k-loop variants made the compiler merge their s_waitcnt scoreboards and drain every prefetch early
+    constexpr bool single = SINGLE;
 
-    uint4 ra[A_CH], rb[B_CH];
+    // Staging is split in two (cdna_hip_programming.md "Async-STAGE split"): load_* only ISSUES the global loads into
+    // raw registers; the prologue math, the bounds select and the ds_write happen in store_*, after the MFMAs of the
+    // current tile.  (Selecting / converting inside load_* makes the compiler wait for the data before the MFMAs.)
+    uint4 rp[A_CH], rq[A_CH], rb[B_CH];
+    int ld_m0 = 0, ld_k0 = 0, ldb_k0 = 0;
     // A staging: this thread's 16-byte column chunk (kc = tid & 7) is the same for its A_CH rows, so the
     // per-channel prologue coefficients are loaded once per k-tile, not once per chunk
     ColCoef<ALD == LD_PE ? LD_PLAIN : ALD, T> cf;
@@ -112,6 +119,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     const T* Ap = reinterpret_cast<const T*>(g.a.p);
     const T* Aq = reinterpret_cast<const T*>(g.a.q);
     auto load_a = [&](int m0, int k0) {
+        ld_m0 = m0; ld_k0 = k0;
         const int kc = tid & 7;
         const int k = k0 + kc * KC;
         const bool kok = k < g.K;
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
                 int m = m0 + (tid >> 3) + 32 * i;
-                ra[i] = (m < g.M && kok) ? load_op_packed<LD_PE, T>(g.a, (i64)m, acol0 + k) : make_uint4(0, 0, 0, 0);
+                rp[i] = (m < g.M && kok) ? load_op_packed<LD_PE, T>(g.a, (i64)m, acol0 + k) : make_uint4(0, 0, 0, 0);
             }
         } else if (EPI == EPI_STORE_CAT && k >= g.K1) {
             // K-concatenated second operand (plain): A[m][k] = a2[m][k - K1]
@@ -127,12 +135,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
                 int m = m0 + (tid >> 3) + 32 * i;
-                ra[i] = (m < g.M && kok) ? *reinterpret_cast<const uint4*>(A2p + (i64)m * g.a2_ld + (k - g.K1))
-                                         : make_uint4(0, 0, 0, 0);
+                const bool ok = m < g.M && kok;
+                rp[i] = *reinterpret_cast<const uint4*>(A2p + (ok ? (i64)m * g.a2_ld + (k - g.K1) : 0));
             }
         } else {
             if (kok && k != cf_k) { cf.load(g.a, acol0 + k); cf_k = k; }
-            uint4 rp[A_CH], rq[A_CH];
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
                 int m = m0 + (tid >> 3) + 32 * i;
@@ -140,31 +147,37 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                 const i64 off = ok ? (i64)m * g.a.ld + acol0 + k : 0;
                 rp[i] = *reinterpret_cast<const uint4*>(Ap + off);
                 if constexpr (decltype(cf)::two_tensors) rq[i] = *reinterpret_cast<const uint4*>(Aq + off);
-                else rq[i] = make_uint4(0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < A_CH; ++i) {
-                int m = m0 + (tid >> 3) + 32 * i;
-                ra[i] = (m < g.M && kok) ? cf.apply(g.a, (unsigned)m, rp[i], rq[i]) : make_uint4(0, 0, 0, 0);
             }
         }
     };
     auto load_b = [&](int k0) {
+        ldb_k0 = k0;
 #pragma unroll
         for (int i = 0; i < B_CH; ++i) {
             int c = tid + 256 * i;
             int row = c >> 3, kc = c & 7;
             int n = n0 + row, k = k0 + kc * KC;
-            if (n < g.N && k < g.K) rb[i] = *reinterpret_cast<const uint4*>(Bp + (i64)n * g.ldb + k);
-            else rb[i] = make_uint4(0, 0, 0, 0);
+            const bool ok = n < g.N && k < g.K;
+            rb[i] = *reinterpret_cast<const uint4*>(Bp + (ok ? (i64)n * g.ldb + k : 0));
         }
     };
     auto store_a = [&]() {
+        const int kk = ld_k0 + (tid & 7) * KC;
+        const bool kok = kk < g.K;
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
             int c = tid + 256 * i;
             int row = c >> 3, kc = c & 7;
-            *reinterpret_cast<uint4*>(sA + row * ROWB + ((kc ^ (row & 7)) << 4)) = ra[i];
+            const int m = ld_m0 + row;
+            const bool ok = m < g.M && kok;
+            uint4 v;
+            if constexpr (ALD == LD_PE) v = rp[i];
+            else if (EPI == EPI_STORE_CAT && kk >= g.K1) v = ok ? rp[i] : make_uint4(0, 0, 0, 0);
+            else {
+                if constexpr (decltype(cf)::two_tensors) v = ok ? cf.apply(g.a, (unsigned)m, rp[i], rq[i]) : make_uint4(0, 0, 0, 0);
+                else v = ok ? cf.apply(g.a, (unsigned)m, rp[i], make_uint4(0, 0, 0, 0)) : make_uint4(0, 0, 0, 0);
+            }
+            *reinterpret_cast<uint4*>(sA + row * ROWB + ((kc ^ (row & 7)) << 4)) = v;
         }
     };
     auto store_b = [&]() {
@@ -172,7 +185,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
         for (int i = 0; i < B_CH; ++i) {
             int c = tid + 256 * i;
             int row = c >> 3, kc = c & 7;
-            *reinterpret_cast<uint4*>(sB + row * ROWB + ((kc ^ (row & 7)) << 4)) = rb[i];
+            const bool ok = (n0 + row) < g.N && (ldb_k0 + kc * KC) < g.K;
+            *reinterpret_cast<uint4*>(sB + row * ROWB + ((kc ^ (row & 7)) << 4)) = ok ? rb[i] : make_uint4(0, 0, 0, 0);
         }
     };
 
@@ -207,6 +221,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     // read-back role of this thread: one 16-byte column chunk, rows tid/CPR + k*(256/CPR)
     const int ch = tid % CPR;
     const int ncol = n0 + ch * KC;
+    // a valid chunk of the same row for lanes past N (fast epilogue path): N % KC == 0, n0 < N
+    const int nvalid_ch = (g.N - n0) / KC < CPR ? (g.N - n0) / KC : CPR;
+    const int ch_e = ch < nvalid_ch ? ch : ch % nvalid_ch;
+    const int ncol_e = n0 + ch_e * KC;
     float st0[KC], st1[KC], dgp[KC], s3[KC], t3[KC];
 #pragma unroll
     for (int i = 0; i < KC; ++i) { st0[i] = 0.f; st1[i] = 0.f; dgp[i] = 0.f; s3[i] = 0.f; t3[i] = 0.f; }
@@ -231,21 +249,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
         for (int i = 0; i < KC; ++i) dgp[i] = 0.f;
     };
 
-    if (single) {
+    if constexpr (single) {
         load_b(0);
         store_b();
         load_a(mt_beg * BM, 0);
         store_a();
         __syncthreads();
     }
-    for (int mt = mt_beg; mt < mt_end; ++mt) {
+    // One tile, specialised at compile time on HN (a next tile exists: prefetch its A rows / stage them afterwards;
+    // resident-B variant only) and on `fast` (see the epilogue).  The copies keep every path between the prefetch loads
+    // and their use free of data-dependent branches, so the compiler's s_waitcnt vmcnt(N) counts are exact.
+    auto tile = [&](const int mt, auto hn_c, auto fast_c) {
+        [[maybe_unused]] constexpr bool HN = decltype(hn_c)::value;
         const int m0 = mt * BM;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (single) {
-            if (mt + 1 < mt_end) load_a((mt + 1) * BM, 0);      // in flight under the MFMAs and the epilogue
+        if constexpr (single) {
+            if constexpr (HN) load_a((mt + 1) * BM, 0);         // in flight under the MFMAs and the epilogue
             mma_tile();
         } else {
             load_a(m0, 0);
@@ -293,14 +315,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int prow0 = pass * CROWS;            // first tile row of this pass
                 const int mp = m0 + prow0;
+                // Fast path (every row of the tile valid, and for EPI_DG the pass inside one sample): every global
+                // access below is UNCONDITIONAL — lanes past N redo a valid chunk of the same row (idempotent store,
+                // their sums are never flushed) — so the compiler counts the stores exactly and the s_waitcnt of the
+                // next tile's prefetched A rows (issued before these stores) does not drain them.
+                constexpr bool fast = decltype(fast_c)::value;
                 // EPI_DG: fetch this pass's z3 chunks now so they are in flight across the LDS round trip
                 [[maybe_unused]] uint4 zraw[CROWS * CPR / 256];
                 if constexpr (EPI == EPI_DG) {
+                    if constexpr (fast) {
 #pragma unroll
-                    for (int it = 0; it < CROWS * CPR / 256; ++it) {
-                        const int m = mp + tid / CPR + it * (256 / CPR);
-                        const bool ok = m < g.M && ncol < g.N;
-                        zraw[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(g.y3) + (ok ? (i64)m * g.ldy3 + ncol : 0));
+                        for (int it = 0; it < CROWS * CPR / 256; ++it) {
+                            const int m = mp + tid / CPR + it * (256 / CPR);
+                            zraw[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(g.y3) + (i64)m * g.ldy3 + ncol_e);
+                        }
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < CROWS * CPR / 256; ++it) {
+                            const int m = mp + tid / CPR + it * (256 / CPR);
+                            const bool ok = m < g.M && ncol < g.N;
+                            zraw[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(g.y3) + (ok ? (i64)m * g.ldy3 + ncol : 0));
+                        }
                     }
                 }
                 if (CROWS >= 64 ? (wm == prow0 / 64 || CROWS == 128) : (wm == prow0 / 64)) {
@@ -330,6 +365,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                     }
                 }
                 __syncthreads();
+                if constexpr (fast) {
+#pragma unroll
+                    for (int it = 0; it < CROWS * CPR / 256; ++it) {
+                        const int row = tid / CPR + it * (256 / CPR);
+                        const int m = mp + row;
+                        const uint4 raw = *reinterpret_cast<const uint4*>(sC + row * CROW + ch_e * 16);
+                        *reinterpret_cast<uint4*>(Cp + (i64)m * g.ldc + ccol0 + ncol_e) = raw;
+                        float v[KC];
+                        unpack16<T>(raw, v);
+                        if (g.stats) {
+#pragma unroll
+                            for (int i = 0; i < KC; ++i) { st0[i] += v[i]; st1[i] += v[i] * v[i]; }
+                        }
+                        if constexpr (EPI == EPI_DG) {
+                            float y[KC];
+                            unpack16<T>(zraw[it], y);
+                            if (g.s3) {          // y3 raw: apply bn3 + SiLU here; else `y3` already holds z3
+#pragma unroll
+                                for (int i = 0; i < KC; ++i) y[i] = siluf_(fmaf(y[i], s3[i], t3[i]));
+                            }
+#pragma unroll
+                            for (int i = 0; i < KC; ++i) dgp[i] += v[i] * y[i];
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int it = 0; it < CROWS * CPR / 256; ++it) {
                     const int row = tid / CPR + it * (256 / CPR);
@@ -363,6 +423,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                         }
                     }
                 }
+                }
                 if constexpr (EPI == EPI_DG) {
                     // dgp belongs to sample b_pass; flush when the next pass starts a different sample (uniform)
                     const int b_pass = mp / g.rows_per_sample;
@@ -377,10 +438,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                 }
             }
         }
-        if (single && mt + 1 < mt_end) {
+        if constexpr (single && HN) {
             if constexpr (EPI == EPI_READOUT) __syncthreads();   // no barrier in that epilogue: all waves must be done with sA
             store_a();
             __syncthreads();
+        }
+    };
+    for (int mt = mt_beg; mt < mt_end; ++mt) {
+        const int m0_ = mt * BM;
+        bool fast = m0_ + BM <= g.M;
+        if constexpr (EPI == EPI_DG) fast = fast && (m0_ / g.rows_per_sample == (m0_ + BM - 1) / g.rows_per_sample);
+        if constexpr (EPI == EPI_READOUT) fast = false;
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        if constexpr (single) {
+            if (mt + 1 < mt_end) { if (fast) tile(mt, T_{}, T_{}); else tile(mt, T_{}, F_{}); }
+            else { if (fast) tile(mt, F_{}, T_{}); else tile(mt, F_{}, F_{}); }
+        } else {
+            tile(mt, F_{}, F_{});       // k-loop variant: its prefetches live inside the k loop; one generic copy
         }
     }
     if constexpr (EPI != EPI_READOUT) {
@@ -404,18 +479,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     }
 }
 
-template <typename T, int ALD, int EPI>
-static int launch_nn_t(const GemmNN& g, hipStream_t s) {
+template <typename T, int ALD, int EPI, int BNv, bool SINGLE>
+static int launch_nn_k(const GemmNN& g, hipStream_t s) {
     const int BM = 128;
     const int ntm = (g.M + BM - 1) / BM;
-    const int BNv = g.N <= 64 ? 64 : 128;
     const int ntn = (g.N + BNv - 1) / BNv;
     // persistent grid = exactly the resident workgroups (256 CUs x blocks/CU from the occupancy query: the unified
     // VGPR+AGPR budget decides, not the arch-VGPR count); every workgroup gets a contiguous range of M-tiles
     int bpc = 0;
-    hipError_t oe = (BNv == 64)
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, gemm_nn_kernel<T, ALD, EPI, 64>, 256, 0)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, gemm_nn_kernel<T, ALD, EPI, 128>, 256, 0);
+    hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, gemm_nn_kernel<T, ALD, EPI, BNv, SINGLE>, 256, 0);
     if (oe != hipSuccess || bpc < 1) { (void)hipGetLastError(); bpc = 1; }
     // never more workgroups than resident slots (a second partial wave of persistent workgroups doubles the
     // kernel time); nranges * ntn must be a multiple of 8 for the XCD-major logical id
@@ -425,10 +497,26 @@ static int launch_nn_t(const GemmNN& g, hipStream_t s) {
     while (nranges > 1 && (nranges * ntn) % 8 != 0) --nranges;
     if ((nranges * ntn) % 8 != 0) nranges = 8;
     dim3 grid(nranges * ntn, g.groups);
-    if (BNv == 64) hipLaunchKernelGGL((gemm_nn_kernel<T, ALD, EPI, 64>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_nn_kernel<T, ALD, EPI, 128>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_nn_kernel<T, ALD, EPI, BNv, SINGLE>), grid, dim3(256), 0, s, g);
     DWN_CHECK_LAUNCH();
     return 0;
+}
+
+// resident-B single-k-tile instantiations exist for the loaders/epilogues whose hot shapes have K <= one k-tile (the
+// point-wise expand conv and the project conv's data gradient); every other combination runs K <= BK through the
+// k-loop variant (one step, no prefetch)
+template <int ALD, int EPI> struct HasSingle {
+    static constexpr bool value = (ALD == LD_PLAIN && (EPI == EPI_STORE || EPI == EPI_DG)) || (ALD == LD_PE && EPI == EPI_STORE);
+};
+
+template <typename T, int ALD, int EPI>
+static int launch_nn_t(const GemmNN& g, hipStream_t s) {
+    constexpr int BK = 128 / (int)sizeof(T);
+    const bool n64 = g.N <= 64;
+    if constexpr (HasSingle<ALD, EPI>::value) {
+        if (g.K <= BK) return n64 ? launch_nn_k<T, ALD, EPI, 64, true>(g, s) : launch_nn_k<T, ALD, EPI, 128, true>(g, s);
+    }
+    return n64 ? launch_nn_k<T, ALD, EPI, 64, false>(g, s) : launch_nn_k<T, ALD, EPI, 128, false>(g, s);
 }
 
 template <typename T>
@@ -503,7 +591,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    uint4 rp[NCH], rq[NCH];
+    // raw staged vectors: load_tiles only issues the global loads; the prologue math and the bounds select run in
+    // store_tiles, after the MFMAs of the current step (otherwise the loads are waited for before the MFMAs)
+    uint4 p1[NCH], p2[NCH], q1[NCH], q2[NCH];
+    i64 ld_mb = 0;
     // this thread's column chunk (tid % CPR) never changes: hoist the prologue coefficients out of the M loop
     const int chq = tid % CPR;
     const int rcol = r0 + chq * KC, ccol = c0 + chq * KC;
@@ -517,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN g) {
     const T* Qp = reinterpret_cast<const T*>(g.q.p);
     const T* Qq = reinterpret_cast<const T*>(g.q.q);
     auto load_tiles = [&](i64 mb) {
-        uint4 p1[NCH], p2[NCH], q1[NCH], q2[NCH];
+        ld_mb = mb;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             i64 m = mb + tid / CPR + (256 / CPR) * i;
@@ -527,30 +618,33 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN g) {
             if constexpr (PLD != LD_PE) {
                 p1[i] = *reinterpret_cast<const uint4*>(Pp + offp);
                 if constexpr (decltype(cfp)::two_tensors) p2[i] = *reinterpret_cast<const uint4*>(Pq + offp);
-                else p2[i] = make_uint4(0, 0, 0, 0);
+            } else {
+                p1[i] = (mok && rok) ? load_op_packed<LD_PE, T>(g.p, m, pcol0 + rcol) : make_uint4(0, 0, 0, 0);
             }
             if constexpr (QLD != LD_PE) {
                 q1[i] = *reinterpret_cast<const uint4*>(Qp + offq);
                 if constexpr (decltype(cfq)::two_tensors) q2[i] = *reinterpret_cast<const uint4*>(Qq + offq);
-                else q2[i] = make_uint4(0, 0, 0, 0);
+            } else {
+                q1[i] = (mok && cok) ? load_op_packed<LD_PE, T>(g.q, m, qcol0 + ccol) : make_uint4(0, 0, 0, 0);
             }
-        }
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            i64 m = mb + tid / CPR + (256 / CPR) * i;
-            const bool mok = m < mend;
-            if constexpr (PLD == LD_PE) rp[i] = (mok && rok) ? load_op_packed<LD_PE, T>(g.p, m, pcol0 + rcol) : make_uint4(0, 0, 0, 0);
-            else rp[i] = (mok && rok) ? cfp.apply(g.p, (unsigned)m, p1[i], p2[i]) : make_uint4(0, 0, 0, 0);
-            if constexpr (QLD == LD_PE) rq[i] = (mok && cok) ? load_op_packed<LD_PE, T>(g.q, m, qcol0 + ccol) : make_uint4(0, 0, 0, 0);
-            else rq[i] = (mok && cok) ? cfq.apply(g.q, (unsigned)m, q1[i], q2[i]) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_tiles = [&]() {
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             int mrow = tid / CPR + (256 / CPR) * i;
-            *reinterpret_cast<uint4*>(sP + mrow * RS + chq * 16) = rp[i];
-            *reinterpret_cast<uint4*>(sQ + mrow * RS + chq * 16) = rq[i];
+            const i64 m = ld_mb + mrow;
+            const bool mok = m < mend;
+            uint4 vp, vq;
+            if constexpr (PLD == LD_PE) vp = p1[i];
+            else if constexpr (decltype(cfp)::two_tensors) vp = (mok && rok) ? cfp.apply(g.p, (unsigned)m, p1[i], p2[i]) : z4;
+            else vp = (mok && rok) ? cfp.apply(g.p, (unsigned)m, p1[i], z4) : z4;
+            if constexpr (QLD == LD_PE) vq = q1[i];
+            else if constexpr (decltype(cfq)::two_tensors) vq = (mok && cok) ? cfq.apply(g.q, (unsigned)m, q1[i], q2[i]) : z4;
+            else vq = (mok && cok) ? cfq.apply(g.q, (unsigned)m, q1[i], z4) : z4;
+            *reinterpret_cast<uint4*>(sP + mrow * RS + chq * 16) = vp;
+            *reinterpret_cast<uint4*>(sQ + mrow * RS + chq * 16) = vq;
         }
     };
 
