@@ -79,6 +79,8 @@ typedef struct dwn_gemm_nn_args {
     double* stats; int stat_rep_stride_unused; int stat_nchan;
     int epi;
     const float* bias; float sp_beta; float* out_nct; int Tn; int n_valid;
+    /* DWN_EPI_DG: y3 = the activated project-conv input z3 = SiLU(BN3(y3)) [M][N] (materialised by the forward);
+     * dg[b][n] += sum_{m in sample b} C[m][n] * z3[m][n].  s3 / t3 are reserved and must be NULL. */
     const void* y3; long long ldy3; const float* s3; const float* t3; float* dg; int dg_ld; int rows_per_sample;
     /* optional K-concatenation: columns k >= K1 of the A operand come from a2[m][k - K1] (plain loads);
      * only with epi == DWN_EPI_STORE_CAT, which also adds `bias` (fp32 [N]) before rounding. */

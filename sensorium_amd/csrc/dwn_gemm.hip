@@ -225,12 +225,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     const int nvalid_ch = (g.N - n0) / KC < CPR ? (g.N - n0) / KC : CPR;
     const int ch_e = ch < nvalid_ch ? ch : ch % nvalid_ch;
     const int ncol_e = n0 + ch_e * KC;
-    float st0[KC], st1[KC], dgp[KC], s3[KC], t3[KC];
+    float st0[KC], st1[KC], dgp[KC];
 #pragma unroll
-    for (int i = 0; i < KC; ++i) { st0[i] = 0.f; st1[i] = 0.f; dgp[i] = 0.f; s3[i] = 0.f; t3[i] = 0.f; }
-    if constexpr (EPI == EPI_DG) {
-        if (ncol < g.N && g.s3) { ld_coef<KC>(g.s3 + ncol, s3); ld_coef<KC>(g.t3 + ncol, t3); }
-    }
+    for (int i = 0; i < KC; ++i) { st0[i] = 0.f; st1[i] = 0.f; dgp[i] = 0.f; }
     [[maybe_unused]] int dg_b = -1;                    // sample whose partial sums dgp currently holds
     T* Cp = reinterpret_cast<T*>(g.c);
 
@@ -270,14 +267,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
             if constexpr (HN) load_a((mt + 1) * BM, 0);         // in flight under the MFMAs and the epilogue
             mma_tile();
         } else {
-            load_a(m0, 0);
-            load_b(0);
+            // this tile's first k-tile was issued before the previous tile's epilogue (or before the loop)
             store_a();
             store_b();
             __syncthreads();
             for (int k0 = 0; k0 < g.K; k0 += BK) {
                 const bool has_next = (k0 + BK) < g.K;
                 if (has_next) { load_a(m0, k0 + BK); load_b(k0 + BK); }
+                else if (mt + 1 < mt_end) { load_a(m0 + BM, 0); load_b(0); }   // next tile: in flight under the epilogue
                 mma_tile();
                 __syncthreads();
                 if (has_next) {
@@ -381,10 +378,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                         if constexpr (EPI == EPI_DG) {
                             float y[KC];
                             unpack16<T>(zraw[it], y);
-                            if (g.s3) {          // y3 raw: apply bn3 + SiLU here; else `y3` already holds z3
-#pragma unroll
-                                for (int i = 0; i < KC; ++i) y[i] = siluf_(fmaf(y[i], s3[i], t3[i]));
-                            }
 #pragma unroll
                             for (int i = 0; i < KC; ++i) dgp[i] += v[i] * y[i];
                         }
@@ -410,10 +403,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                         float y[KC];
                         unpack16<T>(zraw[it], y);
                         const int b_pass = mp / g.rows_per_sample;
-                        if (g.s3) {          // y3 raw: apply bn3 + SiLU here; else `y3` already holds z3
-#pragma unroll
-                            for (int i = 0; i < KC; ++i) y[i] = siluf_(fmaf(y[i], s3[i], t3[i]));
-                        }
                         if (b == b_pass) {
 #pragma unroll
                             for (int i = 0; i < KC; ++i) dgp[i] += v[i] * y[i];
@@ -444,6 +433,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
             __syncthreads();
         }
     };
+    if constexpr (!single) { load_a(mt_beg * BM, 0); load_b(0); }
     for (int mt = mt_beg; mt < mt_end; ++mt) {
         const int m0_ = mt * BM;
         bool fast = m0_ + BM <= g.M;
@@ -529,6 +519,7 @@ static int launch_nn_d(const GemmNN& g, hipStream_t s) {
     }
     if (g.N % TT<T>::KC != 0) return dwn_set_error(-2, "gemm_nn: N must be a multiple of the 16-byte vector");
     if (g.epi == EPI_DG) {
+        if (g.s3 || g.t3) return dwn_set_error(-3, "gemm_nn: the dg epilogue reads the activated z3; s3/t3 must be NULL");
         if (g.a_kind == LD_PLAIN && g.groups == 1) return launch_nn_t<T, LD_PLAIN, EPI_DG>(g, s);
         return dwn_set_error(-3, "gemm_nn: unsupported loader for dg epilogue");
     }
