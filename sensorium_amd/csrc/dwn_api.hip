@@ -307,11 +307,16 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     const int dt = a.dtype, tr = a.training;
     const i64 Min = (i64)a.B * a.T * a.Hin * a.Win, Mout = (i64)a.B * a.T * a.Hout * a.Wout;
     const int S_out = a.T * a.Hout * a.Wout;
-    TRY(k_zero(w.zero_beg, ((size_t)(w.zero_end - w.zero_beg) + 15) & ~(size_t)15, s));
-    TRY(k_pack_weight(a.w_pw, w.wpw, 1, a.Cmid, a.Cin, 0, a.Cmid, a.Cin, dt, s));
-    TRY(k_pack_weight(a.w_pwl, w.wpwl, 1, a.Cout, a.Cmid, 0, a.Cout, a.Cmid, dt, s));
-    TRY(k_pack_dw(a.w_dws, w.wdws, a.Cmid, a.ks * a.ks, s));
-    TRY(k_pack_dw(a.w_dwt, w.wdwt, a.Cmid, a.kt, s));
+    {   // one launch: zero the statistics arena, pack the four weights
+        PrepArgs pa;
+        bool ok = pa.zero(w.zero_beg, ((size_t)(w.zero_end - w.zero_beg) + 15) & ~(size_t)15);
+        ok = ok && pa.packw(a.w_pw, w.wpw, 1, a.Cmid, a.Cin, 0, a.Cmid, a.Cin);
+        ok = ok && pa.packw(a.w_pwl, w.wpwl, 1, a.Cout, a.Cmid, 0, a.Cout, a.Cmid);
+        ok = ok && pa.packdw(a.w_dws, w.wdws, a.Cmid, a.ks * a.ks);
+        ok = ok && pa.packdw(a.w_dwt, w.wdwt, a.Cmid, a.kt);
+        if (!ok) return dwn_set_error(-2, "block_forward: workspace arena must be 16-byte aligned");
+        TRY(k_prep(pa, dt, s));
+    }
 
     // PositionalEncoding3d (dwiseneuro.py:184-192): normally already folded into x by the producer (stem /
     // previous block's residual kernel); stand-alone callers get it materialised here
@@ -382,12 +387,17 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     const i64 Min = (i64)a.B * a.T * a.Hin * a.Win, Mout = (i64)a.B * a.T * a.Hout * a.Wout;
     const int S_out = a.T * a.Hout * a.Wout;
     float* dg = w.pooled;
-    TRY(k_zero(w.zero_beg, ((size_t)(w.zero_end - w.zero_beg) + 15) & ~(size_t)15, s));
-    TRY(k_pack_weight(a.w_pwl, w.wpwl, 1, a.Cout, a.Cmid, 1, a.Cmid, a.Cout, dt, s));  // W2^T [Cmid][Cout]
-    TRY(k_pack_dw(a.w_dws, w.wdws, a.Cmid, a.ks * a.ks, s));
-    TRY(k_pack_dw(a.w_dwt, w.wdwt, a.Cmid, a.kt, s));
-    TRY(k_fill_f32(w.ident3, 1.0f, a.Cmid, s));
-    TRY(k_fill_f32(w.ident3 + a.Cmid, 0.0f, 2 * a.Cmid, s));
+    {   // one launch: zero the statistics arena, W2^T [Cmid][Cout], tap-major depth-wise weights, identity affine
+        PrepArgs pa;
+        bool ok = pa.zero(w.zero_beg, ((size_t)(w.zero_end - w.zero_beg) + 15) & ~(size_t)15);
+        ok = ok && pa.packw(a.w_pwl, w.wpwl, 1, a.Cout, a.Cmid, 1, a.Cmid, a.Cout);
+        ok = ok && pa.packdw(a.w_dws, w.wdws, a.Cmid, a.ks * a.ks);
+        ok = ok && pa.packdw(a.w_dwt, w.wdwt, a.Cmid, a.kt);
+        ok = ok && pa.fill(w.ident3, 1.0f, a.Cmid);
+        ok = ok && pa.fill(w.ident3 + a.Cmid, 0.0f, 2 * a.Cmid);
+        if (!ok) return dwn_set_error(-2, "block_backward: workspace arena must be 16-byte aligned");
+        TRY(k_prep(pa, dt, s));
+    }
 
     LoadDesc xin = ld_plain(a.x_has_pe ? a.x : a.a0, a.Cin);     // block input including its positional encoding
     ResGeom gm = geom_of(a);
@@ -508,8 +518,13 @@ int dwn_cortex_forward(const dwn_cortex_args* ap, int device, void* stream) {
     CortexWs w = carve_cortex(a, 0, a.ws, a.ws_bytes);
     if (w.bytes > a.ws_bytes) return dwn_set_error(-6, "cortex_forward: workspace too small");
     const int M = a.B * a.T, Kg = a.Cin / a.groups, Ng = a.C / a.groups, dt = a.dtype, tr = a.training;
-    TRY(k_zero(w.zb, ((size_t)(w.ze - w.zb) + 15) & ~(size_t)15, s));
-    TRY(k_pack_weight(a.w, w.wp, 1, a.C, Kg, 0, a.C, Kg, dt, s));
+    {
+        PrepArgs pa;
+        bool ok = pa.zero(w.zb, ((size_t)(w.ze - w.zb) + 15) & ~(size_t)15);
+        ok = ok && pa.packw(a.w, w.wp, 1, a.C, Kg, 0, a.C, Kg);
+        if (!ok) return dwn_set_error(-2, "cortex_forward: workspace arena must be 16-byte aligned");
+        TRY(k_prep(pa, dt, s));
+    }
     GemmNN g = nn_base(ld_plain(a.x, a.Cin), LD_PLAIN, w.wp, Kg, a.y, a.C, M, Ng, Kg, a.groups);
     g.stats = tr ? w.st : nullptr; g.stat_nchan = a.C;
     TRY(launch_gemm_nn(g, dt, s));
@@ -527,8 +542,13 @@ int dwn_cortex_backward(const dwn_cortex_args* ap, int device, void* stream) {
     CortexWs w = carve_cortex(a, 1, a.ws, a.ws_bytes);
     if (w.bytes > a.ws_bytes) return dwn_set_error(-6, "cortex_backward: workspace too small");
     const int M = a.B * a.T, Kg = a.Cin / a.groups, Ng = a.C / a.groups, dt = a.dtype;
-    TRY(k_zero(w.zb, ((size_t)(w.ze - w.zb) + 15) & ~(size_t)15, s));
-    TRY(k_pack_weight(a.w, w.wp, a.groups, Ng, Kg, 1, Kg, Ng, dt, s));     // per group W^T [Kg][Ng]
+    {
+        PrepArgs pa;
+        bool ok = pa.zero(w.zb, ((size_t)(w.ze - w.zb) + 15) & ~(size_t)15);
+        ok = ok && pa.packw(a.w, w.wp, a.groups, Ng, Kg, 1, Kg, Ng);       // per group W^T [Kg][Ng]
+        if (!ok) return dwn_set_error(-2, "cortex_backward: workspace arena must be 16-byte aligned");
+        TRY(k_prep(pa, dt, s));
+    }
     TRY(k_cortex_bwd_reduce(a.y, a.x, a.dout, a.dout_mask, a.dout_mask_ld, a.bn.coef, a.bnsc.coef, a.drop_scale, M, a.T,
                             a.Cin, a.C, a.groups, w.st, w.stsc, dt, s));
     TRY(k_bn_bwd_finalize(w.st, (double)M, a.bn.coef, a.bn.dgamma, a.bn.dbeta, w.abc, a.C, s));

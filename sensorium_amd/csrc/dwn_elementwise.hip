@@ -61,18 +61,29 @@ static inline dim3 slice_grid(i64 rows, int C, int KC, int cap = 2048) {
 // BatchNorm finalisation (BatchNormAct, dwiseneuro.py:9-22; torch BatchNorm semantics)
 // coef layout: [4][C] = scale, shift, mean, invstd
 // ------------------------------------------------------------------------------------------------
-__global__ void bn_finalize_train_kernel(const double* stats, int stat_c, double count, const float* gamma,
-                                         const float* beta, float* running_mean, float* running_var,
-                                         long long* nbt, float momentum, float eps, float* coef, int C) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) *nbt += 1;
-    if (c >= C) return;
-    int sc = c % stat_c;                     // shortcut BN: out channel c uses the stats of in channel c % C_in
-    double s = 0, ss = 0;
-    for (int r = 0; r < DWN_NREP; ++r) {
-        s += stats[((i64)r * 2 + 0) * stat_c + sc];
-        ss += stats[((i64)r * 2 + 1) * stat_c + sc];
-    }
+// One lane per (channel, replica): 32 consecutive lanes hold the 32 replicas of a channel's two fp64 sums and combine
+// them with xor-shuffles — a single-thread loop over the replicas was 64 dependent-latency loads (7-8 us per launch,
+// ~100 launches per training step).
+static_assert(DWN_NREP == 32, "replica reduce below assumes 32 replicas");
+__device__ __forceinline__ void rep_reduce(const double* stats, int stat_c, int sc, int r, bool ok, double& s, double& ss) {
+    s = ok ? stats[((i64)r * 2 + 0) * stat_c + sc] : 0.0;
+    ss = ok ? stats[((i64)r * 2 + 1) * stat_c + sc] : 0.0;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_train_kernel(const double* stats, int stat_c, double count,
+                                                                const float* gamma, const float* beta,
+                                                                float* running_mean, float* running_var, long long* nbt,
+                                                                float momentum, float eps, float* coef, int C) {
+    const int r = threadIdx.x & 31;
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (c == 0 && r == 0 && nbt) *nbt += 1;
+    const bool ok = c < C;
+    const int sc = ok ? c % stat_c : 0;      // shortcut BN: out channel c uses the stats of in channel c % C_in
+    double s, ss;
+    rep_reduce(stats, stat_c, sc, r, ok, s, ss);
+    if (!ok || r != 0) return;
     double mean = s / count;
     double var = ss / count - mean * mean;
     if (var < 0) var = 0;
@@ -102,15 +113,14 @@ __global__ void bn_finalize_eval_kernel(const float* gamma, const float* beta, c
 }
 
 // backward: stats = [NREP][2][C] with Σdh and Σdh·ŷ.  dy = A1*dh + A2*y + A3 (y raw), dgamma = Σdh·ŷ, dbeta = Σdh
-__global__ void bn_bwd_finalize_kernel(const double* stats, double count, const float* coef, float* dgamma,
-                                       float* dbeta, float* abc, int C) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0, s2 = 0;
-    for (int r = 0; r < DWN_NREP; ++r) {
-        s1 += stats[((i64)r * 2 + 0) * C + c];
-        s2 += stats[((i64)r * 2 + 1) * C + c];
-    }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* stats, double count, const float* coef,
+                                                              float* dgamma, float* dbeta, float* abc, int C) {
+    const int r = threadIdx.x & 31;
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool ok = c < C;
+    double s1, s2;
+    rep_reduce(stats, C, ok ? c : 0, r, ok, s1, s2);
+    if (!ok || r != 0) return;
     float scale = coef[c], mean = coef[2 * C + c], invstd = coef[3 * C + c];
     if (dgamma) dgamma[c] = (float)s2;
     if (dbeta) dbeta[c] = (float)s1;
@@ -123,7 +133,7 @@ __global__ void bn_bwd_finalize_kernel(const double* stats, double count, const 
 int k_bn_finalize_train(const double* stats, int stat_c, double count, const float* gamma, const float* beta,
                         float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef, int C,
                         hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, stat_c, count,
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 7) / 8), dim3(256), 0, s, stats, stat_c, count,
                        gamma, beta, rm, rv, nbt, momentum, eps, coef, C);
     DWN_CHECK_LAUNCH();
     return 0;
@@ -137,7 +147,7 @@ int k_bn_finalize_eval(const float* gamma, const float* beta, const float* rm, c
 }
 int k_bn_bwd_finalize(const double* stats, double count, const float* coef, float* dgamma, float* dbeta,
                       float* abc, int C, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, count, coef, dgamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, s, stats, count, coef, dgamma,
                        dbeta, abc, C);
     DWN_CHECK_LAUNCH();
     return 0;
@@ -717,6 +727,105 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* dg, const 
     }
 }
 
+// ---- latency-oriented variants for R <= SE_RT hidden units (the model's R = Cmid / 32 <= 56).
+// The generic kernels above walk the hidden units one after another per wave: ~R/4 dependent rounds of L2 latency
+// (40-50 us per launch).  Here every thread owns a fixed set of channels and keeps one partial sum per hidden unit in
+// registers, so all R x C/256 weight loads of the squeeze layer are independent; the partials are combined with
+// xor-shuffles and one LDS atomic per wave.
+#define SE_RT 64
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void se_mlp_fwd_fast_kernel(const float* pooled_sum, float inv_s, const float* wr,
+                                                              const float* br, const float* we, const float* be, int C,
+                                                              int R, float* pmean, float* hid_pre, float* gate) {
+    __shared__ float hid[SE_RT];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int split = gridDim.y, part = blockIdx.y;
+    if (tid < SE_RT) hid[tid] = 0.f;
+    __syncthreads();
+    float acc[SE_RT];
+#pragma unroll
+    for (int r = 0; r < SE_RT; ++r) acc[r] = 0.f;
+    for (int c = tid; c < C; c += 256) {
+        const float v = pooled_sum[(i64)b * C + c] * inv_s;
+        if (part == 0) pmean[(i64)b * C + c] = v;
+#pragma unroll
+        for (int r = 0; r < SE_RT; ++r)
+            if (r < R) acc[r] = fmaf(wr[(i64)r * C + c], v, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < SE_RT; ++r) {
+        if (r < R) {
+            const float t = wave_sum(acc[r]);
+            if (lane == 0) atomicAdd(&hid[r], t);
+        }
+    }
+    __syncthreads();
+    if (tid < R) {
+        const float h = hid[tid] + br[tid];
+        if (part == 0) hid_pre[(i64)b * R + tid] = h;
+        hid[tid] = siluf_(h);
+    }
+    __syncthreads();
+    const int per = (C + split - 1) / split;
+    const int c_end = (part + 1) * per < C ? (part + 1) * per : C;
+    for (int c = part * per + tid; c < c_end; c += 256) {
+        float a = be[c];
+        const float* wrow = we + (i64)c * R;
+#pragma unroll 8
+        for (int r = 0; r < R; ++r) a = fmaf(wrow[r], hid[r], a);
+        gate[(i64)b * C + c] = sigmoidf_(a);
+    }
+}
+
+__global__ __launch_bounds__(256) void se_mlp_bwd_fast_kernel(const float* dg, const float* gate, const float* hid_pre,
+                                                              const float* wr, const float* we, int C, int R,
+                                                              float inv_s, float* dgp_out, float* dhp_out, float* dps) {
+    __shared__ float dhp[SE_RT];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int split = gridDim.y, part = blockIdx.y;
+    if (tid < SE_RT) dhp[tid] = 0.f;
+    __syncthreads();
+    float acc[SE_RT];
+#pragma unroll
+    for (int r = 0; r < SE_RT; ++r) acc[r] = 0.f;
+    for (int c = tid; c < C; c += 256) {
+        const float g = gate[(i64)b * C + c];
+        const float v = dg[(i64)b * C + c] * g * (1.f - g);
+        if (part == 0) dgp_out[(i64)b * C + c] = v;
+        const float* wrow = we + (i64)c * R;
+#pragma unroll
+        for (int r = 0; r < SE_RT; ++r)
+            if (r < R) acc[r] = fmaf(wrow[r], v, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < SE_RT; ++r) {
+        if (r < R) {
+            const float t = wave_sum(acc[r]);
+            if (lane == 0) atomicAdd(&dhp[r], t);
+        }
+    }
+    __syncthreads();
+    if (tid < R) {
+        const float v = dhp[tid] * silu_gradf_(hid_pre[(i64)b * R + tid]);
+        dhp[tid] = v;
+        if (part == 0) dhp_out[(i64)b * R + tid] = v;
+    }
+    __syncthreads();
+    const int per = (C + split - 1) / split;
+    const int c_end = (part + 1) * per < C ? (part + 1) * per : C;
+    for (int c = part * per + tid; c < c_end; c += 256) {
+        float a = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < R; ++r) a = fmaf(wr[(i64)r * C + c], dhp[r], a);
+        dps[(i64)b * C + c] = a * inv_s;
+    }
+}
+
 // parameter grads of the SE MLP.  grid.x = ceil(C/256), grid.y = R: thread (c, r) reduces over the batch.
 __global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const float* dgp, const float* dhp, const float* pmean,
                                                            const float* hid_pre, int B, int C, int R, float* dwr,
@@ -744,16 +853,24 @@ __global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const float* dgp, con
 
 int k_se_mlp_fwd(const float* pooled_sum, float inv_s, const float* wr, const float* br, const float* we,
                  const float* be, int B, int C, int R, float* pmean, float* hid_pre, float* gate, hipStream_t s) {
-    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(B, 8), dim3(256), (C + R) * sizeof(float), s, pooled_sum, inv_s, wr, br, we,
-                       be, C, R, pmean, hid_pre, gate);
+    if (R <= SE_RT)
+        hipLaunchKernelGGL(se_mlp_fwd_fast_kernel, dim3(B, 8), dim3(256), 0, s, pooled_sum, inv_s, wr, br, we, be, C, R,
+                           pmean, hid_pre, gate);
+    else
+        hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(B, 8), dim3(256), (C + R) * sizeof(float), s, pooled_sum, inv_s, wr, br,
+                           we, be, C, R, pmean, hid_pre, gate);
     DWN_CHECK_LAUNCH();
     return 0;
 }
 int k_se_mlp_bwd(const float* dg, const float* gate, const float* hid_pre, const float* pmean, const float* wr,
                  const float* we, int B, int C, int R, float inv_s, float* dgp, float* dhp, float* dps, float* dwr,
                  float* dbr, float* dwe, float* dbe, hipStream_t s) {
-    hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(B, 8), dim3(256), (C + R) * sizeof(float), s, dg, gate, hid_pre, wr, we, C,
-                       R, inv_s, dgp, dhp, dps);
+    if (R <= SE_RT)
+        hipLaunchKernelGGL(se_mlp_bwd_fast_kernel, dim3(B, 8), dim3(256), 0, s, dg, gate, hid_pre, wr, we, C, R, inv_s, dgp,
+                           dhp, dps);
+    else
+        hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(B, 8), dim3(256), (C + R) * sizeof(float), s, dg, gate, hid_pre, wr, we,
+                           C, R, inv_s, dgp, dhp, dps);
     DWN_CHECK_LAUNCH();
     hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 255) / 256, R), dim3(256), 0, s, dgp, dhp, pmean, hid_pre, B, C, R,
                        dwr, dbr, dwe, dbe);
@@ -1239,6 +1356,48 @@ __global__ void fill_f32_kernel(float* p, float v, int n) {
 }
 int k_fill_f32(float* p, float v, int n, hipStream_t s) {
     hipLaunchKernelGGL(fill_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- one launch for the per-call preparation work of a composite (zero the statistics arena, constant vectors,
+// weight packs): these were 5-6 separate 3-10 us launches in front of every block forward / backward.
+template <typename T>
+__global__ __launch_bounds__(256) void prep_kernel(const PrepArgs pa) {
+    int blk = blockIdx.x, o = 0;
+    while (o < pa.nops - 1 && blk >= pa.op[o].nblocks) { blk -= pa.op[o].nblocks; ++o; }
+    const PrepOp& q = pa.op[o];
+    const i64 idx = (i64)blk * 256 + threadIdx.x;
+    if (q.kind == PREP_ZERO) {
+        uint4* p = reinterpret_cast<uint4*>(q.dst);
+        for (i64 i = idx; i < q.n; i += (i64)q.nblocks * 256) p[i] = make_uint4(0, 0, 0, 0);
+    } else if (q.kind == PREP_FILL) {
+        if (idx < q.n) reinterpret_cast<float*>(q.dst)[idx] = q.v;
+    } else if (q.kind == PREP_PACKDW) {            // [C][taps] -> [taps][C] fp32
+        if (idx < q.n) {
+            const int C = q.C, k = (int)(idx / C), c = (int)(idx % C);
+            reinterpret_cast<float*>(q.dst)[idx] = q.src[(i64)c * q.R + k];
+        }
+    } else {                                        // PREP_PACKW: see pack_weight_kernel
+        if (idx < q.n) {
+            const i64 per = (i64)q.Rd * q.Cd;
+            const int g = (int)(idx / per);
+            const i64 rem = idx % per;
+            const int rd = (int)(rem / q.Cd), cd = (int)(rem % q.Cd);
+            float v = 0.f;
+            if (!q.transpose) { if (rd < q.R && cd < q.C) v = q.src[((i64)g * q.R + rd) * q.C + cd]; }
+            else { if (cd < q.R && rd < q.C) v = q.src[((i64)g * q.R + cd) * q.C + rd]; }
+            reinterpret_cast<T*>(q.dst)[idx] = from_f<T>(v);
+        }
+    }
+}
+int k_prep(const PrepArgs& pa, int dtype, hipStream_t s) {
+    int total = 0;
+    for (int i = 0; i < pa.nops; ++i) total += pa.op[i].nblocks;
+    if (total == 0) return 0;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((prep_kernel<bf16_t>), dim3(total), dim3(256), 0, s, pa),
+        hipLaunchKernelGGL((prep_kernel<float>), dim3(total), dim3(256), 0, s, pa));
     DWN_CHECK_LAUNCH();
     return 0;
 }
