@@ -85,6 +85,32 @@ struct FastDiv {
     __device__ __forceinline__ int rem(int f, int q) const { return f - __mul24(q, d); }
 };
 
+// ---- exact unsigned division by a kernel-uniform divisor for 0 <= n < 2^31 (row indices): one v_mul_hi_u32 and a
+// shift instead of the ~80-instruction 64-bit division the row -> (frame, y, x) decodes used to cost per row.
+// With s = ceil(log2 d) and m = ceil(2^(31+s) / d) (< 2^32), floor(n / d) = (n * m) >> (31 + s) for every n < 2^31.
+struct UDiv32 {
+    unsigned d, m;
+    int sh;
+    __device__ __forceinline__ explicit UDiv32(unsigned d_) : d(d_) {
+        const int s = d_ <= 1 ? 1 : 32 - __clz((int)(d_ - 1));
+        sh = s - 1;
+        m = d_ <= 1 ? 0u : (unsigned)((((unsigned long long)1 << (31 + s)) + d_ - 1) / d_);
+    }
+    __device__ __forceinline__ unsigned div(unsigned n) const { return d <= 1 ? n : (__umulhi(n, m) >> sh); }
+};
+// row of a [frames][H][W] raster -> (frame, y, x)
+struct RasterIdx {
+    UDiv32 dw, dh;
+    unsigned W, H;
+    __device__ __forceinline__ RasterIdx(int H_, int W_) : dw((unsigned)W_), dh((unsigned)H_), W((unsigned)W_), H((unsigned)H_) {}
+    __device__ __forceinline__ void decode(unsigned row, unsigned& f, int& y, int& x) const {
+        const unsigned r2 = dw.div(row);
+        x = (int)(row - r2 * W);
+        f = dh.div(r2);
+        y = (int)(r2 - f * H);
+    }
+};
+
 // ---- activation math
 // v_exp_f32 + v_rcp_f32 (1 ulp each): an IEEE fp32 division would cost ~10 VALU instructions per element
 __device__ __forceinline__ float sigmoidf_(float h) { return __builtin_amdgcn_rcpf(1.0f + __expf(-h)); }

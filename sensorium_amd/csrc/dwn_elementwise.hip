@@ -21,13 +21,21 @@
 template <int KC>
 __device__ __forceinline__ void slice_stats_flush(float* lstat, const float* s0, const float* s1, int cv,
                                                  int c0, int C, double* stats, int rep) {
+    // lanes l, l+8, l+16, ... of a wave hold the same channel vector (cv = tid % NCV, NCV = 8): combine them with
+    // xor-shuffles so that one lane per vector and wave touches LDS
+    static_assert(NCV == 8, "wave pre-reduction below assumes 8 channel vectors per slice");
+    const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < KC; ++i) {
-        atomicAdd(&lstat[cv * KC + i], s0[i]);
-        atomicAdd(&lstat[NCV * KC + cv * KC + i], s1[i]);
+        float a = s0[i], b = s1[i];
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        if ((tid & 63) < NCV) {
+            atomicAdd(&lstat[cv * KC + i], a);
+            atomicAdd(&lstat[NCV * KC + cv * KC + i], b);
+        }
     }
     __syncthreads();
-    const int tid = threadIdx.x;
     if (tid < 2 * NCV * KC) {
         int which = tid / (NCV * KC), c = c0 + tid % (NCV * KC);
         if (c < C) stat_add(stats, rep, C, which, c, lstat[tid]);
@@ -37,10 +45,11 @@ __device__ __forceinline__ void slice_stats_flush(float* lstat, const float* s0,
 // persistent sizing for the streaming kernels that keep per-workgroup accumulators: exactly one resident wave of
 // workgroups (occupancy query), so start-up / flush costs are paid once per CU slot and there is no ragged tail
 template <typename K>
-static dim3 resident_slice_grid(K kernel, i64 rows, int C, int KC) {
+static dim3 resident_slice_grid(K kernel, i64 rows, int C, int KC, int max_bpc = 1 << 20) {
     int slices = (C + NCV * KC - 1) / (NCV * KC);
     int bpc = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kernel, 256, 0) != hipSuccess || bpc < 1) { (void)hipGetLastError(); bpc = 4; }
+    if (bpc > max_bpc) bpc = max_bpc;
     i64 bx = (256 * (i64)bpc) / slices;
     i64 need = (rows + 31) / 32;
     if (bx > need) bx = need;
@@ -53,6 +62,17 @@ static inline dim3 slice_grid(i64 rows, int C, int KC, int cap = 2048) {
     i64 bx = (rows + 31) / 32;
     int capx = (cap + slices - 1) / slices;
     if (bx > capx) bx = capx;
+    if (bx < 1) bx = 1;
+    return dim3((unsigned)bx, (unsigned)slices);
+}
+
+// one 1024-thread workgroup per CU in total (across the channel slices): the fewest end-of-kernel flushes per
+// statistics address that still fills the chip
+static inline dim3 fat_slice_grid(i64 rows, int C, int KC) {
+    int slices = (C + NCV * KC - 1) / (NCV * KC);
+    i64 bx = 256 / slices;
+    i64 need = (rows + (1024 / NCV) - 1) / (1024 / NCV);
+    if (bx > need) bx = need;
     if (bx < 1) bx = 1;
     return dim3((unsigned)bx, (unsigned)slices);
 }
@@ -374,8 +394,29 @@ int k_stem_bwd(const LoadDesc& dy, const float* x, float* dw, int B, int Cin, i6
 // shortcut (interpolate_shortcut, dwiseneuro.py:125-134) + residual (:143)
 // geometry of one block's shortcut gather
 // ------------------------------------------------------------------------------------------------
+// All kernels of this section walk output (or input) rows with 32-bit indices (rows < 2^31 is checked by the
+// launchers), decode (frame, y, x) with UDiv32 and keep RU rows in flight per thread.
+#define RES_RU 2
+// The nearest-neighbour index tables (<= RES_TAB entries each) are staged in LDS once per workgroup: reading them from
+// global memory put two dependent memory latencies in front of every gathered row.
+#define RES_TAB 256
+#define RES_STAGE_TABLES(hptr, hn, wptr, wn)                                             \
+    __shared__ int s_ht[RES_TAB], s_wt[RES_TAB];                                         \
+    const bool tab_lds = (hn) <= RES_TAB && (wn) <= RES_TAB;                             \
+    if (tab_lds) {                                                                       \
+        for (int i_ = threadIdx.x; i_ < (hn); i_ += blockDim.x) s_ht[i_] = (hptr)[i_];          \
+        for (int i_ = threadIdx.x; i_ < (wn); i_ += blockDim.x) s_wt[i_] = (wptr)[i_];          \
+    }                                                                                    \
+    __syncthreads();                                                                     \
+    const int* const ht_ = tab_lds ? s_ht : (hptr);                                      \
+    const int* const wt_ = tab_lds ? s_wt : (wptr);
+// Few, fat workgroups (2 per CU, SC_RU rows in flight per thread): with one or two channel slices a fully resident
+// grid put 64 workgroups on every replica address of the fp64 statistics and their end-of-kernel atomics serialised at
+// the memory side (~45 us fixed, more than the data pass itself).
+#define SC_RU 4
+#define STAT_NT 1024        // threads per workgroup of the small-C statistics kernels: one workgroup per CU
 template <typename T>
-__global__ __launch_bounds__(256) void shortcut_stats_kernel(LoadDesc xin, ResGeom gm, double* stats) {
+__global__ __launch_bounds__(STAT_NT) void shortcut_stats_kernel(LoadDesc xin, ResGeom gm, double* stats) {
     // Σ, Σ² of (x + PE) at the gathered (nearest) positions, per *input* channel
     SLICE_SETUP(gm.Cin)
     __shared__ float lstat[2 * NCV * KC];
@@ -384,19 +425,32 @@ __global__ __launch_bounds__(256) void shortcut_stats_kernel(LoadDesc xin, ResGe
     float s0[KC], s1[KC];
 #pragma unroll
     for (int i = 0; i < KC; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
-    const i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
-    if (chan_ok)
-        for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
-            int wo = (int)(row % gm.Wout);
-            i64 r2 = row / gm.Wout;
-            int ho = (int)(r2 % gm.Hout);
-            i64 bt = r2 / gm.Hout;
-            i64 rin = (bt * gm.Hin + gm.hsrc[ho]) * gm.Win + gm.wsrc[wo];
-            float v[KC];
-            load_op<LD_PLAIN, T>(xin, rin, chan, v);
+    const unsigned rows = (unsigned)gm.BT * gm.Hout * gm.Wout;
+    const RasterIdx ro(gm.Hout, gm.Wout);
+    const T* xp = reinterpret_cast<const T*>(xin.p);
+    RES_STAGE_TABLES(gm.hsrc, gm.Hout, gm.wsrc, gm.Wout)
+    if (chan_ok) {
+        const unsigned stride = gridDim.x * (unsigned)(STAT_NT / NCV);
+        for (unsigned row0 = blockIdx.x * (unsigned)(STAT_NT / NCV) + pl; row0 < rows; row0 += SC_RU * stride) {
+            uint4 raw[SC_RU];
 #pragma unroll
-            for (int i = 0; i < KC; ++i) { float r = round_t<T>(v[i]); s0[i] += r; s1[i] += r * r; }
+            for (int u = 0; u < SC_RU; ++u) {
+                const unsigned row = row0 + u * stride < rows ? row0 + u * stride : row0;
+                unsigned bt; int ho, wo;
+                ro.decode(row, bt, ho, wo);
+                const i64 rin = ((i64)bt * gm.Hin + ht_[ho]) * gm.Win + wt_[wo];
+                raw[u] = *reinterpret_cast<const uint4*>(xp + rin * xin.ld + chan);
+            }
+#pragma unroll
+            for (int u = 0; u < SC_RU; ++u) {
+                if (row0 + u * stride >= rows) break;
+                float v[KC];
+                unpack16<T>(raw[u], v);
+#pragma unroll
+                for (int i = 0; i < KC; ++i) { s0[i] += v[i]; s1[i] += v[i] * v[i]; }
+            }
         }
+    }
     slice_stats_flush<KC>(lstat, s0, s1, cv, c0, gm.Cin, stats, blockIdx.x % DWN_NREP);
 }
 
@@ -407,41 +461,56 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(LoadDesc xin, const T
                                                            const float* ope_t, const float* ope_h, const float* ope_w,
                                                            T* out) {
     SLICE_SETUP(gm.Cout)
+    RES_STAGE_TABLES(gm.hsrc, gm.Hout, gm.wsrc, gm.Wout)
     if (!chan_ok) return;
     float s4[KC], t4[KC], ss[KC], ts[KC];
     ld_coef<KC>(coef4 + chan, s4); ld_coef<KC>(coef4 + gm.Cout + chan, t4);
     ld_coef<KC>(coefsc + chan, ss); ld_coef<KC>(coefsc + gm.Cout + chan, ts);
     const int csrc = chan % gm.Cin;
-    const i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
-    const i64 rows_per_b = (i64)gm.T * gm.Hout * gm.Wout;
-    for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
-        int wo = (int)(row % gm.Wout);
-        i64 r2 = row / gm.Wout;
-        int ho = (int)(r2 % gm.Hout);
-        i64 bt = r2 / gm.Hout;
-        i64 rin = (bt * gm.Hin + gm.hsrc[ho]) * gm.Win + gm.wsrc[wo];
-        float sv[KC], yv[KC], o[KC];
-        load_op<LD_PLAIN, T>(xin, rin, csrc, sv);
-        ld_vec<T>(y4 + row * gm.Cout + chan, yv);
-        float d = dscale ? dscale[row / rows_per_b] : 1.0f;
+    const unsigned rows = (unsigned)gm.BT * gm.Hout * gm.Wout;
+    const RasterIdx ro(gm.Hout, gm.Wout);
+    const UDiv32 dT((unsigned)gm.T);
+    const T* xp = reinterpret_cast<const T*>(xin.p);
+    const unsigned stride = gridDim.x * 32u;
+    for (unsigned row0 = blockIdx.x * 32u + pl; row0 < rows; row0 += RES_RU * stride) {
+        uint4 rs[RES_RU], ry[RES_RU];
+        unsigned btv[RES_RU]; int hov[RES_RU], wov[RES_RU];
 #pragma unroll
-        for (int i = 0; i < KC; ++i)
-            o[i] = d * fmaf(yv[i], s4[i], t4[i]) + fmaf(round_t<T>(sv[i]), ss[i], ts[i]);
-        if (ope_t) {       // the NEXT block's positional encoding is folded into this block's output
-            float pa[KC], pb[KC], pc[KC];
-            ld_coef<KC>(ope_t + (i64)(bt % gm.T) * gm.Cout + chan, pa);
-            ld_coef<KC>(ope_h + (i64)ho * gm.Cout + chan, pb);
-            ld_coef<KC>(ope_w + (i64)wo * gm.Cout + chan, pc);
-#pragma unroll
-            for (int i = 0; i < KC; ++i) o[i] = round_t<T>(o[i]) + ((pa[i] + pb[i]) + pc[i]);
+        for (int u = 0; u < RES_RU; ++u) {
+            const unsigned row = row0 + u * stride < rows ? row0 + u * stride : row0;
+            ro.decode(row, btv[u], hov[u], wov[u]);
+            const i64 rin = ((i64)btv[u] * gm.Hin + ht_[hov[u]]) * gm.Win + wt_[wov[u]];
+            rs[u] = *reinterpret_cast<const uint4*>(xp + rin * xin.ld + csrc);
+            ry[u] = *reinterpret_cast<const uint4*>(y4 + (i64)row * gm.Cout + chan);
         }
-        st_vec<T>(out + row * gm.Cout + chan, o);
+#pragma unroll
+        for (int u = 0; u < RES_RU; ++u) {
+            const unsigned row = row0 + u * stride;
+            if (row >= rows) break;
+            float sv[KC], yv[KC], o[KC];
+            unpack16<T>(rs[u], sv);
+            unpack16<T>(ry[u], yv);
+            const unsigned b = dT.div(btv[u]);
+            const float d = dscale ? dscale[b] : 1.0f;
+#pragma unroll
+            for (int i = 0; i < KC; ++i) o[i] = d * fmaf(yv[i], s4[i], t4[i]) + fmaf(sv[i], ss[i], ts[i]);
+            if (ope_t) {       // the NEXT block's positional encoding is folded into this block's output
+                float pa[KC], pb[KC], pc[KC];
+                ld_coef<KC>(ope_t + (i64)(btv[u] - b * (unsigned)gm.T) * gm.Cout + chan, pa);
+                ld_coef<KC>(ope_h + (i64)hov[u] * gm.Cout + chan, pb);
+                ld_coef<KC>(ope_w + (i64)wov[u] * gm.Cout + chan, pc);
+#pragma unroll
+                for (int i = 0; i < KC; ++i) o[i] = round_t<T>(o[i]) + ((pa[i] + pb[i]) + pc[i]);
+            }
+            st_vec<T>(out + (i64)row * gm.Cout + chan, o);
+        }
     }
 }
 
 // Σ d·dout, Σ d·dout·ŷ4 -> stats4 ; Σ dout, Σ dout·ŝ -> statssc   (per out channel)
+#define RR_RU 2
 template <typename T>
-__global__ __launch_bounds__(256) void residual_bwd_reduce_kernel(LoadDesc xin, const T* y4, const T* dout,
+__global__ __launch_bounds__(STAT_NT) void residual_bwd_reduce_kernel(LoadDesc xin, const T* y4, const T* dout,
                                                                   const float* coef4, const float* coefsc,
                                                                   const float* dscale, ResGeom gm, double* stats4,
                                                                   double* statssc) {
@@ -449,7 +518,7 @@ __global__ __launch_bounds__(256) void residual_bwd_reduce_kernel(LoadDesc xin, 
     __shared__ float lstat[2 * NCV * KC];
     __shared__ float lstat2[2 * NCV * KC];
     if (tid < 2 * NCV * KC) { lstat[tid] = 0.f; lstat2[tid] = 0.f; }
-    __syncthreads();
+    RES_STAGE_TABLES(gm.hsrc, gm.Hout, gm.wsrc, gm.Wout)
     float a0[KC], a1[KC], b0[KC], b1[KC];
 #pragma unroll
     for (int i = 0; i < KC; ++i) { a0[i] = a1[i] = b0[i] = b1[i] = 0.f; }
@@ -458,26 +527,40 @@ __global__ __launch_bounds__(256) void residual_bwd_reduce_kernel(LoadDesc xin, 
         ld_coef<KC>(coef4 + 2 * gm.Cout + chan, m4); ld_coef<KC>(coef4 + 3 * gm.Cout + chan, i4);
         ld_coef<KC>(coefsc + 2 * gm.Cout + chan, ms); ld_coef<KC>(coefsc + 3 * gm.Cout + chan, is);
         const int csrc = chan % gm.Cin;
-        const i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
-        const i64 rows_per_b = (i64)gm.T * gm.Hout * gm.Wout;
-        for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
-            int wo = (int)(row % gm.Wout);
-            i64 r2 = row / gm.Wout;
-            int ho = (int)(r2 % gm.Hout);
-            i64 bt = r2 / gm.Hout;
-            i64 rin = (bt * gm.Hin + gm.hsrc[ho]) * gm.Win + gm.wsrc[wo];
-            float sv[KC], yv[KC], g[KC];
-            load_op<LD_PLAIN, T>(xin, rin, csrc, sv);
-            ld_vec<T>(y4 + row * gm.Cout + chan, yv);
-            ld_vec<T>(dout + row * gm.Cout + chan, g);
-            float d = dscale ? dscale[row / rows_per_b] : 1.0f;
+        const unsigned rows = (unsigned)gm.BT * gm.Hout * gm.Wout;
+        const RasterIdx ro(gm.Hout, gm.Wout);
+        const UDiv32 dT((unsigned)gm.T);
+        const T* xp = reinterpret_cast<const T*>(xin.p);
+        const unsigned stride = gridDim.x * (unsigned)(STAT_NT / NCV);
+        for (unsigned row0 = blockIdx.x * (unsigned)(STAT_NT / NCV) + pl; row0 < rows; row0 += RR_RU * stride) {
+            uint4 rs[RR_RU], ry[RR_RU], rg[RR_RU];
+            unsigned btv[RR_RU];
 #pragma unroll
-            for (int i = 0; i < KC; ++i) {
-                float gd = g[i] * d;
-                a0[i] += gd;
-                a1[i] += gd * (yv[i] - m4[i]) * i4[i];
-                b0[i] += g[i];
-                b1[i] += g[i] * (round_t<T>(sv[i]) - ms[i]) * is[i];
+            for (int u = 0; u < RR_RU; ++u) {
+                const unsigned row = row0 + u * stride < rows ? row0 + u * stride : row0;
+                int ho, wo;
+                ro.decode(row, btv[u], ho, wo);
+                const i64 rin = ((i64)btv[u] * gm.Hin + ht_[ho]) * gm.Win + wt_[wo];
+                rs[u] = *reinterpret_cast<const uint4*>(xp + rin * xin.ld + csrc);
+                ry[u] = *reinterpret_cast<const uint4*>(y4 + (i64)row * gm.Cout + chan);
+                rg[u] = *reinterpret_cast<const uint4*>(dout + (i64)row * gm.Cout + chan);
+            }
+#pragma unroll
+            for (int u = 0; u < RR_RU; ++u) {
+                if (row0 + u * stride >= rows) break;
+                float sv[KC], yv[KC], g[KC];
+                unpack16<T>(rs[u], sv);
+                unpack16<T>(ry[u], yv);
+                unpack16<T>(rg[u], g);
+                const float d = dscale ? dscale[dT.div(btv[u])] : 1.0f;
+#pragma unroll
+                for (int i = 0; i < KC; ++i) {
+                    float gd = g[i] * d;
+                    a0[i] += gd;
+                    a1[i] += gd * (yv[i] - m4[i]) * i4[i];
+                    b0[i] += g[i];
+                    b1[i] += g[i] * (sv[i] - ms[i]) * is[i];
+                }
             }
         }
     }
@@ -494,16 +577,29 @@ __global__ __launch_bounds__(256) void residual_bwd_dy4_kernel(const T* y4, cons
     if (!chan_ok) return;
     float a1[KC], a2[KC], a3[KC];
     ld_coef<KC>(abc4 + chan, a1); ld_coef<KC>(abc4 + gm.Cout + chan, a2); ld_coef<KC>(abc4 + 2 * gm.Cout + chan, a3);
-    const i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
-    const i64 rows_per_b = (i64)gm.T * gm.Hout * gm.Wout;
-    for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
-        float yv[KC], g[KC], o[KC];
-        ld_vec<T>(y4 + row * gm.Cout + chan, yv);
-        ld_vec<T>(dout + row * gm.Cout + chan, g);
-        float d = dscale ? dscale[row / rows_per_b] : 1.0f;
+    const unsigned rows = (unsigned)gm.BT * gm.Hout * gm.Wout;
+    const UDiv32 dS((unsigned)(gm.T * gm.Hout * gm.Wout));
+    const unsigned stride = gridDim.x * 32u;
+    for (unsigned row0 = blockIdx.x * 32u + pl; row0 < rows; row0 += RES_RU * stride) {
+        uint4 ry[RES_RU], rg[RES_RU];
 #pragma unroll
-        for (int i = 0; i < KC; ++i) o[i] = fmaf(a1[i], g[i] * d, fmaf(a2[i], yv[i], a3[i]));
-        st_vec<T>(dy4 + row * gm.Cout + chan, o);
+        for (int u = 0; u < RES_RU; ++u) {
+            const unsigned row = row0 + u * stride < rows ? row0 + u * stride : row0;
+            ry[u] = *reinterpret_cast<const uint4*>(y4 + (i64)row * gm.Cout + chan);
+            rg[u] = *reinterpret_cast<const uint4*>(dout + (i64)row * gm.Cout + chan);
+        }
+#pragma unroll
+        for (int u = 0; u < RES_RU; ++u) {
+            const unsigned row = row0 + u * stride;
+            if (row >= rows) break;
+            float yv[KC], g[KC], o[KC];
+            unpack16<T>(ry[u], yv);
+            unpack16<T>(rg[u], g);
+            const float d = dscale ? dscale[dS.div(row)] : 1.0f;
+#pragma unroll
+            for (int i = 0; i < KC; ++i) o[i] = fmaf(a1[i], g[i] * d, fmaf(a2[i], yv[i], a3[i]));
+            st_vec<T>(dy4 + (i64)row * gm.Cout + chan, o);
+        }
     }
 }
 
@@ -512,30 +608,45 @@ template <typename T>
 __global__ __launch_bounds__(256) void residual_bwd_dx_kernel(LoadDesc xin, const T* da0, const T* dout,
                                                               const float* abcsc, ResGeom gm, T* dx) {
     SLICE_SETUP(gm.Cin)
+    RES_STAGE_TABLES(gm.hinv, gm.Hin, gm.winv, gm.Win)
     if (!chan_ok) return;
-    const i64 rows = (i64)gm.BT * gm.Hin * gm.Win;
-    for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
-        int wi = (int)(row % gm.Win);
-        i64 r2 = row / gm.Win;
-        int hi = (int)(r2 % gm.Hin);
-        i64 bt = r2 / gm.Hin;
-        float o[KC];
-        ld_vec<T>(da0 + row * gm.Cin + chan, o);
-        int ho = gm.hinv[hi], wo = gm.winv[wi];
-        if (ho >= 0 && wo >= 0) {
-            i64 rout = (bt * gm.Hout + ho) * gm.Wout + wo;
-            float sv[KC];
-            load_op<LD_PLAIN, T>(xin, row, chan, sv);
-            for (int cc = chan; cc < gm.Cout; cc += gm.Cin) {
-                float g[KC], a1[KC], a2[KC], a3[KC];
-                ld_vec<T>(dout + rout * gm.Cout + cc, g);
-                ld_coef<KC>(abcsc + cc, a1); ld_coef<KC>(abcsc + gm.Cout + cc, a2);
-                ld_coef<KC>(abcsc + 2 * gm.Cout + cc, a3);
+    const unsigned rows = (unsigned)gm.BT * gm.Hin * gm.Win;
+    const RasterIdx ri(gm.Hin, gm.Win);
+    const T* xp = reinterpret_cast<const T*>(xin.p);
+    const unsigned stride = gridDim.x * 32u;
+    for (unsigned row0 = blockIdx.x * 32u + pl; row0 < rows; row0 += RES_RU * stride) {
+        uint4 ra[RES_RU], rx[RES_RU];
+        i64 routv[RES_RU];
 #pragma unroll
-                for (int i = 0; i < KC; ++i) o[i] += fmaf(a1[i], g[i], fmaf(a2[i], round_t<T>(sv[i]), a3[i]));
-            }
+        for (int u = 0; u < RES_RU; ++u) {
+            const unsigned row = row0 + u * stride < rows ? row0 + u * stride : row0;
+            unsigned bt; int hi, wi;
+            ri.decode(row, bt, hi, wi);
+            const int ho = ht_[hi], wo = wt_[wi];
+            routv[u] = (ho >= 0 && wo >= 0) ? ((i64)bt * gm.Hout + ho) * gm.Wout + wo : -1;
+            ra[u] = *reinterpret_cast<const uint4*>(da0 + (i64)row * gm.Cin + chan);
+            rx[u] = *reinterpret_cast<const uint4*>(xp + (i64)row * xin.ld + chan);
         }
-        st_vec<T>(dx + row * gm.Cin + chan, o);
+#pragma unroll
+        for (int u = 0; u < RES_RU; ++u) {
+            const unsigned row = row0 + u * stride;
+            if (row >= rows) break;
+            float o[KC];
+            unpack16<T>(ra[u], o);
+            if (routv[u] >= 0) {
+                float sv[KC];
+                unpack16<T>(rx[u], sv);
+                for (int cc = chan; cc < gm.Cout; cc += gm.Cin) {
+                    float g[KC], a1[KC], a2[KC], a3[KC];
+                    ld_vec<T>(dout + routv[u] * gm.Cout + cc, g);
+                    ld_coef<KC>(abcsc + cc, a1); ld_coef<KC>(abcsc + gm.Cout + cc, a2);
+                    ld_coef<KC>(abcsc + 2 * gm.Cout + cc, a3);
+#pragma unroll
+                    for (int i = 0; i < KC; ++i) o[i] += fmaf(a1[i], g[i], fmaf(a2[i], sv[i], a3[i]));
+                }
+            }
+            st_vec<T>(dx + (i64)row * gm.Cin + chan, o);
+        }
     }
 }
 
@@ -543,8 +654,8 @@ __global__ __launch_bounds__(256) void residual_bwd_dx_kernel(LoadDesc xin, cons
 int k_shortcut_stats(const LoadDesc& xin, const ResGeom& gm, double* stats, int dtype, hipStream_t s) {
     i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL((shortcut_stats_kernel<bf16_t>), resident_slice_grid(shortcut_stats_kernel<bf16_t>, rows, gm.Cin, 8), dim3(256), 0, s, xin, gm, stats),
-        hipLaunchKernelGGL((shortcut_stats_kernel<float>), resident_slice_grid(shortcut_stats_kernel<float>, rows, gm.Cin, 4), dim3(256), 0, s, xin, gm, stats));
+        hipLaunchKernelGGL((shortcut_stats_kernel<bf16_t>), fat_slice_grid(rows, gm.Cin, 8), dim3(STAT_NT), 0, s, xin, gm, stats),
+        hipLaunchKernelGGL((shortcut_stats_kernel<float>), fat_slice_grid(rows, gm.Cin, 4), dim3(STAT_NT), 0, s, xin, gm, stats));
     DWN_CHECK_LAUNCH();
     return 0;
 }
@@ -563,8 +674,8 @@ int k_residual_bwd_reduce(const LoadDesc& xin, const void* y4, const void* dout,
                           double* statssc, int dtype, hipStream_t s) {
     i64 rows = (i64)gm.BT * gm.Hout * gm.Wout;
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL((residual_bwd_reduce_kernel<bf16_t>), resident_slice_grid(residual_bwd_reduce_kernel<bf16_t>, rows, gm.Cout, 8), dim3(256), 0, s, xin, (const bf16_t*)y4, (const bf16_t*)dout, coef4, coefsc, dscale, gm, stats4, statssc),
-        hipLaunchKernelGGL((residual_bwd_reduce_kernel<float>), resident_slice_grid(residual_bwd_reduce_kernel<float>, rows, gm.Cout, 4), dim3(256), 0, s, xin, (const float*)y4, (const float*)dout, coef4, coefsc, dscale, gm, stats4, statssc));
+        hipLaunchKernelGGL((residual_bwd_reduce_kernel<bf16_t>), fat_slice_grid(rows, gm.Cout, 8), dim3(STAT_NT), 0, s, xin, (const bf16_t*)y4, (const bf16_t*)dout, coef4, coefsc, dscale, gm, stats4, statssc),
+        hipLaunchKernelGGL((residual_bwd_reduce_kernel<float>), fat_slice_grid(rows, gm.Cout, 4), dim3(STAT_NT), 0, s, xin, (const float*)y4, (const float*)dout, coef4, coefsc, dscale, gm, stats4, statssc));
     DWN_CHECK_LAUNCH();
     return 0;
 }
@@ -739,29 +850,38 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// RP = compile-time bound on R (16 / 32 / 64), walked in register blocks of RB = min(RP, 32) hidden units (64
+// accumulators per thread spill).  Hidden units r >= R re-read row R-1 (clamped index) and are ignored: every load of
+// the squeeze layer is unconditional, so all RB x C/256 of them are in flight together.
+template <int RP>
 __global__ __launch_bounds__(256) void se_mlp_fwd_fast_kernel(const float* pooled_sum, float inv_s, const float* wr,
                                                               const float* br, const float* we, const float* be, int C,
                                                               int R, float* pmean, float* hid_pre, float* gate) {
-    __shared__ float hid[SE_RT];
+    constexpr int RB = RP < 32 ? RP : 32;
+    __shared__ float hid[RP];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int split = gridDim.y, part = blockIdx.y;
-    if (tid < SE_RT) hid[tid] = 0.f;
+    if (tid < RP) hid[tid] = 0.f;
     __syncthreads();
-    float acc[SE_RT];
+#pragma unroll 1
+    for (int r0 = 0; r0 < RP; r0 += RB) {
+        if (r0 >= R) break;
+        float acc[RB];
 #pragma unroll
-    for (int r = 0; r < SE_RT; ++r) acc[r] = 0.f;
-    for (int c = tid; c < C; c += 256) {
-        const float v = pooled_sum[(i64)b * C + c] * inv_s;
-        if (part == 0) pmean[(i64)b * C + c] = v;
+        for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+        for (int c = tid; c < C; c += 256) {
+            const float v = pooled_sum[(i64)b * C + c] * inv_s;
+            if (part == 0 && r0 == 0) pmean[(i64)b * C + c] = v;
 #pragma unroll
-        for (int r = 0; r < SE_RT; ++r)
-            if (r < R) acc[r] = fmaf(wr[(i64)r * C + c], v, acc[r]);
-    }
+            for (int r = 0; r < RB; ++r) {
+                const int rr = r0 + r < R ? r0 + r : R - 1;
+                acc[r] = fmaf(wr[(i64)rr * C + c], v, acc[r]);
+            }
+        }
 #pragma unroll
-    for (int r = 0; r < SE_RT; ++r) {
-        if (r < R) {
+        for (int r = 0; r < RB; ++r) {
             const float t = wave_sum(acc[r]);
-            if (lane == 0) atomicAdd(&hid[r], t);
+            if (lane == 0 && r0 + r < R) atomicAdd(&hid[r0 + r], t);
         }
     }
     __syncthreads();
@@ -776,37 +896,70 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_fast_kernel(const float* poole
     for (int c = part * per + tid; c < c_end; c += 256) {
         float a = be[c];
         const float* wrow = we + (i64)c * R;
-#pragma unroll 8
-        for (int r = 0; r < R; ++r) a = fmaf(wrow[r], hid[r], a);
+#pragma unroll 1
+        for (int r0 = 0; r0 < RP; r0 += 16) {
+            if (r0 >= R) break;
+            float wv[16];
+            if ((R & 3) == 0) {        // rows of `we` are 16-byte aligned: 4x fewer (uncoalesced, stride R) requests
+                const float4* w4 = reinterpret_cast<const float4*>(wrow);
+                const int nq = R >> 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int qi = (r0 >> 2) + q;
+                    const float4 t = w4[qi < nq ? qi : nq - 1];
+                    wv[4 * q] = t.x; wv[4 * q + 1] = t.y; wv[4 * q + 2] = t.z; wv[4 * q + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) wv[r] = wrow[r0 + r < R ? r0 + r : R - 1];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a = fmaf(wv[r], r0 + r < R ? hid[r0 + r] : 0.f, a);
+        }
         gate[(i64)b * C + c] = sigmoidf_(a);
     }
 }
 
+template <int RP>
 __global__ __launch_bounds__(256) void se_mlp_bwd_fast_kernel(const float* dg, const float* gate, const float* hid_pre,
                                                               const float* wr, const float* we, int C, int R,
                                                               float inv_s, float* dgp_out, float* dhp_out, float* dps) {
-    __shared__ float dhp[SE_RT];
+    constexpr int RB = RP < 32 ? RP : 32;
+    __shared__ float dhp[RP];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int split = gridDim.y, part = blockIdx.y;
-    if (tid < SE_RT) dhp[tid] = 0.f;
+    if (tid < RP) dhp[tid] = 0.f;
     __syncthreads();
-    float acc[SE_RT];
+#pragma unroll 1
+    for (int r0 = 0; r0 < RP; r0 += RB) {
+        if (r0 >= R) break;
+        float acc[RB];
 #pragma unroll
-    for (int r = 0; r < SE_RT; ++r) acc[r] = 0.f;
-    for (int c = tid; c < C; c += 256) {
-        const float g = gate[(i64)b * C + c];
-        const float v = dg[(i64)b * C + c] * g * (1.f - g);
-        if (part == 0) dgp_out[(i64)b * C + c] = v;
-        const float* wrow = we + (i64)c * R;
+        for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+        for (int c = tid; c < C; c += 256) {
+            const float g = gate[(i64)b * C + c];
+            const float v = dg[(i64)b * C + c] * g * (1.f - g);
+            if (part == 0 && r0 == 0) dgp_out[(i64)b * C + c] = v;
+            const float* wrow = we + (i64)c * R;
+            if ((R & 3) == 0 && (RB & 3) == 0) {
+                const float4* w4 = reinterpret_cast<const float4*>(wrow);
+                const int nq = R >> 2;
 #pragma unroll
-        for (int r = 0; r < SE_RT; ++r)
-            if (r < R) acc[r] = fmaf(wrow[r], v, acc[r]);
-    }
+                for (int q = 0; q < RB / 4; ++q) {
+                    const int qi = (r0 >> 2) + q;
+                    const float4 t = w4[qi < nq ? qi : nq - 1];
+                    acc[4 * q] = fmaf(t.x, v, acc[4 * q]); acc[4 * q + 1] = fmaf(t.y, v, acc[4 * q + 1]);
+                    acc[4 * q + 2] = fmaf(t.z, v, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(t.w, v, acc[4 * q + 3]);
+                }
+            } else {
 #pragma unroll
-    for (int r = 0; r < SE_RT; ++r) {
-        if (r < R) {
+                for (int r = 0; r < RB; ++r) acc[r] = fmaf(wrow[r0 + r < R ? r0 + r : R - 1], v, acc[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
             const float t = wave_sum(acc[r]);
-            if (lane == 0) atomicAdd(&dhp[r], t);
+            if (lane == 0 && r0 + r < R) atomicAdd(&dhp[r0 + r], t);
         }
     }
     __syncthreads();
@@ -820,8 +973,15 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_fast_kernel(const float* dg, c
     const int c_end = (part + 1) * per < C ? (part + 1) * per : C;
     for (int c = part * per + tid; c < c_end; c += 256) {
         float a = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < R; ++r) a = fmaf(wr[(i64)r * C + c], dhp[r], a);
+#pragma unroll 1
+        for (int r0 = 0; r0 < RP; r0 += 16) {
+            if (r0 >= R) break;
+            float wv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wv[r] = wr[(i64)(r0 + r < R ? r0 + r : R - 1) * C + c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a = fmaf(wv[r], r0 + r < R ? dhp[r0 + r] : 0.f, a);
+        }
         dps[(i64)b * C + c] = a * inv_s;
     }
 }
@@ -853,8 +1013,14 @@ __global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const float* dgp, con
 
 int k_se_mlp_fwd(const float* pooled_sum, float inv_s, const float* wr, const float* br, const float* we,
                  const float* be, int B, int C, int R, float* pmean, float* hid_pre, float* gate, hipStream_t s) {
-    if (R <= SE_RT)
-        hipLaunchKernelGGL(se_mlp_fwd_fast_kernel, dim3(B, 8), dim3(256), 0, s, pooled_sum, inv_s, wr, br, we, be, C, R,
+    if (R <= 16)
+        hipLaunchKernelGGL(se_mlp_fwd_fast_kernel<16>, dim3(B, 8), dim3(256), 0, s, pooled_sum, inv_s, wr, br, we, be, C, R,
+                           pmean, hid_pre, gate);
+    else if (R <= 32)
+        hipLaunchKernelGGL(se_mlp_fwd_fast_kernel<32>, dim3(B, 8), dim3(256), 0, s, pooled_sum, inv_s, wr, br, we, be, C, R,
+                           pmean, hid_pre, gate);
+    else if (R <= SE_RT)
+        hipLaunchKernelGGL(se_mlp_fwd_fast_kernel<SE_RT>, dim3(B, 8), dim3(256), 0, s, pooled_sum, inv_s, wr, br, we, be, C, R,
                            pmean, hid_pre, gate);
     else
         hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(B, 8), dim3(256), (C + R) * sizeof(float), s, pooled_sum, inv_s, wr, br,
@@ -865,9 +1031,15 @@ int k_se_mlp_fwd(const float* pooled_sum, float inv_s, const float* wr, const fl
 int k_se_mlp_bwd(const float* dg, const float* gate, const float* hid_pre, const float* pmean, const float* wr,
                  const float* we, int B, int C, int R, float inv_s, float* dgp, float* dhp, float* dps, float* dwr,
                  float* dbr, float* dwe, float* dbe, hipStream_t s) {
-    if (R <= SE_RT)
-        hipLaunchKernelGGL(se_mlp_bwd_fast_kernel, dim3(B, 8), dim3(256), 0, s, dg, gate, hid_pre, wr, we, C, R, inv_s, dgp,
+    if (R <= 16)
+        hipLaunchKernelGGL(se_mlp_bwd_fast_kernel<16>, dim3(B, 8), dim3(256), 0, s, dg, gate, hid_pre, wr, we, C, R, inv_s, dgp,
                            dhp, dps);
+    else if (R <= 32)
+        hipLaunchKernelGGL(se_mlp_bwd_fast_kernel<32>, dim3(B, 8), dim3(256), 0, s, dg, gate, hid_pre, wr, we, C, R, inv_s, dgp,
+                           dhp, dps);
+    else if (R <= SE_RT)
+        hipLaunchKernelGGL(se_mlp_bwd_fast_kernel<SE_RT>, dim3(B, 8), dim3(256), 0, s, dg, gate, hid_pre, wr, we, C, R, inv_s,
+                           dgp, dhp, dps);
     else
         hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(B, 8), dim3(256), (C + R) * sizeof(float), s, dg, gate, hid_pre, wr, we,
                            C, R, inv_s, dgp, dhp, dps);
