@@ -231,6 +231,202 @@ __global__ __launch_bounds__(NT, 4) void dw_spatial_fwd_kernel(const DwSpatialFw
 }
 
 // ------------------------------------------------------------------------------------------------
+// spatial forward, bf16 storage, 3x3, stride 1 or 2: x-pair-packed LDS tile + v_dot2c_f32_bf16.
+//
+// The activated input is staged as dwords holding two horizontally adjacent pixels of one channel,
+// tile[row][xp][c] = (z[row][2xp][c], z[row][2xp+1][c])  (xs = wi + 1 is the zero-padded column index).
+// A 3-tap row of the stencil is then 2 dot2 instructions on packed operands — dot2(P[j], (w0,w1)) +
+// dot2(P[j+1], (w2,0)) for an even output column, dot2(P[j], (0,w0)) + dot2(P[j+1], (w1,w2)) for an odd one —
+// instead of 3 bf16->fp32 unpacks + 1.5 packed FMAs per channel, and a thread's 4 channels of a pixel pair are
+// one ds_read_b128.  Weights are rounded to bf16 (as the reference's autocast conv does); accumulation is fp32.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+template <int ST, int NT>
+__global__ __launch_bounds__(NT, 4) void dw_spatial_fwd_pair_kernel(const DwSpatialFwd a) {
+    typedef bf16_t T;
+    constexpr int NCV = 16, CS = 64, LP = NT / NCV, P = 1;
+    constexpr int NWC = ST == 1 ? 4 : 2;                 // packed weight combinations per stencil row
+    __shared__ float lstat[2 * CS];
+    const int tid = threadIdx.x;
+    const int cv = tid % NCV, pl = tid / NCV;
+    const int c0 = blockIdx.y * CS;
+    const int chan = c0 + cv * 4;
+    const bool chan_ok = chan < a.C;
+    const int chs = chan_ok ? chan : 0;
+    if (tid < 2 * CS) lstat[tid] = 0.f;
+    __syncthreads();
+
+    // packed weights per stencil row dy and channel: A = (w0,w1), B = (w2,0) [, C = (0,w0), D = (w1,w2)]
+    unsigned wp[3][NWC][4];
+    {
+        float w[9][4];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            ldc4(a.w + (i64)k * a.C + chs, w[k]);
+            if (!chan_ok) { w[k][0] = w[k][1] = w[k][2] = w[k][3] = 0.f; }
+        }
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                wp[dy][0][q] = pack_bf16x2(w[dy * 3 + 0][q], w[dy * 3 + 1][q]);
+                wp[dy][1][q] = pack_bf16x2(w[dy * 3 + 2][q], 0.f);
+                if constexpr (ST == 1) {
+                    wp[dy][2][q] = pack_bf16x2(0.f, w[dy * 3 + 0][q]);
+                    wp[dy][3][q] = pack_bf16x2(w[dy * 3 + 1][q], w[dy * 3 + 2][q]);
+                }
+            }
+    }
+    f2_t st0[2] = {f2_t{0.f, 0.f}, f2_t{0.f, 0.f}}, st1[2] = {f2_t{0.f, 0.f}, f2_t{0.f, 0.f}};
+
+    const int Wp = a.Win + 2 * P;
+    const int Wpp = (Wp + 1) >> 1;                       // staged pixel pairs per row
+    const int Wop = (a.Wout + 1) >> 1;                   // output pixel pairs per row
+    const FastDiv dvpp(Wpp), dvop(Wop);
+    const int nbands = (a.Hout + a.rows_band - 1) / a.rows_band;
+    const int ntiles = a.planes * nbands;
+    const T* inp = reinterpret_cast<const T*>(a.in.p);
+    T* outp = reinterpret_cast<T*>(a.out);
+    unsigned* tile = reinterpret_cast<unsigned*>(dyn_smem);          // [rows_in][Wpp][64] dwords
+    // staging role: 8 channels x one pixel pair
+    constexpr int SV = 8, LPS = NT / SV, NB = 4;
+    const int scv = tid % SV, spl = tid / SV;
+    const int sch = c0 + scv * 8;
+    const bool sch_ok = sch < a.C;
+    const int schs = sch_ok ? sch : 0;
+    f2_t s8[4], t8[4];
+    {
+        float sf[8], tf[8];
+        ldc4(a.in.v1 + schs, sf); ldc4(a.in.v1 + schs + 4, sf + 4);
+        ldc4(a.in.v2 + schs, tf); ldc4(a.in.v2 + schs + 4, tf + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s8[i] = f2_t{sf[2 * i], sf[2 * i + 1]}; t8[i] = f2_t{tf[2 * i], tf[2 * i + 1]}; }
+    }
+    for (int tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+        const int plane = tile_id / nbands, band = tile_id % nbands;
+        const int ho0 = band * a.rows_band;
+        const int nro = (a.Hout - ho0 < a.rows_band) ? a.Hout - ho0 : a.rows_band;
+        const int hi0 = ho0 * ST - P;
+        const int rows_in = (nro - 1) * ST + 3;
+        const i64 plane_row0 = (i64)plane * a.Hin * a.Win;
+        const int total_st = rows_in * Wpp;
+        const T* in0 = inp + plane_row0 * a.in.ld + schs;
+        for (int f0 = spl; f0 < total_st; f0 += NB * LPS) {
+            uint4 ra[NB], rb[NB];
+            unsigned msk[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int f = f0 + u * LPS;
+                const int r = dvpp.div(f);
+                const int xp = dvpp.rem(f, r);
+                const int hi = hi0 + r, wi0 = 2 * xp - P;
+                const bool rok = sch_ok && f < total_st && (unsigned)hi < (unsigned)a.Hin;
+                const bool ok0 = rok && (unsigned)wi0 < (unsigned)a.Win, ok1 = rok && (unsigned)(wi0 + 1) < (unsigned)a.Win;
+                const int rowpix = __mul24(hi, a.Win);
+                ra[u] = *reinterpret_cast<const uint4*>(in0 + (ok0 ? __umul24((unsigned)(rowpix + wi0), (unsigned)a.in.ld) : 0u));
+                rb[u] = *reinterpret_cast<const uint4*>(in0 + (ok1 ? __umul24((unsigned)(rowpix + wi0 + 1), (unsigned)a.in.ld) : 0u));
+                msk[u] = (ok0 ? 0x0000ffffu : 0u) | (ok1 ? 0xffff0000u : 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int f = f0 + u * LPS;
+                if (f < total_st) {
+                    const unsigned wa[4] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w};
+                    const unsigned wb[4] = {rb[u].x, rb[u].y, rb[u].z, rb[u].w};
+                    unsigned o[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f2_t ya = f2_t{__uint_as_float(wa[i] << 16), __uint_as_float(wa[i] & 0xffff0000u)};
+                        const f2_t yb = f2_t{__uint_as_float(wb[i] << 16), __uint_as_float(wb[i] & 0xffff0000u)};
+                        const f2_t ha = ya * s8[i] + t8[i], hb = yb * s8[i] + t8[i];
+                        const f2_t za = ha * f2_t{sigmoidf_(ha.x), sigmoidf_(ha.y)};
+                        const f2_t zb = hb * f2_t{sigmoidf_(hb.x), sigmoidf_(hb.y)};
+                        o[2 * i] = pack_bf16x2(za.x, zb.x) & msk[u];
+                        o[2 * i + 1] = pack_bf16x2(za.y, zb.y) & msk[u];
+                    }
+                    uint4* dst = reinterpret_cast<uint4*>(tile + f * CS + scv * 8);
+                    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int total = nro * Wop;
+            const i64 orow0 = ((i64)plane * a.Hout + ho0) * a.Wout;
+            T* out0 = outp + orow0 * a.C + chan;
+            const int rowdw = Wpp * CS;                  // dwords per staged row
+            for (int i = pl; i < total; i += LP) {
+                const int oy = dvop.div(i);
+                const int j = dvop.rem(i, oy);
+                const int ox0 = 2 * j;
+                float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (ST == 1) {
+                    const unsigned* tp = tile + (__mul24(oy, Wpp) + j) * CS + cv * 4;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const uint4 p0 = *reinterpret_cast<const uint4*>(tp + dy * rowdw);
+                        const uint4 p1 = *reinterpret_cast<const uint4*>(tp + dy * rowdw + CS);
+                        const unsigned a0[4] = {p0.x, p0.y, p0.z, p0.w}, a1[4] = {p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc0[q] = dot2_bf16(a0[q], wp[dy][0][q], acc0[q]);
+                            acc0[q] = dot2_bf16(a1[q], wp[dy][1][q], acc0[q]);
+                            acc1[q] = dot2_bf16(a0[q], wp[dy][2][q], acc1[q]);
+                            acc1[q] = dot2_bf16(a1[q], wp[dy][3][q], acc1[q]);
+                        }
+                    }
+                } else {
+                    // stride 2: output ox reads staged columns 2ox .. 2ox+2 = P[ox] and the low half of P[ox+1]
+                    const int jp2 = (ox0 + 2 < Wpp) ? 2 : 1;      // P[ox0+2] only feeds the (possibly invalid) odd output
+                    const unsigned* tp = tile + (__mul24(oy * 2, Wpp) + ox0) * CS + cv * 4;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const uint4 p0 = *reinterpret_cast<const uint4*>(tp + dy * rowdw);
+                        const uint4 p1 = *reinterpret_cast<const uint4*>(tp + dy * rowdw + CS);
+                        const uint4 p2 = *reinterpret_cast<const uint4*>(tp + dy * rowdw + jp2 * CS);
+                        const unsigned a0[4] = {p0.x, p0.y, p0.z, p0.w}, a1[4] = {p1.x, p1.y, p1.z, p1.w};
+                        const unsigned a2[4] = {p2.x, p2.y, p2.z, p2.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc0[q] = dot2_bf16(a0[q], wp[dy][0][q], acc0[q]);
+                            acc0[q] = dot2_bf16(a1[q], wp[dy][1][q], acc0[q]);
+                            acc1[q] = dot2_bf16(a1[q], wp[dy][0][q], acc1[q]);
+                            acc1[q] = dot2_bf16(a2[q], wp[dy][1][q], acc1[q]);
+                        }
+                    }
+                }
+                if (chan_ok) {
+                    const unsigned pix = (unsigned)(__mul24(oy, a.Wout) + ox0);
+                    const uint2 pk0 = make_uint2(pack_bf16x2(acc0[0], acc0[1]), pack_bf16x2(acc0[2], acc0[3]));
+                    T* dst = out0 + __umul24(pix, (unsigned)a.C);
+                    *reinterpret_cast<uint2*>(dst) = pk0;
+                    f2_t r0, r1;
+                    unpack_pairs<T>(pk0, r0, r1);
+                    st0[0] += r0; st0[1] += r1; st1[0] += r0 * r0; st1[1] += r1 * r1;
+                    if (ox0 + 1 < a.Wout) {
+                        const uint2 pk1 = make_uint2(pack_bf16x2(acc1[0], acc1[1]), pack_bf16x2(acc1[2], acc1[3]));
+                        *reinterpret_cast<uint2*>(dst + a.C) = pk1;
+                        unpack_pairs<T>(pk1, r0, r1);
+                        st0[0] += r0; st0[1] += r1; st1[0] += r0 * r0; st1[1] += r1 * r1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (a.stats) {
+        const float s0[4] = {st0[0].x, st0[0].y, st0[1].x, st0[1].y}, s1[4] = {st1[0].x, st1[0].y, st1[1].x, st1[1].y};
+        block_stats_flush<T>(lstat, s0, s1, cv, c0, a.C, a.stats, blockIdx.x % DWN_NREP);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // spatial backward: dh1 = (dwS^T dy2) * silu'(h1), dW, Σdh1, Σdh1·ŷ1
 // ------------------------------------------------------------------------------------------------
 template <typename T, int KS, int ST>
@@ -759,7 +955,12 @@ static int spatial_fwd_t(DwSpatialFwd a, hipStream_t s) {
     if (a.ks != 3) return dwn_set_error(-4, "dw_spatial: only spatial_kernel=3 is built");
     if (a.C % 8) return dwn_set_error(-2, "dw_spatial: C must be a multiple of 8");
     const int Wp = a.Win + 2;
-    auto tile_bytes = [&](int rb) { return (size_t)((rb - 1) * a.stride + 3) * Wp * 128; };
+    // bf16, stride 1/2: x-pair-packed tile (dot2 kernel), rows of ceil(Wp/2) pairs x 256 bytes
+    static const bool pair_off = getenv("DWN_DWS_NOPAIR") != nullptr;
+    const bool pair = TT<T>::IS_BF16 && (a.stride == 1 || a.stride == 2) && !pair_off;
+    auto tile_bytes = [&](int rb) {
+        return pair ? (size_t)((rb - 1) * a.stride + 3) * ((Wp + 1) / 2) * 256 : (size_t)((rb - 1) * a.stride + 3) * Wp * 128;
+    };
     if (a.rows_band <= 0) {
         // largest band whose tile fits the LDS budget: fewer halo rows re-read, fewer barriers per byte
         int rb = 1;
@@ -778,6 +979,18 @@ static int spatial_fwd_t(DwSpatialFwd a, hipStream_t s) {
 #define DWS_FWD_LAUNCH(ST_, NT_) do { \
         dim3 grid(resident_grid_x(dw_spatial_fwd_kernel<T, 3, ST_, NT_>, lds, slices, work, NT_), slices); \
         hipLaunchKernelGGL((dw_spatial_fwd_kernel<T, 3, ST_, NT_>), grid, dim3(NT_), lds, s, a); } while (0)
+    if constexpr (TT<T>::IS_BF16) {
+        if (pair) {
+#define DWS_PAIR_LAUNCH(ST_, NT_) do { \
+        dim3 grid(resident_grid_x(dw_spatial_fwd_pair_kernel<ST_, NT_>, lds, slices, work, NT_), slices); \
+        hipLaunchKernelGGL((dw_spatial_fwd_pair_kernel<ST_, NT_>), grid, dim3(NT_), lds, s, a); } while (0)
+            if (a.stride == 1) { if (big) DWS_PAIR_LAUNCH(1, 512); else DWS_PAIR_LAUNCH(1, 256); }
+            else { if (big) DWS_PAIR_LAUNCH(2, 512); else DWS_PAIR_LAUNCH(2, 256); }
+#undef DWS_PAIR_LAUNCH
+            DWN_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (a.stride == 1) { if (big) DWS_FWD_LAUNCH(1, 512); else DWS_FWD_LAUNCH(1, 256); }
     else if (a.stride == 2) { if (big) DWS_FWD_LAUNCH(2, 512); else DWS_FWD_LAUNCH(2, 256); }
     else DWS_FWD_LAUNCH(0, 256);
