@@ -1002,6 +1002,223 @@ int launch_dw_spatial_fwd(const DwSpatialFwd& a, int dtype, hipStream_t s) {
     return dtype == DWN_BF16 ? spatial_fwd_t<bf16_t>(a, s) : spatial_fwd_t<float>(a, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// spatial backward, bf16 storage, 3x3, stride 1: x-pair-packed gradient tile + v_dot2c_f32_bf16.
+//
+// The staged gradient g = dL/dy2 (BatchNorm-backward affine applied, zero halo; column index xq = wo + 1) is
+// packed as G[k] = (g[2k], g[2k+1]) per channel.  A thread owns the input pixel pair (2j, 2j+1) of a row:
+//   dz[2j]   = dot2(G[j], (w2,w1)) + dot2(G[j+1], (w0,0))         dz[2j+1] = dot2(G[j], (0,w2)) + dot2(G[j+1], (w1,w0))
+//   dW[.,2] += dot2(Z, G[j])      dW[.,0] += dot2(Z, G[j+1])      dW[.,1] += dot2(Z, (G[j].hi, G[j+1].lo))
+// with Z = (z1[2j], z1[2j+1]) rounded to bf16 (the reference's autocast stores z1 in bf16): 8 VALU ops per stencil row,
+// channel and pixel pair instead of 6 unpacks + 6 packed FMAs.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DWS_BWD_THREADS, 3) void dw_spatial_bwd_pair_kernel(const DwSpatialBwd a) {
+    typedef bf16_t T;
+    constexpr int NT = DWS_BWD_THREADS, NCV = 16, CS = 64, LP = NT / NCV, KS = 3, P = 1;
+    __shared__ float lstat[2 * CS];
+    __shared__ __attribute__((aligned(16))) float lw[KS * KS * CS];          // dW reduction at the end
+    __shared__ __attribute__((aligned(16))) unsigned lwp[3 * 4 * CS];        // packed weights [dy][combo][channel]
+    const int tid = threadIdx.x;
+    const int cv = tid % NCV, pl = tid / NCV;
+    const int c0 = blockIdx.y * CS;
+    const int chan = c0 + cv * 4;
+    const bool chan_ok = chan < a.C;
+    const int chs = chan_ok ? chan : 0;
+    if (tid < 2 * CS) lstat[tid] = 0.f;
+    for (int i = tid; i < 3 * CS; i += NT) {
+        const int dy = i / CS, cc = i % CS, c = c0 + cc;
+        float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+        if (c < a.C) { w0 = a.w[(i64)(dy * 3 + 0) * a.C + c]; w1 = a.w[(i64)(dy * 3 + 1) * a.C + c]; w2 = a.w[(i64)(dy * 3 + 2) * a.C + c]; }
+        lwp[(dy * 4 + 0) * CS + cc] = pack_bf16x2(w2, w1);
+        lwp[(dy * 4 + 1) * CS + cc] = pack_bf16x2(w0, 0.f);
+        lwp[(dy * 4 + 2) * CS + cc] = pack_bf16x2(0.f, w2);
+        lwp[(dy * 4 + 3) * CS + cc] = pack_bf16x2(w1, w0);
+    }
+    __syncthreads();
+
+    float dwp[KS * KS][4];
+#pragma unroll
+    for (int k = 0; k < KS * KS; ++k) { dwp[k][0] = dwp[k][1] = dwp[k][2] = dwp[k][3] = 0.f; }
+    float bs[4], bt[4], bm[4], bi[4];
+    ldc4(a.y1.v1 + chs, bs); ldc4(a.y1.v2 + chs, bt); ldc4(a.y1.v3 + chs, bm); ldc4(a.y1.v4 + chs, bi);
+    const f2_t bs2[2] = {f2_t{bs[0], bs[1]}, f2_t{bs[2], bs[3]}}, bt2[2] = {f2_t{bt[0], bt[1]}, f2_t{bt[2], bt[3]}};
+    const f2_t bi2[2] = {f2_t{bi[0], bi[1]}, f2_t{bi[2], bi[3]}};
+    const f2_t nbm2[2] = {f2_t{-bm[0] * bi[0], -bm[1] * bi[1]}, f2_t{-bm[2] * bi[2], -bm[3] * bi[3]}};   // yhat = y*bi + nbm
+    f2_t sp0[2] = {f2_t{0.f, 0.f}, f2_t{0.f, 0.f}}, sp1[2] = {f2_t{0.f, 0.f}, f2_t{0.f, 0.f}};
+
+    const int Wq = a.Wout + 2;                       // staged columns wo = -1 .. Wout
+    const int Wqp = (Wq + 1) >> 1;                   // ... as pairs
+    const int Wip = (a.Win + 1) >> 1;                // input pixel pairs per row
+    const FastDiv dvq(Wqp), dvw(Wip);
+    const int nbands = (a.Hin + a.rows_band - 1) / a.rows_band;
+    const int ntiles = a.planes * nbands;
+    T* dhp = reinterpret_cast<T*>(a.dh1);
+    const T* y1p = reinterpret_cast<const T*>(a.y1.p);
+    const T* dpp = reinterpret_cast<const T*>(a.dy.p);
+    const T* dqp = reinterpret_cast<const T*>(a.dy.q);
+    unsigned* tile = reinterpret_cast<unsigned*>(dyn_smem);      // [rows_q][Wqp][64] dwords
+    const int rowdw = Wqp * CS;
+    for (int tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+        const int plane = tile_id / nbands, band = tile_id % nbands;
+        const int hi0 = band * a.rows_band;
+        const int nri = (a.Hin - hi0 < a.rows_band) ? a.Hin - hi0 : a.rows_band;
+        const int ho_lo = hi0 - 1;                   // stride 1: rows ho = hi - 1 .. hi + 1
+        const int rows_q = nri + 2;
+        const i64 orow0 = (i64)plane * a.Hout * a.Wout;
+        {
+            constexpr int NB = 4;
+            const int total_st = rows_q * Wqp;
+            float a1[4], a2[4], a3[4];
+            ldc4(a.dy.v1 + chs, a1); ldc4(a.dy.v2 + chs, a2); ldc4(a.dy.v3 + chs, a3);
+            const f2_t a1v[2] = {f2_t{a1[0], a1[1]}, f2_t{a1[2], a1[3]}}, a2v[2] = {f2_t{a2[0], a2[1]}, f2_t{a2[2], a2[3]}};
+            const f2_t a3v[2] = {f2_t{a3[0], a3[1]}, f2_t{a3[2], a3[3]}};
+            const T* dp0 = dpp + orow0 * a.dy.ld + chs;
+            const T* dq0 = dqp + orow0 * a.dy.ld + chs;
+            for (int f0 = pl; f0 < total_st; f0 += NB * LP) {
+                uint2 rp[NB][2], rq[NB][2];
+                unsigned msk[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int f = f0 + u * LP;
+                    const int r = dvq.div(f);
+                    const int xp = dvq.rem(f, r);
+                    const int ho = ho_lo + r, wo0 = 2 * xp - 1;
+                    const bool rok = chan_ok && f < total_st && (unsigned)ho < (unsigned)a.Hout;
+                    const bool ok0 = rok && (unsigned)wo0 < (unsigned)a.Wout, ok1 = rok && (unsigned)(wo0 + 1) < (unsigned)a.Wout;
+                    const int rowpix = __mul24(ho, a.Wout);
+                    const unsigned off0 = ok0 ? __umul24((unsigned)(rowpix + wo0), (unsigned)a.dy.ld) : 0u;
+                    const unsigned off1 = ok1 ? __umul24((unsigned)(rowpix + wo0 + 1), (unsigned)a.dy.ld) : 0u;
+                    rp[u][0] = ld4_raw<T>(dp0 + off0); rq[u][0] = ld4_raw<T>(dq0 + off0);
+                    rp[u][1] = ld4_raw<T>(dp0 + off1); rq[u][1] = ld4_raw<T>(dq0 + off1);
+                    msk[u] = (ok0 ? 0x0000ffffu : 0u) | (ok1 ? 0xffff0000u : 0u);
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int f = f0 + u * LP;
+                    if (f < total_st) {
+                        f2_t g[2][2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            f2_t p0, p1, q0, q1;
+                            unpack_pairs<T>(rp[u][h], p0, p1);
+                            unpack_pairs<T>(rq[u][h], q0, q1);
+                            g[h][0] = a1v[0] * p0 + (a2v[0] * q0 + a3v[0]);
+                            g[h][1] = a1v[1] * p1 + (a2v[1] * q1 + a3v[1]);
+                        }
+                        const uint4 o = make_uint4(pack_bf16x2(g[0][0].x, g[1][0].x) & msk[u], pack_bf16x2(g[0][0].y, g[1][0].y) & msk[u],
+                                                   pack_bf16x2(g[0][1].x, g[1][1].x) & msk[u], pack_bf16x2(g[0][1].y, g[1][1].y) & msk[u]);
+                        *reinterpret_cast<uint4*>(tile + f * CS + cv * 4) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const i64 prow0 = (i64)plane * a.Hin * a.Win;
+            T* dh0 = dhp + prow0 * a.C + chan;
+            const T* y10 = y1p + prow0 * a.y1.ld + chs;
+            const int total = nri * Wip;
+            const int grow0 = hi0 * a.Win;
+            constexpr int XB = 2;                    // pixel pairs in flight per thread
+            for (int i0 = pl; i0 < total; i0 += XB * LP) {
+                uint2 ry[XB][2];
+                int jj[XB], iyv[XB];
+                bool v1[XB];
+#pragma unroll
+                for (int u = 0; u < XB; ++u) {
+                    const int i = i0 + u * LP;
+                    const bool ok = chan_ok && i < total;
+                    const int iv = ok ? i : 0;
+                    iyv[u] = dvw.div(iv);
+                    jj[u] = dvw.rem(iv, iyv[u]);
+                    const int pix = grow0 + __mul24(iyv[u], a.Win) + 2 * jj[u];
+                    v1[u] = 2 * jj[u] + 1 < a.Win;
+                    ry[u][0] = ld4_raw<T>(y10 + __umul24((unsigned)pix, (unsigned)a.y1.ld));
+                    ry[u][1] = ld4_raw<T>(y10 + __umul24((unsigned)(pix + (v1[u] ? 1 : 0)), (unsigned)a.y1.ld));
+                }
+#pragma unroll
+                for (int u = 0; u < XB; ++u) {
+                    if (!chan_ok || i0 + u * LP >= total) continue;
+                    f2_t y[2][2], z1[2][2], dsl[2][2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        unpack_pairs<T>(ry[u][h], y[h][0], y[h][1]);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const f2_t hh = y[h][q] * bs2[q] + bt2[q];
+                            const f2_t sg = f2_t{sigmoidf_(hh.x), sigmoidf_(hh.y)};
+                            z1[h][q] = hh * sg;
+                            dsl[h][q] = sg * (1.0f + hh * (1.0f - sg));
+                        }
+                    }
+                    if (!v1[u]) { z1[1][0] = f2_t{0.f, 0.f}; z1[1][1] = f2_t{0.f, 0.f}; }
+                    const unsigned Z[4] = {pack_bf16x2(z1[0][0].x, z1[1][0].x), pack_bf16x2(z1[0][0].y, z1[1][0].y),
+                                           pack_bf16x2(z1[0][1].x, z1[1][1].x), pack_bf16x2(z1[0][1].y, z1[1][1].y)};
+                    float dz0[4] = {0.f, 0.f, 0.f, 0.f}, dz1[4] = {0.f, 0.f, 0.f, 0.f};
+                    const unsigned* tp = tile + (__mul24(iyv[u], Wqp) + jj[u]) * CS + cv * 4;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        // tile row iy + (2 - dy): output row ho = hi + 1 - dy
+                        const uint4 G0 = *reinterpret_cast<const uint4*>(tp + (2 - dy) * rowdw);
+                        const uint4 G1 = *reinterpret_cast<const uint4*>(tp + (2 - dy) * rowdw + CS);
+                        const uint4 Wa = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 0) * CS + cv * 4]);
+                        const uint4 Wb = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 1) * CS + cv * 4]);
+                        const uint4 Wc = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 2) * CS + cv * 4]);
+                        const uint4 Wd = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 3) * CS + cv * 4]);
+                        const unsigned g0[4] = {G0.x, G0.y, G0.z, G0.w}, g1[4] = {G1.x, G1.y, G1.z, G1.w};
+                        const unsigned wa[4] = {Wa.x, Wa.y, Wa.z, Wa.w}, wb[4] = {Wb.x, Wb.y, Wb.z, Wb.w};
+                        const unsigned wc[4] = {Wc.x, Wc.y, Wc.z, Wc.w}, wd[4] = {Wd.x, Wd.y, Wd.z, Wd.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            dz0[q] = dot2_bf16(g0[q], wa[q], dz0[q]);
+                            dz0[q] = dot2_bf16(g1[q], wb[q], dz0[q]);
+                            dz1[q] = dot2_bf16(g0[q], wc[q], dz1[q]);
+                            dz1[q] = dot2_bf16(g1[q], wd[q], dz1[q]);
+                            const unsigned gm = __builtin_amdgcn_alignbit(g1[q], g0[q], 16);      // (G0.hi, G1.lo)
+                            dwp[dy * 3 + 2][q] = dot2_bf16(Z[q], g0[q], dwp[dy * 3 + 2][q]);
+                            dwp[dy * 3 + 1][q] = dot2_bf16(Z[q], gm, dwp[dy * 3 + 1][q]);
+                            dwp[dy * 3 + 0][q] = dot2_bf16(Z[q], g1[q], dwp[dy * 3 + 0][q]);
+                        }
+                    }
+                    const int pix = grow0 + __mul24(iyv[u], a.Win) + 2 * jj[u];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if (h == 1 && !v1[u]) break;
+                        const float* dz = h == 0 ? dz0 : dz1;
+                        const f2_t d0 = f2_t{dz[0], dz[1]} * dsl[h][0], d1 = f2_t{dz[2], dz[3]} * dsl[h][1];
+                        const uint2 packed = make_uint2(pack_bf16x2(d0.x, d0.y), pack_bf16x2(d1.x, d1.y));
+                        *reinterpret_cast<uint2*>(dh0 + __umul24((unsigned)(pix + h), (unsigned)a.C)) = packed;
+                        f2_t r0, r1;
+                        unpack_pairs<T>(packed, r0, r1);
+                        sp0[0] += r0; sp0[1] += r1;
+                        sp1[0] += r0 * (y[h][0] * bi2[0] + nbm2[0]);
+                        sp1[1] += r1 * (y[h][1] * bi2[1] + nbm2[1]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // weight gradient: reduce over the threads sharing a channel vector through LDS, then global fp32 atomics
+    for (int i = tid; i < KS * KS * CS; i += NT) lw[i] = 0.f;
+    __syncthreads();
+    if (chan_ok) {
+#pragma unroll
+        for (int k = 0; k < KS * KS; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) atomicAdd(&lw[k * CS + cv * 4 + q], dwp[k][q]);
+    }
+    __syncthreads();
+    for (int i = tid; i < KS * KS * CS; i += NT) {
+        const int k = i / CS, c = c0 + i % CS;
+        if (c < a.C) atomicAdd(&a.dw[(i64)c * (KS * KS) + k], lw[i]);
+    }
+    if (a.stats) {
+        const float s0[4] = {sp0[0].x, sp0[0].y, sp0[1].x, sp0[1].y}, s1[4] = {sp1[0].x, sp1[0].y, sp1[1].x, sp1[1].y};
+        block_stats_flush<T>(lstat, s0, s1, cv, c0, a.C, a.stats, blockIdx.x % DWN_NREP);
+    }
+}
+
 template <typename T>
 static int spatial_bwd_t(DwSpatialBwd a, hipStream_t s) {
     constexpr int CS = SL<T>::CS;
@@ -1009,19 +1226,24 @@ static int spatial_bwd_t(DwSpatialBwd a, hipStream_t s) {
     if (a.C % 8) return dwn_set_error(-2, "dw_spatial: C must be a multiple of 8");
     const int Wq = a.Wout + 2;
     auto rows_q = [&](int rb) { return (rb - 1 + 2) / a.stride + 2; };   // upper bound on staged output rows
+    // bf16, stride 1: x-pair-packed gradient tile (dot2 kernel), rows of ceil(Wq/2) pairs x 256 bytes
+    static const bool pair_off = getenv("DWN_DWS_NOPAIR") != nullptr;
+    const bool pair = TT<T>::IS_BF16 && a.stride == 1 && !pair_off;
+    const size_t row_bytes = pair ? (size_t)((Wq + 1) / 2) * 256 : (size_t)Wq * 128;
     if (a.rows_band <= 0) {
         int rb = 1;
-        while (rb < a.Hin && (size_t)rows_q(rb + 1) * Wq * 128 <= (size_t)DWS_BWD_LDS_BUDGET) ++rb;
+        while (rb < a.Hin && (size_t)rows_q(rb + 1) * row_bytes <= (size_t)DWS_BWD_LDS_BUDGET) ++rb;
         const int nb = (a.Hin + rb - 1) / rb;
         a.rows_band = (a.Hin + nb - 1) / nb;
     }
     if (a.rows_band > a.Hin) a.rows_band = a.Hin;
-    const size_t lds = (size_t)rows_q(a.rows_band) * Wq * 128;
+    const size_t lds = (size_t)rows_q(a.rows_band) * row_bytes;
     if (lds > 150 * 1024) return dwn_set_error(-5, "dw_spatial_bwd: plane too wide for the LDS tile");
     const int nbands = (a.Hin + a.rows_band - 1) / a.rows_band;
     const int slices = (a.C + CS - 1) / CS;
     const i64 work = (i64)a.planes * nbands;
-    if (a.stride == 1) { dim3 grid(resident_grid_x(dw_spatial_bwd_kernel<T, 3, 1>, lds, slices, work, DWS_BWD_THREADS), slices); hipLaunchKernelGGL((dw_spatial_bwd_kernel<T, 3, 1>), grid, dim3(DWS_BWD_THREADS), lds, s, a); }
+    if (pair) { dim3 grid(resident_grid_x(dw_spatial_bwd_pair_kernel, lds, slices, work, DWS_BWD_THREADS), slices); hipLaunchKernelGGL(dw_spatial_bwd_pair_kernel, grid, dim3(DWS_BWD_THREADS), lds, s, a); }
+    else if (a.stride == 1) { dim3 grid(resident_grid_x(dw_spatial_bwd_kernel<T, 3, 1>, lds, slices, work, DWS_BWD_THREADS), slices); hipLaunchKernelGGL((dw_spatial_bwd_kernel<T, 3, 1>), grid, dim3(DWS_BWD_THREADS), lds, s, a); }
     else if (a.stride == 2) { dim3 grid(resident_grid_x(dw_spatial_bwd_kernel<T, 3, 2>, lds, slices, work, DWS_BWD_THREADS), slices); hipLaunchKernelGGL((dw_spatial_bwd_kernel<T, 3, 2>), grid, dim3(DWS_BWD_THREADS), lds, s, a); }
     else { dim3 grid(resident_grid_x(dw_spatial_bwd_kernel<T, 3, 0>, lds, slices, work, DWS_BWD_THREADS), slices); hipLaunchKernelGGL((dw_spatial_bwd_kernel<T, 3, 0>), grid, dim3(DWS_BWD_THREADS), lds, s, a); }
     DWN_CHECK_LAUNCH();
