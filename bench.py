@@ -217,6 +217,21 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "launches_per_step": launches_per_step, "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_bytes_per_launch": int(bytes_per_launch)}
+            # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected inside the timed
+            # run): read from the committed summary of the same command at the default metric shape, see
+            # tools/pmc_traffic.py; expressed like `achieved` (bytes per launch / this run's launch duration)
+            default_shape = (args.batch, args.frames, args.height, args.width, args.expansion, args.dtype) == \
+                            (32, 32, 36, 64, 7, "bf16")
+            tpath = ROOT / "profiles" / "r1c_pmc_traffic.json"
+            if default_shape and tpath.exists():
+                try:
+                    tf = json.loads(tpath.read_text())["families"].get(fam)
+                    if tf:
+                        roof["traffic"] = round(tf["traffic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, 1)
+                        roof["traffic_bytes_per_launch"] = int(tf["traffic_bytes_per_launch"])
+                        roof["traffic_source"] = "profiles/r1c_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
+                except (ValueError, KeyError):
+                    pass
         out = {
             "metric": "training clips/sec/GPU (DwiseNeuro fwd+bwd, B=32 T=32 36x64) at 1/2/4/8 GPUs",
             "value_is": "whole-job aggregate clips/s over all n_gpus (per-GPU figure: clips_per_s_per_gpu); a step "

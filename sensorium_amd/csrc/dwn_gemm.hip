@@ -563,12 +563,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN g) {
 
     const int tid = threadIdx.x;
     const int ntc = (g.Cc + BC - 1) / BC;
-    const int rt = blockIdx.x / ntc, ct = blockIdx.x % ntc;
+    // XCD-aware order: the output tiles of one M-split re-read the same P / Q rows, so they get consecutive slots of
+    // one XCD (workgroups are dealt to the 8 XCDs round-robin in linear id order) instead of 8 different L2s
+    int tile_id = blockIdx.x, split_id = blockIdx.y;
+    {
+        const unsigned total = gridDim.x * gridDim.y, bid = blockIdx.x + gridDim.x * blockIdx.y;
+        if ((total & 7u) == 0u) {
+            const unsigned lid = (bid & 7u) * (total >> 3) + (bid >> 3);
+            tile_id = (int)(lid % gridDim.x);
+            split_id = (int)(lid / gridDim.x);
+        }
+    }
+    const int rt = tile_id / ntc, ct = tile_id % ntc;
     const int r0 = rt * BR, c0 = ct * BC;
     const int grp = blockIdx.z;
     const int Rl = g.R_load > 0 ? g.R_load : g.R;
     const int pcol0 = grp * Rl, qcol0 = grp * g.Cc;
-    const i64 mbeg = (i64)blockIdx.y * g.rows_per_split;
+    const i64 mbeg = (i64)split_id * g.rows_per_split;
     i64 mend = mbeg + g.rows_per_split;
     if (mend > g.M) mend = g.M;
 
@@ -731,10 +742,21 @@ static int launch_tn_t(const GemmTN& g_in, hipStream_t s) {
         const int maxsplit = (int)((g.M + 511) / 512);
         if (want > maxsplit) want = maxsplit;
         if (want < 1) want = 1;
-        i64 rows = (g.M + want - 1) / want;
-        rows = (rows + 63) / 64 * 64;
-        g.rows_per_split = (int)rows;
-        g.nsplit = (int)((g.M + rows - 1) / rows);
+        // prefer a split count that makes tiles x splits a multiple of 8 (XCD-aware tile order in the kernel)
+        const int tiles_g = ((g.R + 127) / 128) * ((g.Cc + 127) / 128);
+        for (int w = want; w >= 1 && w > want - 8; --w) {
+            i64 rows = (g.M + w - 1) / w;
+            rows = (rows + 63) / 64 * 64;
+            g.rows_per_split = (int)rows;
+            g.nsplit = (int)((g.M + rows - 1) / rows);
+            if (((tiles_g * g.nsplit) & 7) == 0) break;
+        }
+        if (((tiles_g * g.nsplit) & 7) != 0) {       // none found: keep the fullest grid
+            i64 rows = (g.M + want - 1) / want;
+            rows = (rows + 63) / 64 * 64;
+            g.rows_per_split = (int)rows;
+            g.nsplit = (int)((g.M + rows - 1) / rows);
+        }
     }
     dim3 grid(((g.R + 127) / 128) * ((g.Cc + 127) / 128), g.nsplit, g.groups);
     hipLaunchKernelGGL((gemm_tn_kernel<T, PLD, QLD>), grid, dim3(256), 0, s, g);
