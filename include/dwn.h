@@ -85,6 +85,10 @@ typedef struct dwn_gemm_nn_args {
     /* optional K-concatenation: columns k >= K1 of the A operand come from a2[m][k - K1] (plain loads);
      * only with epi == DWN_EPI_STORE_CAT, which also adds `bias` (fp32 [N]) before rounding. */
     const void* a2; long long a2_ld; int K1;
+    /* optional per-sample weights: rows [b*b_rows_per_sample, (b+1)*b_rows_per_sample) multiply the weight matrix at
+     * b + b*b_sample_stride elements (e.g. W . diag(gate_b): the SE gate folded into conv_pwl).  Needs
+     * b_rows_per_sample % 128 == 0, groups == 1 and K > one k-tile; 0 = one weight matrix for every row. */
+    long long b_sample_stride; int b_rows_per_sample;
 } dwn_gemm_nn_args;
 
 /* dW[R][Cc] += sum_m load(P)[m][r] * load(Q)[m][c]   (fp32 atomics; dW must be zeroed by the caller) */

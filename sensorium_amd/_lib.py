@@ -40,7 +40,7 @@ class GemmNNArgs(C.Structure):
                 ("stat_rep_stride_unused", c_i), ("stat_nchan", c_i), ("epi", c_i), ("bias", c_p),
                 ("sp_beta", c_f), ("out_nct", c_p), ("Tn", c_i), ("n_valid", c_i), ("y3", c_p), ("ldy3", c_ll),
                 ("s3", c_p), ("t3", c_p), ("dg", c_p), ("dg_ld", c_i), ("rows_per_sample", c_i),
-                ("a2", c_p), ("a2_ld", c_ll), ("K1", c_i)]
+                ("a2", c_p), ("a2_ld", c_ll), ("K1", c_i), ("b_sample_stride", c_ll), ("b_rows_per_sample", c_i)]
 
 
 class GemmTNArgs(C.Structure):

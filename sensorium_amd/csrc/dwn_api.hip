@@ -120,9 +120,16 @@ struct BlockWs {
     float *abc1, *abc2, *abc3, *abc4, *abcsc, *ident3;
     float *dgp, *dhp, *dps;
     void* bp; float* r3; float* gacc;                      // conv_pw data-gradient folding (see dwn_elementwise.hip)
+    void* wgated;                                          // [B][Cout][Cmid] W2 . diag(gate_b) (forward only)
     char* zero_beg; char* zero_end;
     size_t bytes;
 };
+// conv_pwl forward with the SE gate folded into per-sample weights (plain A loader): needs whole tiles per sample and
+// the k-loop GEMM variant
+static bool pwl_gated_weights(const dwn_block_args& a) {
+    const int bk = a.dtype == DWN_BF16 ? 64 : 32;
+    return ((a.T * a.Hout * a.Wout) % 128) == 0 && a.Cmid > bk;
+}
 BlockWs carve_block(const dwn_block_args& a, int backward, void* base, size_t cap) {
     BlockWs w; memset(&w, 0, sizeof(w));
     Carver c(base, cap);
@@ -131,6 +138,7 @@ BlockWs carve_block(const dwn_block_args& a, int backward, void* base, size_t ca
     w.wpwl = c.take<char>((size_t)a.Cout * a.Cmid * ts);
     w.wdws = c.take<float>((size_t)a.ks * a.ks * a.Cmid);
     w.wdwt = c.take<float>((size_t)a.kt * a.Cmid);
+    if (!backward && pwl_gated_weights(a)) w.wgated = c.take<char>((size_t)a.B * a.Cout * a.Cmid * ts);
     c.take<char>(0);
     size_t z0 = (c.off + 255) & ~(size_t)255;
     w.st1 = c.take<double>(nstat(a.Cmid));
@@ -358,7 +366,14 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     TRY(k_se_mlp_fwd(w.pooled, 1.0f / (float)S_out, a.se_wr, a.se_br, a.se_we, a.se_be, a.B, a.Cmid, a.se_r,
                      a.se_pmean, a.se_hidpre, a.se_gate, s));
     // conv_pwl (:117-120): y4 = (silu(bn3(y3)) * gate) @ W2^T
-    {
+    if (pwl_gated_weights(a)) {
+        // (z3 * gate_b) @ W2^T == z3 @ (W2 . diag(gate_b))^T: B small weight matrices instead of a per-element multiply
+        TRY(k_gate_weights(a.w_pwl, a.se_gate, w.wgated, a.B, a.Cout, a.Cmid, dt, s));
+        GemmNN g = nn_base(ld_plain(a.z3, a.Cmid), LD_PLAIN, w.wgated, a.Cmid, a.y4, a.Cout, (int)Mout, a.Cout, a.Cmid, 1);
+        g.b_sample_stride = (i64)a.Cout * a.Cmid; g.b_rows_per_sample = S_out;
+        g.stats = tr ? w.st4 : nullptr; g.stat_nchan = a.Cout;
+        PROF(DWN_FAM_PWL_FWD, launch_gemm_nn(g, dt, s));
+    } else {
         LoadDesc u = ld_plain(a.z3, a.Cmid);
         u.gate = a.se_gate; u.gate_ld = a.Cmid; u.rows_per_sample = S_out;
         GemmNN g = nn_base(u, LD_GATE, w.wpwl, a.Cmid, a.y4, a.Cout, (int)Mout, a.Cout, a.Cmid, 1);

@@ -1331,6 +1331,28 @@ int k_pack_weight(const float* src, void* dst, int groups, int R, int C, int tra
     DWN_CHECK_LAUNCH();
     return 0;
 }
+// per-sample gated weights: dst[b][n][k] = T(w[n][k] * gate[b][k])  — the SE gate folded into conv_pwl's weights so
+// that its GEMM streams the activated tensor z3 with a plain loader (dwiseneuro.py:40-43,117-120)
+template <typename T>
+__global__ __launch_bounds__(256) void gate_weights_kernel(const float* w, const float* gate, T* dst, int N, int K) {
+    const int b = blockIdx.y;
+    const i64 per = (i64)N * K;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < per; i += (i64)gridDim.x * 256) {
+        const int k = (int)(i % K);
+        dst[(i64)b * per + i] = from_f<T>(w[i] * gate[(i64)b * K + k]);
+    }
+}
+int k_gate_weights(const float* w, const float* gate, void* dst, int B, int N, int K, int dtype, hipStream_t s) {
+    i64 per = (i64)N * K;
+    unsigned bx = (unsigned)((per + 255) / 256);
+    if (bx > 64) bx = 64;
+    dim3 grid(bx, (unsigned)B);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((gate_weights_kernel<bf16_t>), grid, dim3(256), 0, s, w, gate, (bf16_t*)dst, N, K),
+        hipLaunchKernelGGL((gate_weights_kernel<float>), grid, dim3(256), 0, s, w, gate, (float*)dst, N, K));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
 // depth-wise weights: reference layout [C][taps] -> tap-major [taps][C] fp32
 __global__ void pack_dw_kernel(const float* src, float* dst, int C, int taps) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;

@@ -150,15 +150,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
             }
         }
     };
-    auto load_b = [&](int k0) {
+    // m0b: first row of the tile the weights are for (selects the sample with per-sample weight matrices)
+    auto load_b = [&](int k0, int m0b = 0) {
         ldb_k0 = k0;
+        const T* Bt = Bp;
+        if (g.b_sample_stride) Bt += (i64)(m0b / g.b_rows_per_sample) * g.b_sample_stride;
 #pragma unroll
         for (int i = 0; i < B_CH; ++i) {
             int c = tid + 256 * i;
             int row = c >> 3, kc = c & 7;
             int n = n0 + row, k = k0 + kc * KC;
             const bool ok = n < g.N && k < g.K;
-            rb[i] = *reinterpret_cast<const uint4*>(Bp + (ok ? (i64)n * g.ldb + k : 0));
+            rb[i] = *reinterpret_cast<const uint4*>(Bt + (ok ? (i64)n * g.ldb + k : 0));
         }
     };
     auto store_a = [&]() {
@@ -273,8 +276,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
             __syncthreads();
             for (int k0 = 0; k0 < g.K; k0 += BK) {
                 const bool has_next = (k0 + BK) < g.K;
-                if (has_next) { load_a(m0, k0 + BK); load_b(k0 + BK); }
-                else if (mt + 1 < mt_end) { load_a(m0 + BM, 0); load_b(0); }   // next tile: in flight under the epilogue
+                if (has_next) { load_a(m0, k0 + BK); load_b(k0 + BK, m0); }
+                else if (mt + 1 < mt_end) { load_a(m0 + BM, 0); load_b(0, m0 + BM); }   // next tile: in flight under the epilogue
                 mma_tile();
                 __syncthreads();
                 if (has_next) {
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
             __syncthreads();
         }
     };
-    if constexpr (!single) { load_a(mt_beg * BM, 0); load_b(0); }
+    if constexpr (!single) { load_a(mt_beg * BM, 0); load_b(0, mt_beg * BM); }
     for (int mt = mt_beg; mt < mt_end; ++mt) {
         const int m0_ = mt * BM;
         bool fast = m0_ + BM <= g.M;
@@ -540,6 +543,11 @@ static int launch_nn_d(const GemmNN& g, hipStream_t s) {
 
 int launch_gemm_nn(const GemmNN& g, int dtype, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return 0;
+    if (g.b_sample_stride) {
+        const int bk = dtype == DWN_BF16 ? 64 : 32;
+        if (g.b_rows_per_sample <= 0 || g.b_rows_per_sample % 128 || g.groups != 1 || g.K <= bk)
+            return dwn_set_error(-2, "gemm_nn: per-sample weights need b_rows_per_sample % 128 == 0, groups == 1, K > one k-tile");
+    }
     return dtype == DWN_BF16 ? launch_nn_d<bf16_t>(g, s) : launch_nn_d<float>(g, s);
 }
 

@@ -57,6 +57,7 @@ int k_cortex_bwd_dx(const void* dxmain, const void* x, const void* dout, const f
 int k_pack_weight(const float* src, void* dst, int groups, int R, int C, int transpose, int Rd, int Cd, int dtype,
                   hipStream_t s);
 int k_pack_dw(const float* src, float* dst, int C, int taps, hipStream_t s);
+int k_gate_weights(const float* w, const float* gate, void* dst, int B, int N, int K, int dtype, hipStream_t s);
 int k_readout_dz(const float* dout, const float* out, float beta, int B, int Tn, int n_valid, int Rg, int Rp,
                  int groups, void* dz, float* db, int dtype, hipStream_t s);
 int k_poisson_fwd(const float* pred, const float* target, const float* w, i64 per_sample, i64 total, float eps,
