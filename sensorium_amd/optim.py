@@ -20,9 +20,32 @@ _ENTRY_DTYPE = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), 
 assert _ENTRY_DTYPE.itemsize == C.sizeof(L.TensorEntry)
 
 
-def _upload_table(entries: np.ndarray, device) -> torch.Tensor:
-    host = torch.from_numpy(entries.view(np.uint8).copy())
-    return host.to(device, non_blocking=False)
+class _TableCache:
+    """Device copy of a pointer table, re-uploaded only when its contents change.
+
+    The table of a training step is almost always identical to the previous step's (parameters, optimizer state and
+    EMA tensors never move; the caching allocator hands the gradients the same blocks every step).  A blocking
+    host-to-device copy per step would also stall the host until the whole backward has drained, leaving the GPU idle
+    while the next step's first kernels are being queued — so a changed table goes through pinned memory, asynchronously.
+    """
+
+    def __init__(self):
+        self._bytes = None
+        self._dev = None
+        self._pinned = None          # kept alive until the next upload: the async copy reads it
+
+    def get(self, entries: np.ndarray, device) -> torch.Tensor:
+        raw = entries.view(np.uint8).tobytes()
+        if self._dev is not None and self._bytes == raw and self._dev.device == device:
+            return self._dev
+        host = torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory()
+        dev = torch.empty(len(raw), dtype=torch.uint8, device=device)
+        dev.copy_(host, non_blocking=True)
+        self._bytes, self._dev, self._pinned = raw, dev, host
+        return dev
+
+
+_lerp_cache = _TableCache()
 
 
 class FusedAdamWEma(torch.optim.Optimizer):
@@ -38,6 +61,7 @@ class FusedAdamWEma(torch.optim.Optimizer):
         if ema_params is not None and len(ema_params) != len(flat):
             raise ValueError("ema_params must align one-to-one with the optimised parameters")
         self._ema_of = {id(p): e for p, e in zip(flat, ema_params)} if ema_params is not None else {}
+        self._tables = {}
 
     def state_for(self, p):
         return self.state[p]
@@ -75,7 +99,7 @@ class FusedAdamWEma(torch.optim.Optimizer):
                 ema = self._ema_of.get(id(p))
                 entries[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                               0 if ema is None else ema.data_ptr(), p.numel(), 0, 0)
-            table = _upload_table(entries, dev)
+            table = self._tables.setdefault(id(group), _TableCache()).get(entries, dev)
             b1, b2 = group["betas"]
             L.check(L.lib.dwn_adamw_ema_multi(table.data_ptr(), len(params), self.max_blocks, float(group["lr"]),
                                               float(b1), float(b2), float(group["eps"]),
@@ -105,6 +129,6 @@ def ema_lerp_state(ema_tensors: List[torch.Tensor], model_tensors: List[torch.Te
         if not (e.is_contiguous() and m.is_contiguous() and e.is_cuda and m.is_cuda):
             raise RuntimeError("ema_lerp_state: contiguous GPU tensors only")
         entries[i] = (m.data_ptr(), 0, 0, 0, e.data_ptr(), e.numel(), is_int, 0)
-    table = _upload_table(entries, dev)
+    table = _lerp_cache.get(entries, dev)
     L.check(L.lib.dwn_ema_lerp_multi(table.data_ptr(), len(ema_tensors), max_blocks, float(decay), dev.index,
                                      torch.cuda.current_stream(dev).cuda_stream), "dwn_ema_lerp_multi")
