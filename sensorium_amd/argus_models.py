@@ -132,7 +132,7 @@ class MouseModel:
         self._ensure_optimizer()
         self.train()
         if self.buckets is not None:
-            self.buckets.zero_grad()
+            self.buckets.zero_grad(self.iter_size)
         else:
             self.optimizer.zero_grad(set_to_none=True)
         loss_value = 0

@@ -46,43 +46,52 @@ class GradBuckets:
     def _add_bucket(self, params):
         n = sum(p.numel() for p in params)
         flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
-        off = 0
-        for p in params:
-            p.grad = flat[off:off + p.numel()].view_as(p)      # gradients accumulate straight into the bucket
-            off += p.numel()
         self.buckets.append(dict(params=params, flat=flat, pending=len(params), count=len(params)))
+
+    def _views(self, b):
+        off = 0
+        for p in b["params"]:
+            yield p, b["flat"][off:off + p.numel()].view_as(p)
+            off += p.numel()
 
     def _make_hook(self, bi: int):
         def hook(_param):
             b = self.buckets[bi]
             b["pending"] -= 1
             if b["pending"] == 0:
+                # gather the bucket's gradients with ONE concatenation (autograd handed each parameter a fresh tensor;
+                # accumulating ~200 gradients into pre-assigned views would cost one small add kernel per parameter)
+                torch.cat([p.grad.reshape(-1) for p in b["params"]], out=b["flat"])
                 op = dist.ReduceOp.AVG if dist.get_backend(self.pg) == "nccl" else dist.ReduceOp.SUM
                 self._handles.append((dist.all_reduce(b["flat"], op=op, group=self.pg, async_op=True), bi, op))
         return hook
 
-    def zero_grad(self):
-        """Keep the views alive: zero the flat buffers instead of dropping ``.grad``."""
+    def zero_grad(self, n_backward: int = 1):
+        """Drop ``.grad`` so that autograd hands over freshly produced gradient tensors (no accumulate kernels).
+        ``n_backward`` = backward passes that accumulate into this step's gradients (argus ``iter_size``): a bucket is
+        reduced when every parameter has been visited that many times."""
         for b in self.buckets:
-            b["flat"].zero_()
-            b["pending"] = b["count"]
-            off = 0
+            b["pending"] = b["count"] * int(n_backward)
+            b["expect"] = b["pending"]
             for p in b["params"]:
-                if p.grad is None or p.grad.data_ptr() != b["flat"].data_ptr() + off * 4:
-                    p.grad = b["flat"][off:off + p.numel()].view_as(p)
-                off += p.numel()
+                p.grad = None
 
     def finish(self):
-        """Wait for the outstanding all-reduces (call after backward, before the optimizer step)."""
+        """Wait for the outstanding all-reduces (call after backward, before the optimizer step); afterwards every
+        ``p.grad`` is a view of its bucket and holds the rank-averaged gradient."""
         for handle, bi, op in self._handles:
             handle.wait()
             if op == dist.ReduceOp.SUM:
                 self.buckets[bi]["flat"].div_(self.world)
+        reduced = {bi for _, bi, _ in self._handles}
         self._handles.clear()
         if self.world > 1:
-            for b in self.buckets:
-                if b["pending"] not in (0, b["count"]):
+            for bi, b in enumerate(self.buckets):
+                if b["pending"] not in (0, b.get("expect", b["count"])):
                     raise RuntimeError("GradBuckets: a bucket saw only part of its gradients this step")
+                if bi in reduced:
+                    for p, v in self._views(b):
+                        p.grad = v
 
     def num_elements(self) -> int:
         return sum(b["flat"].numel() for b in self.buckets)

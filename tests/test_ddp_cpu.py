@@ -1,5 +1,6 @@
 """World-size-2 gloo tests (CPU) of the data-parallel gradient exchange (sensorium_amd/ddp.py): bucket layout,
-hook-driven all-reduce, mean semantics, persistence of the flat-buffer views across zero_grad."""
+hook-driven all-reduce, mean semantics, gradients delivered as views of the flat buckets, accumulation over
+several backward passes."""
 import os
 import socket
 
@@ -50,6 +51,22 @@ def _worker(rank, world, port, ret):
             b0 = buckets.buckets[0]
             assert b0["params"][0] is list(model.parameters())[-1]
             assert b0["params"][0].grad.data_ptr() == b0["flat"].data_ptr()
+        # gradient accumulation over two backward passes (argus iter_size = 2): reduced once, after the second pass
+        buckets.zero_grad(2)
+        for c in range(2):
+            torch.manual_seed(50 + rank + 10 * c)
+            model(torch.randn(4, 6)).pow(2).sum().backward()
+        buckets.finish()
+        got = torch.cat([p.grad.reshape(-1) for p in reversed(list(model.parameters()))])
+        ref = 0
+        for r in range(world):
+            m2 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+            m2.load_state_dict(model.state_dict())
+            for c in range(2):
+                torch.manual_seed(50 + r + 10 * c)
+                m2(torch.randn(4, 6)).pow(2).sum().backward()
+            ref = ref + torch.cat([p.grad.reshape(-1) for p in reversed(list(m2.parameters()))])
+        assert torch.allclose(got, ref / world, rtol=1e-5, atol=1e-6)
         assert buckets.num_elements() == sum(p.numel() for p in model.parameters())
         ret[rank] = "ok"
     finally:
