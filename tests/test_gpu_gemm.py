@@ -162,3 +162,53 @@ def test_gemm_tn_exact(L, dtype):
     L.check(L.lib.dwn_gemm_tn(C.byref(g), _dt(L, dtype), 0, stream()), "gemm_tn")
     torch.cuda.synchronize()
     assert torch.equal(dw, p.t() @ q)
+
+
+def test_gemm_nn_rejects_unsupported_requests(L):
+    """The C-ABI fails loudly (non-zero code + dwn_last_error) instead of computing something else."""
+    M, N, K = 256, 128, 128
+    a = torch.zeros(M, K, device=dev(), dtype=torch.bfloat16)
+    b = torch.zeros(N, K, device=dev(), dtype=torch.bfloat16)
+    c = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+    dummy = torch.zeros(N, device=dev())
+
+    def base():
+        g = L.GemmNNArgs()
+        g.a = load_desc(L, a, K); g.a_kind = L.LD_PLAIN
+        g.b = b.data_ptr(); g.ldb = K; g.c = c.data_ptr(); g.ldc = N
+        g.M, g.N, g.K, g.groups = M, N, K, 1
+        g.epi = L.EPI_STORE
+        return g
+
+    g = base()                                   # per-sample weights need whole 128-row tiles per sample
+    g.b_sample_stride = N * K; g.b_rows_per_sample = 96
+    assert L.lib.dwn_gemm_nn(C.byref(g), L.DWN_BF16, 0, stream()) != 0
+    assert b"per-sample" in L.lib.dwn_last_error()
+    g = base()                                   # the dg epilogue reads the activated z3: s3 / t3 are reserved
+    g.epi = L.EPI_DG; g.y3 = c.data_ptr(); g.ldy3 = N; g.dg = dummy.data_ptr(); g.dg_ld = N; g.rows_per_sample = 128
+    g.s3 = dummy.data_ptr(); g.t3 = dummy.data_ptr()
+    assert L.lib.dwn_gemm_nn(C.byref(g), L.DWN_BF16, 0, stream()) != 0
+    g = base()                                   # K must be a multiple of the 16-byte vector
+    g.K = 12
+    assert L.lib.dwn_gemm_nn(C.byref(g), L.DWN_BF16, 0, stream()) != 0
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_nn_per_sample_weights(L, dtype):
+    """Rows of sample b multiply weight matrix b (the SE gate folded into conv_pwl's weights)."""
+    nb, rps, N, K = 3, 256, 64, 192
+    M = nb * rps
+    torch.manual_seed(11)
+    a = torch.randn(M, K, device=dev()).to(dtype)
+    w = (torch.randn(nb, N, K, device=dev()) / K ** 0.5).to(dtype)
+    c = torch.empty(M, N, dtype=dtype, device=dev())
+    g = L.GemmNNArgs()
+    g.a = load_desc(L, a, K); g.a_kind = L.LD_PLAIN
+    g.b = w.data_ptr(); g.ldb = K; g.c = c.data_ptr(); g.ldc = N
+    g.M, g.N, g.K, g.groups = M, N, K, 1
+    g.epi = L.EPI_STORE; g.b_sample_stride = N * K; g.b_rows_per_sample = rps
+    L.check(L.lib.dwn_gemm_nn(C.byref(g), _dt(L, dtype), 0, stream()), "gemm_nn")
+    torch.cuda.synchronize()
+    ref = torch.cat([a[i * rps:(i + 1) * rps].double() @ w[i].double().t() for i in range(nb)])
+    assert rel(c, ref) < tol(dtype, 1e-5, 6e-3)
