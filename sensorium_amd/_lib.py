@@ -9,6 +9,12 @@ import ctypes as C
 import os
 from pathlib import Path
 
+# torch must be imported BEFORE the shared library is loaded: torch ships its own libamdhip64 and the process must
+# hold exactly one HIP runtime.  With torch first, the library's DT_NEEDED libamdhip64.so.N binds to the copy torch
+# already loaded (same SONAME); loaded the other way round the process ends up with two runtimes and every HIP call
+# of this library fails with "no ROCm-capable device is detected".
+import torch  # noqa: F401,E402
+
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "csrc" / "libdwiseneuro_hip.so"
 
