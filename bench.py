@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--height", type=int, default=36)
     ap.add_argument("--width", type=int, default=64)
     ap.add_argument("--expansion", type=int, default=7)
+    ap.add_argument("--no-fwd-bwd", action="store_true", help="skip the extra forward+backward-only timing loop")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--roofline-family", default="dws_bwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -201,6 +202,21 @@ def main():
             ms, n = C.c_double(0), C.c_longlong(0)
             L.check(L.lib.dwn_profile_collect(i, C.byref(ms), C.byref(n)), "profile_collect")
             fam_ms[name] = (ms.value, n.value)
+    L.check(L.lib.dwn_profile_enable(0, local_rank), "profile_disable")
+    # SURVEY.md §8d asks for both figures: the same steps without optimizer / EMA (forward + loss + backward only)
+    fwd_bwd_clips = None
+    if world == 1 and not args.no_fwd_bwd:
+        net, inp, tgt = model.nn_module, batch[0], batch[1]
+        n_fb = max(3, args.steps // 2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_fb):
+            net.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=params["amp"]):
+                loss_fb = model.loss(net(inp), tgt)
+            loss_fb.backward()
+        torch.cuda.synchronize()
+        fwd_bwd_clips = args.batch * n_fb / (time.perf_counter() - t1)
     L.lib.dwn_profile_enable(0, local_rank)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -253,6 +269,7 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "frames": args.frames,
                        "height": args.height, "width": args.width, "parallelism": f"dp{world}"},
             "clips_per_s_per_gpu": round(value / world, 2), "loss": round(loss_value, 3),
+            "clips_per_s_fwd_bwd_only": None if fwd_bwd_clips is None else round(fwd_bwd_clips, 2),
             "roofline": roof,
         }
         if args.profile_all:
