@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Sliding-window trial inference timing (reference: src/predictors.py:36-55,
+scripts/predict.py:24-50).  One model, one trial of L frames at the reference's window (16 frames, step 2); reports
+trials/s for the reference's launch pattern (one window per forward, device->host copy per window is already gone)
+and for batched windows with / without hipGraph replay.  Not the headline metric: prints a small JSON summary.
+
+    python tools/bench_predict.py [--length 300 --height 64 --width 64 --expansion 7 --dtype fp32]
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--length", type=int, default=300)
+    ap.add_argument("--height", type=int, default=64)
+    ap.add_argument("--width", type=int, default=64)
+    ap.add_argument("--expansion", type=int, default=7)
+    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--repeats", type=int, default=3)
+    args = ap.parse_args()
+    from bench import NUM_NEURONS_MOUSE0, model_params
+    from sensorium_amd.argus_models import MouseModel
+    from sensorium_amd.predictors import Predictor
+
+    dev = torch.device("cuda", 0)
+    params = model_params(args.expansion)
+    params["device"] = str(dev)
+    params["amp"] = False
+    torch.manual_seed(0)
+    model = MouseModel(params)
+    if args.dtype == "bf16":
+        model.nn_module.compute_dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(1)
+    inputs = torch.zeros(5, args.length, args.height, args.width)
+    inputs[0] = torch.randint(0, 256, (args.length, args.height, args.width), generator=g).float()
+    inputs[1:] = (torch.rand(4, args.length, 1, 1, generator=g) * 50)
+    out = {"length": args.length, "hw": [args.height, args.width], "dtype": args.dtype, "expansion": args.expansion,
+           "window": [16, 2], "neurons": NUM_NEURONS_MOUSE0, "trials_per_s": {}}
+    ref = None
+    for name, wpb, graph in (("one_window_per_forward", 1, False), ("16_windows_per_forward", 16, False),
+                             ("16_windows_per_forward_hipgraph", 16, True)):
+        pred = Predictor(model, frame_stack_size=16, frame_stack_step=2, windows_per_batch=wpb, use_graph=graph)
+        r = pred.predict_trial(inputs, 0)                       # warm-up (graph capture included)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.repeats):
+            r = pred.predict_trial(inputs, 0)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.repeats
+        out["trials_per_s"][name] = round(1.0 / dt, 3)
+        if ref is None:
+            ref = r
+        else:
+            import numpy as np
+            out.setdefault("max_rel_diff_vs_one_window", {})[name] = float(np.abs(r - ref).max() / (np.abs(ref).max() + 1e-12))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
