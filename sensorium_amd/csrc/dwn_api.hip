@@ -322,6 +322,10 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
         ok = ok && pa.packw(a.w_pwl, w.wpwl, 1, a.Cout, a.Cmid, 0, a.Cout, a.Cmid);
         ok = ok && pa.packdw(a.w_dws, w.wdws, a.Cmid, a.ks * a.ks);
         ok = ok && pa.packdw(a.w_dwt, w.wdwt, a.Cmid, a.kt);
+        if (!tr) {      // eval: the five BatchNorm coefficient sets come from running statistics — same launch
+            ok = ok && pa.bneval(a.bn1, a.Cmid, a.eps) && pa.bneval(a.bn2, a.Cmid, a.eps) && pa.bneval(a.bn3, a.Cmid, a.eps);
+            ok = ok && pa.bneval(a.bn4, a.Cout, a.eps) && pa.bneval(a.bnsc, a.Cout, a.eps);
+        }
         if (!ok) return dwn_set_error(-2, "block_forward: workspace arena must be 16-byte aligned");
         TRY(k_prep(pa, dt, s));
     }
@@ -341,7 +345,7 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
         g.stats = tr ? w.st1 : nullptr; g.stat_nchan = a.Cmid;
         PROF(DWN_FAM_PW_FWD, launch_gemm_nn(g, dt, s));
     }
-    TRY(bn_finalize(w.st1, a.Cmid, (double)Min, a.bn1, a.Cmid, tr, a.momentum, a.eps, s));
+    if (tr) TRY(bn_finalize(w.st1, a.Cmid, (double)Min, a.bn1, a.Cmid, tr, a.momentum, a.eps, s));
     // spat_covn_dw (:96-102)
     {
         DwSpatialFwd d; memset(&d, 0, sizeof(d));
@@ -350,7 +354,7 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
         d.Wout = a.Wout; d.C = a.Cmid; d.stride = a.stride; d.ks = a.ks; d.stats = tr ? w.st2 : nullptr;
         PROF(DWN_FAM_DWS_FWD, launch_dw_spatial_fwd(d, dt, s));
     }
-    TRY(bn_finalize(w.st2, a.Cmid, (double)Mout, a.bn2, a.Cmid, tr, a.momentum, a.eps, s));
+    if (tr) TRY(bn_finalize(w.st2, a.Cmid, (double)Mout, a.bn2, a.Cmid, tr, a.momentum, a.eps, s));
     // temp_covn_dw (:105-111)
     {
         DwTemporalFwd d; memset(&d, 0, sizeof(d));
@@ -359,7 +363,7 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
         d.stats = tr ? w.st3 : nullptr;
         PROF(DWN_FAM_DWT_FWD, launch_dw_temporal_fwd(d, dt, s));
     }
-    TRY(bn_finalize(w.st3, a.Cmid, (double)Mout, a.bn3, a.Cmid, tr, a.momentum, a.eps, s));
+    if (tr) TRY(bn_finalize(w.st3, a.Cmid, (double)Mout, a.bn3, a.Cmid, tr, a.momentum, a.eps, s));
     // se (:38-43)
     LoadDesc z3 = ld_bnact(a.y3, a.Cmid, a.bn3.coef, a.Cmid, 1, nullptr, 0, S_out);
     PROF(DWN_FAM_SE_POOL, k_se_pool(z3, a.B, a.Cmid, S_out, w.pooled, a.z3, dt, s));
@@ -380,11 +384,11 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
         g.stats = tr ? w.st4 : nullptr; g.stat_nchan = a.Cout;
         PROF(DWN_FAM_PWL_FWD, launch_gemm_nn(g, dt, s));
     }
-    TRY(bn_finalize(w.st4, a.Cout, (double)Mout, a.bn4, a.Cout, tr, a.momentum, a.eps, s));
+    if (tr) TRY(bn_finalize(w.st4, a.Cout, (double)Mout, a.bn4, a.Cout, tr, a.momentum, a.eps, s));
     // shortcut (:125-134) + residual (:143)
     ResGeom gm = geom_of(a);
     if (tr) PROF(DWN_FAM_RESID_FWD, k_shortcut_stats(xin, gm, w.stsc, dt, s));
-    TRY(bn_finalize(w.stsc, a.Cin, (double)Mout, a.bnsc, a.Cout, tr, a.momentum, a.eps, s));
+    if (tr) TRY(bn_finalize(w.stsc, a.Cin, (double)Mout, a.bnsc, a.Cout, tr, a.momentum, a.eps, s));
     PROF(DWN_FAM_RESID_FWD, k_residual_fwd(xin, a.y4, a.bn4.coef, a.bnsc.coef, a.drop_scale, gm, a.out_pe_t, a.out_pe_h,
                                            a.out_pe_w, a.out, dt, s));
     return 0;

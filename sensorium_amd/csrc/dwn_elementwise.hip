@@ -1567,6 +1567,17 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs pa) {
         for (i64 i = idx; i < q.n; i += (i64)q.nblocks * 256) p[i] = make_uint4(0, 0, 0, 0);
     } else if (q.kind == PREP_FILL) {
         if (idx < q.n) reinterpret_cast<float*>(q.dst)[idx] = q.v;
+    } else if (q.kind == PREP_BNEVAL) {            // bn_finalize_eval_kernel, folded into this launch
+        if (idx < q.n) {
+            const int c = (int)idx, C = q.C;
+            const float invstd = 1.0f / sqrtf(q.src4[c] + q.v);
+            const float scale = q.src[c] * invstd;
+            float* coef = reinterpret_cast<float*>(q.dst);
+            coef[c] = scale;
+            coef[C + c] = q.src2[c] - q.src3[c] * scale;
+            coef[2 * C + c] = q.src3[c];
+            coef[3 * C + c] = invstd;
+        }
     } else if (q.kind == PREP_PACKDW) {            // [C][taps] -> [taps][C] fp32
         if (idx < q.n) {
             const int C = q.C, k = (int)(idx / C), c = (int)(idx % C);

@@ -77,41 +77,50 @@ int k_pw_bwd_prep(const float* w1, const float* abc, int E, int C, void* bp, flo
                   hipStream_t s);
 
 // ---- fused per-call preparation (k_prep): zero ranges, constant fills and weight packs in one launch
-enum { PREP_ZERO = 0, PREP_FILL = 1, PREP_PACKW = 2, PREP_PACKDW = 3 };
+enum { PREP_ZERO = 0, PREP_FILL = 1, PREP_PACKW = 2, PREP_PACKDW = 3, PREP_BNEVAL = 4 };
+#define PREP_MAX_OPS 12
 struct PrepOp {
     int kind, nblocks;
     const float* src; void* dst;
-    long long n;                       // ZERO: 16-byte units; FILL / PACK*: elements
+    const float* src2; const float* src3; const float* src4;     // BNEVAL: beta, running_mean, running_var (src = gamma)
+    long long n;                       // ZERO: 16-byte units; FILL / PACK* / BNEVAL: elements (channels)
     float v;
     int R, C, transpose, Rd, Cd;       // PACKW: src [groups][R][C] -> dst [groups][Rd][Cd]; PACKDW: C channels, R taps
 };
 struct PrepArgs {
     int nops;
-    PrepOp op[8];
+    PrepOp op[PREP_MAX_OPS];
     PrepArgs() : nops(0) {}
     static int blocks_for(long long n, int cap) { long long b = (n + 255) / 256; return (int)(b > cap ? cap : b); }
     bool zero(void* p, size_t nbytes) {
         if (nbytes == 0) return true;
-        if (((size_t)p & 15) || (nbytes & 15) || nops >= 8) return false;
+        if (((size_t)p & 15) || (nbytes & 15) || nops >= PREP_MAX_OPS) return false;
         PrepOp& q = op[nops++]; q = PrepOp(); q.kind = PREP_ZERO; q.dst = p; q.n = (long long)(nbytes / 16); q.nblocks = blocks_for(q.n, 256);
         return true;
     }
     bool fill(float* p, float v, int n) {
         if (n <= 0) return true;
-        if (nops >= 8) return false;
+        if (nops >= PREP_MAX_OPS) return false;
         PrepOp& q = op[nops++]; q = PrepOp(); q.kind = PREP_FILL; q.dst = p; q.v = v; q.n = n; q.nblocks = blocks_for(n, 1 << 30);
         return true;
     }
     bool packw(const float* src, void* dst, int groups, int R, int C, int transpose, int Rd, int Cd) {
-        if (nops >= 8) return false;
+        if (nops >= PREP_MAX_OPS) return false;
         PrepOp& q = op[nops++]; q = PrepOp(); q.kind = PREP_PACKW; q.src = src; q.dst = dst; q.R = R; q.C = C; q.transpose = transpose;
         q.Rd = Rd; q.Cd = Cd; q.n = (long long)groups * Rd * Cd; q.nblocks = blocks_for(q.n, 1 << 30);
         return true;
     }
     bool packdw(const float* src, float* dst, int C, int taps) {
-        if (nops >= 8) return false;
+        if (nops >= PREP_MAX_OPS) return false;
         PrepOp& q = op[nops++]; q = PrepOp(); q.kind = PREP_PACKDW; q.src = src; q.dst = dst; q.C = C; q.R = taps; q.n = (long long)C * taps;
         q.nblocks = blocks_for(q.n, 1 << 30);
+        return true;
+    }
+    // eval-mode BatchNorm coefficients [4][C] = scale, shift, mean, invstd from the running statistics (v = eps)
+    bool bneval(const dwn_bn& bn, int C, float eps) {
+        if (nops >= PREP_MAX_OPS) return false;
+        PrepOp& q = op[nops++]; q = PrepOp(); q.kind = PREP_BNEVAL; q.src = bn.gamma; q.src2 = bn.beta; q.src3 = bn.running_mean;
+        q.src4 = bn.running_var; q.dst = bn.coef; q.v = eps; q.n = C; q.C = C; q.nblocks = blocks_for(C, 1 << 30);
         return true;
     }
 };
