@@ -187,7 +187,7 @@ typedef struct dwn_block_args {
     const void* dout; void* dx;
     void *buf_a, *buf_b;                     /* scratch [max(M_in,M_out)][Cmid], [M_out][Cmid] */
     void *dy4, *da0;                         /* scratch [M_out][Cout], [M_in][Cin] */
-    float *dw_pw, *dw_dws, *dw_dwt, *dw_pwl, *dse_wr, *dse_br, *dse_we, *dse_be;   /* zeroed by caller */
+    float *dw_pw, *dw_dws, *dw_dwt, *dw_pwl, *dse_wr, *dse_br, *dse_we, *dse_be;   /* overwritten (16-byte aligned) */
     void* ws; size_t ws_bytes;
 } dwn_block_args;
 

@@ -414,7 +414,12 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
         ok = ok && pa.packdw(a.w_dwt, w.wdwt, a.Cmid, a.kt);
         ok = ok && pa.fill(w.ident3, 1.0f, a.Cmid);
         ok = ok && pa.fill(w.ident3 + a.Cmid, 0.0f, 2 * a.Cmid);
-        if (!ok) return dwn_set_error(-2, "block_backward: workspace arena must be 16-byte aligned");
+        // the four atomically accumulated weight gradients are cleared here (callers pass uninitialised buffers)
+        ok = ok && pa.zero(a.dw_pw, (size_t)a.Cmid * a.Cin * sizeof(float));
+        ok = ok && pa.zero(a.dw_dws, (size_t)a.Cmid * a.ks * a.ks * sizeof(float));
+        ok = ok && pa.zero(a.dw_dwt, (size_t)a.Cmid * a.kt * sizeof(float));
+        ok = ok && pa.zero(a.dw_pwl, (size_t)a.Cout * a.Cmid * sizeof(float));
+        if (!ok) return dwn_set_error(-2, "block_backward: workspace arena and dw_* buffers must be 16-byte aligned");
         TRY(k_prep(pa, dt, s));
     }
 

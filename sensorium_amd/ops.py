@@ -272,10 +272,11 @@ class BlockFn(torch.autograd.Function):
         R = blk.se.conv_reduce.out_channels
         # gradients are allocated in the parameters' own shapes (same memory layout as the kernels' 2-D views) so
         # that autograd can take ownership instead of cloning a view
-        dw_pw = torch.zeros_like(blk.conv_pw[0].weight, dtype=torch.float32)
-        dw_dws = torch.zeros_like(blk.spat_covn_dw[0].weight, dtype=torch.float32)
-        dw_dwt = torch.zeros_like(blk.temp_covn_dw[0].weight, dtype=torch.float32)
-        dw_pwl = torch.zeros_like(blk.conv_pwl[0].weight, dtype=torch.float32)
+        # (dwn_block_backward clears the four atomically accumulated weight gradients itself, in its prep launch)
+        dw_pw = torch.empty_like(blk.conv_pw[0].weight, dtype=torch.float32)
+        dw_dws = torch.empty_like(blk.spat_covn_dw[0].weight, dtype=torch.float32)
+        dw_dwt = torch.empty_like(blk.temp_covn_dw[0].weight, dtype=torch.float32)
+        dw_pwl = torch.empty_like(blk.conv_pwl[0].weight, dtype=torch.float32)
         dse_wr = torch.empty_like(blk.se.conv_reduce.weight, dtype=torch.float32); dse_br = torch.empty(R, **f32)
         dse_we = torch.empty_like(blk.se.conv_expand.weight, dtype=torch.float32); dse_be = torch.empty(Cmid, **f32)
         a.dout = dout.data_ptr(); a.dx = dx.data_ptr()
