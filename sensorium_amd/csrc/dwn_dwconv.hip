@@ -21,6 +21,12 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
 #define DWS_THREADS 512      // threads per workgroup of the spatial forward kernel (more waves per LDS tile)
 #endif
 #define DWS_BWD_THREADS 256
+#ifndef DWS_BWD_PAIR_MINW
+#define DWS_BWD_PAIR_MINW 3       // waves per SIMD the pair-packed stride-1 backward is compiled for
+#endif
+#ifndef DWS_BWD_PAIR_XB
+#define DWS_BWD_PAIR_XB 2
+#endif
 #ifndef DWS_BWD_MINB1
 #define DWS_BWD_MINB1 3          // resident workgroups per CU the stride-1 spatial backward is compiled for
 #endif
@@ -1012,7 +1018,7 @@ int launch_dw_spatial_fwd(const DwSpatialFwd& a, int dtype, hipStream_t s) {
 // with Z = (z1[2j], z1[2j+1]) rounded to bf16 (the reference's autocast stores z1 in bf16): 8 VALU ops per stencil row,
 // channel and pixel pair instead of 6 unpacks + 6 packed FMAs.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(DWS_BWD_THREADS, 3) void dw_spatial_bwd_pair_kernel(const DwSpatialBwd a) {
+__global__ __launch_bounds__(DWS_BWD_THREADS, DWS_BWD_PAIR_MINW) void dw_spatial_bwd_pair_kernel(const DwSpatialBwd a) {
     typedef bf16_t T;
     constexpr int NT = DWS_BWD_THREADS, NCV = 16, CS = 64, LP = NT / NCV, KS = 3, P = 1;
     __shared__ float lstat[2 * CS];
@@ -1119,7 +1125,7 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, 3) void dw_spatial_bwd_pair_kernel
             const T* y10 = y1p + prow0 * a.y1.ld + chs;
             const int total = nri * Wip;
             const int grow0 = hi0 * a.Win;
-            constexpr int XB = 2;                    // pixel pairs in flight per thread
+            constexpr int XB = DWS_BWD_PAIR_XB;      // pixel pairs in flight per thread
             for (int i0 = pl; i0 < total; i0 += XB * LP) {
                 uint2 ry[XB][2];
                 int jj[XB], iyv[XB];
