@@ -592,7 +592,7 @@ int dwn_cortex_backward(const dwn_cortex_args* ap, int device, void* stream) {
 
 // ------------------------------------------------------------------------------------------------ readout
 namespace {
-struct ReadoutWs { void* wp; float* ones; float* zeros; void* dz; size_t bytes; int Npad, Rg, Rp; };
+struct ReadoutWs { void* wp; float* ones; float* zeros; void* dz; void* xd; size_t bytes; int Npad, Rg, Rp; };
 ReadoutWs carve_readout(const dwn_readout_args& a, int backward, void* base, size_t cap) {
     ReadoutWs w; memset(&w, 0, sizeof(w));
     Carver c(base, cap);
@@ -606,6 +606,7 @@ ReadoutWs carve_readout(const dwn_readout_args& a, int backward, void* base, siz
     w.ones = c.take<float>(a.Cin);
     w.zeros = c.take<float>(a.Cin);
     if (backward) w.dz = c.take<char>((size_t)M * a.groups * w.Rp * ts);
+    if (a.drop_mask) w.xd = c.take<char>((size_t)M * a.Cin * ts);      // x * dropout mask, materialised once
     w.bytes = c.off + 256;
     return w;
 }
@@ -624,12 +625,16 @@ int dwn_readout_forward(const dwn_readout_args* ap, int device, void* stream) {
     const int M = a.B * a.T, Kg = a.Cin / a.groups, dt = a.dtype;
     TRY(k_pack_weight(a.w, w.wp, 1, w.Npad, Kg, 0, w.Npad, Kg, dt, s));
     LoadDesc x = ld_plain(a.x, a.Cin);
-    int kind = LD_PLAIN;
+    const int kind = LD_PLAIN;
     if (a.drop_mask) {
+        // Dropout1d (dwiseneuro.py:275): the masked input (8 MB) is materialised once — applying the per-(sample,
+        // channel) mask inside the GEMM's operand loader put a dependent mask load in front of every A chunk
         TRY(k_fill_f32(w.ones, 1.0f, a.Cin, s));
         TRY(k_fill_f32(w.zeros, 0.0f, a.Cin, s));
-        x.v1 = w.ones; x.v2 = w.zeros; x.act = 0; x.gate = a.drop_mask; x.gate_ld = a.Cin; x.rows_per_sample = a.T;
-        kind = LD_BNACT;
+        LoadDesc xm = x;
+        xm.v1 = w.ones; xm.v2 = w.zeros; xm.act = 0; xm.gate = a.drop_mask; xm.gate_ld = a.Cin; xm.rows_per_sample = a.T;
+        TRY(k_ew_apply(xm, LD_BNACT, w.xd, a.Cin, M, a.Cin, dt, s));
+        x = ld_plain(w.xd, a.Cin);
     }
     GemmNN g = nn_base(x, kind, w.wp, Kg, nullptr, 0, M, w.Rg, Kg, a.groups);
     g.epi = EPI_READOUT; g.bias = a.bias; g.sp_beta = a.softplus_beta; g.out_nct = a.out; g.Tn = a.T; g.n_valid = a.n_out;
@@ -650,12 +655,14 @@ int dwn_readout_backward(const dwn_readout_args* ap, int device, void* stream) {
         TRY(launch_gemm_nn(g, dt, s));
     }
     LoadDesc x = ld_plain(a.x, a.Cin);
-    int kind = LD_PLAIN;
+    const int kind = LD_PLAIN;
     if (a.drop_mask) {
         TRY(k_fill_f32(w.ones, 1.0f, a.Cin, s));
         TRY(k_fill_f32(w.zeros, 0.0f, a.Cin, s));
-        x.v1 = w.ones; x.v2 = w.zeros; x.act = 0; x.gate = a.drop_mask; x.gate_ld = a.Cin; x.rows_per_sample = a.T;
-        kind = LD_BNACT;
+        LoadDesc xm = x;
+        xm.v1 = w.ones; xm.v2 = w.zeros; xm.act = 0; xm.gate = a.drop_mask; xm.gate_ld = a.Cin; xm.rows_per_sample = a.T;
+        TRY(k_ew_apply(xm, LD_BNACT, w.xd, a.Cin, M, a.Cin, dt, s));     // masked input for the weight gradient
+        x = ld_plain(w.xd, a.Cin);
         // grad wrt the un-dropped input: dx *= mask (in place)
         LoadDesc dxm = ld_plain(a.dx, a.Cin);
         dxm.v1 = w.ones; dxm.v2 = w.zeros; dxm.act = 0; dxm.gate = a.drop_mask; dxm.gate_ld = a.Cin; dxm.rows_per_sample = a.T;
