@@ -1199,6 +1199,7 @@ __global__ void cortex_bwd_reduce_kernel(const T* y, const T* x, const T* dout, 
     int j = (o % (C / groups)) * groups + o / (C / groups);
     float s = coef[o], t = coef[C + o], mean = coef[2 * C + o], invstd = coef[3 * C + o];
     float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
     for (int m = m_beg; m < m_end; ++m) {
         float yv = to_f<T>(y[(i64)m * C + o]);
         float g = to_f<T>(dout[(i64)m * C + j]);
@@ -1215,6 +1216,7 @@ __global__ void cortex_bwd_reduce_kernel(const T* y, const T* x, const T* dout, 
     j = ch;
     float ms = coefsc[2 * C + j], is = coefsc[3 * C + j];
     float b0 = 0.f, b1 = 0.f;
+#pragma unroll 8
     for (int m = m_beg; m < m_end; ++m) {
         float g = to_f<T>(dout[(i64)m * C + j]);
         if (gmask) g *= gmask[(i64)(m / Tn) * gmask_ld + j];
@@ -1274,7 +1276,7 @@ int k_cortex_residual_fwd(const void* y, const void* x, const float* coef, const
 int k_cortex_bwd_reduce(const void* y, const void* x, const void* dout, const float* gmask, int gmask_ld,
                         const float* coef, const float* coefsc, const float* dscale, int M, int Tn, int Cin, int C,
                         int groups, double* stats, double* statssc, int dtype, hipStream_t s) {
-    int rows_per_chunk = 64;
+    int rows_per_chunk = 16;           // short per-thread row loops: the kernel is a latency chain, not a byte mover
     dim3 grid((C + 127) / 128, (M + rows_per_chunk - 1) / rows_per_chunk);
     DISPATCH_T(dtype,
         hipLaunchKernelGGL((cortex_bwd_reduce_kernel<bf16_t>), grid, dim3(128), 0, s, (const bf16_t*)y, (const bf16_t*)x, (const bf16_t*)dout, gmask, gmask_ld, coef, coefsc, dscale, M, Tn, Cin, C, groups, rows_per_chunk, stats, statssc),
