@@ -994,6 +994,7 @@ __global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const float* dgp, con
     const int r = blockIdx.y;
     if (c < C) {
         float a = 0.f, a2 = 0.f, sb = 0.f;
+#pragma unroll 8
         for (int b = 0; b < B; ++b) {
             float g = dgp[(i64)b * C + c];
             a = fmaf(g, siluf_(hid_pre[(i64)b * R + r]), a);
@@ -1673,8 +1674,12 @@ __global__ __launch_bounds__(256) void pw_bwd_gram_kernel(const float* w1, const
     const float* A2 = abc + E;
     const float* A3 = abc + 2 * E;
     float acc = 0.f, acc3 = 0.f;
-    for (int e = e0; e < e1; ++e) {
-        const float wc = round_t<T>(w1[(i64)e * C + c]);
+    (void)e1;
+#pragma unroll 16
+    for (int i = 0; i < 64; ++i) {            // fixed trip count + clamped index: 16 x 4 independent loads in flight
+        const int e = e0 + i < E ? e0 + i : E - 1;
+        const float on = e0 + i < E ? 1.f : 0.f;
+        const float wc = round_t<T>(w1[(i64)e * C + c]) * on;
         acc = fmaf(A2[e] * round_t<T>(w1[(i64)e * C + cp]), wc, acc);
         acc3 = fmaf(A3[e], wc, acc3);
     }
