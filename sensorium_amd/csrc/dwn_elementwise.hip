@@ -299,21 +299,31 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(LoadDesc dy, const float*
     for (int c = 0; c < MAXCIN; ++c)
 #pragma unroll
         for (int i = 0; i < KC; ++i) acc[c][i] = 0.f;
-    const i64 rows = (i64)B * S;
-    if (chan_ok)
-        for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
-            i64 b = row / S, sp = row % S;
-            float g[KC];
-            load_op<LD_AFFINE2, T>(dy, row, chan, g);
+    const unsigned rows = (unsigned)((i64)B * S);          // < 2^31 (checked by the launcher)
+    const UDiv32 dS((unsigned)S);
+    if (chan_ok) {
+        constexpr int RU = 2;                              // rows in flight per thread
+        const unsigned stride = gridDim.x * 32u;
+        for (unsigned row0 = blockIdx.x * 32u + pl; row0 < rows; row0 += RU * stride) {
+            float g[RU][KC], xv[RU][MAXCIN];
 #pragma unroll
-            for (int c = 0; c < MAXCIN; ++c) {
-                if (c < Cin) {
-                    float xv = x[(b * Cin + c) * S + sp];
+            for (int u = 0; u < RU; ++u) {
+                const unsigned row = row0 + u * stride < rows ? row0 + u * stride : row0;
+                const unsigned b = dS.div(row), sp = row - b * (unsigned)S;
+                load_op<LD_AFFINE2, T>(dy, (i64)row, chan, g[u]);
 #pragma unroll
-                    for (int i = 0; i < KC; ++i) acc[c][i] = fmaf(g[i], xv, acc[c][i]);
-                }
+                for (int c = 0; c < MAXCIN; ++c) xv[u][c] = c < Cin ? x[((i64)b * Cin + c) * S + sp] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                if (row0 + u * stride >= rows) break;
+#pragma unroll
+                for (int c = 0; c < MAXCIN; ++c)
+#pragma unroll
+                    for (int i = 0; i < KC; ++i) acc[c][i] = fmaf(g[u][i], xv[u][c], acc[c][i]);
             }
         }
+    }
 #pragma unroll
     for (int c = 0; c < MAXCIN; ++c)
 #pragma unroll
