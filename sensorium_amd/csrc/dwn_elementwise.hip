@@ -345,24 +345,38 @@ __global__ __launch_bounds__(256) void stem_bn_pe_kernel(const T* y0, const floa
     float sc[KC], sh[KC];
     ld_coef<KC>(coef + chan, sc);
     ld_coef<KC>(coef + C + chan, sh);
-    for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
-        float v[KC];
-        ld_vec<T>(y0 + row * C + chan, v);
+    const RasterIdx ro(H, W);
+    const UDiv32 dT((unsigned)Tn);
+    constexpr int RU = 2;                                    // rows in flight per thread
+    const unsigned nrows = (unsigned)rows, stride = gridDim.x * 32u;
+    for (unsigned row0 = blockIdx.x * 32u + pl; row0 < nrows; row0 += RU * stride) {
+        uint4 raw[RU];
 #pragma unroll
-        for (int i = 0; i < KC; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
-        if (pe_t) {
-            unsigned r32 = (unsigned)row;
-            unsigned r2 = r32 / (unsigned)W, w = r32 - r2 * (unsigned)W;
-            unsigned r3 = r2 / (unsigned)H, h = r2 - r3 * (unsigned)H;
-            unsigned t = r3 % (unsigned)Tn;
-            float pa[KC], pb[KC], pc[KC];
-            ld_coef<KC>(pe_t + (i64)t * C + chan, pa);
-            ld_coef<KC>(pe_h + (i64)h * C + chan, pb);
-            ld_coef<KC>(pe_w + (i64)w * C + chan, pc);
-#pragma unroll
-            for (int i = 0; i < KC; ++i) v[i] = round_t<T>(v[i]) + ((pa[i] + pb[i]) + pc[i]);
+        for (int u = 0; u < RU; ++u) {
+            const unsigned row = row0 + u * stride < nrows ? row0 + u * stride : row0;
+            raw[u] = *reinterpret_cast<const uint4*>(y0 + (i64)row * C + chan);
         }
-        st_vec<T>(out + row * C + chan, v);
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const unsigned row = row0 + u * stride;
+            if (row >= nrows) break;
+            float v[KC];
+            unpack16<T>(raw[u], v);
+#pragma unroll
+            for (int i = 0; i < KC; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
+            if (pe_t) {
+                unsigned f; int h, w;
+                ro.decode(row, f, h, w);
+                const unsigned t = f - dT.div(f) * (unsigned)Tn;
+                float pa[KC], pb[KC], pc[KC];
+                ld_coef<KC>(pe_t + (i64)t * C + chan, pa);
+                ld_coef<KC>(pe_h + (i64)h * C + chan, pb);
+                ld_coef<KC>(pe_w + (i64)w * C + chan, pc);
+#pragma unroll
+                for (int i = 0; i < KC; ++i) v[i] = round_t<T>(v[i]) + ((pa[i] + pb[i]) + pc[i]);
+            }
+            st_vec<T>(out + (i64)row * C + chan, v);
+        }
     }
 }
 int k_stem_bn_pe(const void* y0, const float* coef, const float* pe_t, const float* pe_h, const float* pe_w, int Tn,
