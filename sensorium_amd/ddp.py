@@ -3,8 +3,9 @@ RCCL all-reduce over xGMI launched from autograd hooks so it overlaps with the r
 
 The reference has no distributed code; this is the one exchange step data parallelism adds:
 an all-reduce (mean) of the parameter gradients per iteration.  Buckets are built in *reverse* registration
-order — readouts (≈16 M params each, ready first in backward) lead, the ~200 small trunk tensors share one
-flat buffer — so the big transfers are issued while the core backward (≈95 % of the step) is still running.
+order — readouts (≈16 M params each, ready first in backward) lead, then the cortex and the ~200 small core tensors
+in ≈12 MB buckets — so the big transfers are issued while the core backward (≈95 % of the step) is still running
+and only the last small bucket (first blocks + stem) is exposed after it.
 BatchNorm statistics stay local to each rank (standard DDP semantics).
 """
 from __future__ import annotations
@@ -16,7 +17,7 @@ import torch.distributed as dist
 
 
 class GradBuckets:
-    def __init__(self, module: torch.nn.Module, bucket_cap_mb: float = 64.0, process_group=None,
+    def __init__(self, module: torch.nn.Module, bucket_cap_mb: float = 12.0, process_group=None,
                  broadcast_init: bool = True):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -29,7 +30,7 @@ class GradBuckets:
         cur: List[torch.nn.Parameter] = []
         cur_n = 0
         for p in reversed(params):
-            if cur and cur_n + p.numel() > cap:
+            if cur and cur_n + p.numel() > cap and cur_n * 8 > cap:      # tiny leftovers ride with the next tensor
                 self._add_bucket(cur)
                 cur, cur_n = [], 0
             cur.append(p)
