@@ -11,6 +11,14 @@
 // weight-gradient and statistics accumulators live in registers for the whole persistent (grid-stride) kernel.
 // Loads are issued in batches of 4 independent 8/16-byte vectors per tensor so that, at 3-5 waves per SIMD,
 // each CU keeps tens of KB in flight (the HBM latency-bandwidth product).
+//
+// Kernel families in this file:
+//   dw_spatial_fwd_kernel / dw_spatial_bwd_kernel      generic (fp32 parity mode, any stride): packed-fp32 taps
+//   dw_spatial_fwd_pair_kernel (stride 1, 2)            bf16: x-pair-packed LDS tile + v_dot2c_f32_bf16 taps
+//   dw_spatial_bwd_pair_kernel (stride 1)               bf16: same idea for the data and weight gradients
+//   dw_temporal_fwd_kernel / dw_temporal_bwd_kernel     register sliding window along T
+// Integer index math is kept off the per-tap path (FastDiv / 24-bit multiplies / per-pixel tile index): on gfx950 an
+// integer VALU op costs ~1.5 FMAs and a bf16->fp32 unpack is such an op (profiles/r1c_valu_rates.txt).
 #include "dwn_internal.h"
 #include <stdlib.h>
 #include <type_traits>

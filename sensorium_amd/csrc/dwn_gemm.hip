@@ -6,8 +6,13 @@
 //    producer's BN/SiLU/SE-gate/positional-encoding/BN-backward affine is applied in flight
 //    (dwn_common.h loaders); the epilogue stages the tile through LDS so every global store is a full
 //    contiguous row segment, and folds in the batch-norm Σ/Σ² of the *next* BN.
-//  * gemm_tn : dW[R][Cc] += load(P)^T . load(Q), contraction over M, split over workgroups with fp32
-//    atomics.  bf16 fragments come from row-major LDS tiles through ds_read_b64_tr_b16.
+//    Two instantiations: resident-B (K <= one k-tile; weights stay in LDS, the next tile's rows are prefetched
+//    under the MFMAs and the epilogue, branch-free fast epilogue so the compiler's vmcnt counts are exact) and
+//    k-loop (next k-tile, or the next tile's first k-tile under the epilogue).  Staging is split into an issue
+//    phase (raw registers) and a write phase (prologue math + ds_write) after the MFMAs.
+//  * gemm_tn : dW[R][Cc] += load(P)^T . load(Q), contraction over M, split over exactly one resident round of
+//    workgroups with fp32 atomics, XCD-aware tile order.  bf16 fragments come from row-major LDS tiles through
+//    ds_read_b64_tr_b16.
 //
 // MFMA shapes: v_mfma_f32_16x16x32_bf16 (bf16 storage) and v_mfma_f32_16x16x4_f32 (fp32 parity
 // mode, bit-exact fp32 FMA chain).  Operand maps (cdna_hip_programming.md §3): lane l holds
