@@ -46,6 +46,11 @@ CASES = [
     (16, 16, 1, 3, 4, 2, 5, 3, 3),
     (64, 64, 2, 7, 32, 2, 4, 12, 16),
     (64, 128, 1, 7, 32, 1, 8, 9, 16),
+    # degenerate geometry: fewer frames than the temporal kernel, single-row / single-column planes, ragged slices
+    (8, 8, 1, 3, 4, 1, 2, 2, 3),
+    (8, 16, 2, 3, 4, 2, 3, 1, 5),
+    (24, 40, 2, 7, 4, 2, 4, 7, 9),
+    (16, 16, 1, 5, 4, 2, 1, 4, 1),
 ]
 
 
