@@ -458,7 +458,9 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     // temporal dw backward
     {
         DwTemporalBwd d; memset(&d, 0, sizeof(d));
-        d.dy = ld_affine2(du, a.y3, a.Cmid, w.abc3, a.Cmid); d.dy_kind = LD_AFFINE2;
+        static const bool rc_off = getenv("DWN_DWT_NORECOMP") != nullptr;
+        d.dy = ld_affine2(du, a.y3, a.Cmid, w.abc3, a.Cmid);
+        d.dy_kind = rc_off ? LD_AFFINE2 : LD_PLAIN;     // LD_PLAIN: y3 is recomputed from y2 inside the kernel
         d.y2 = ld_ycoef(a.y2, a.Cmid, a.bn2.coef, a.Cmid);
         d.w = w.wdwt; d.dh2 = a.buf_b; d.dw = a.dw_dwt; d.B = a.B; d.T = a.T; d.HW = a.Hout * a.Wout; d.C = a.Cmid;
         d.kt = a.kt; d.stats = w.st2;

@@ -38,6 +38,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
 #ifndef DWS_BWD_MINB1
 #define DWS_BWD_MINB1 3          // resident workgroups per CU the stride-1 spatial backward is compiled for
 #endif
+#ifndef DWT_RC_MINW
+#define DWT_RC_MINW 2        // waves per SIMD the y3-recomputing temporal backward is compiled for
+#endif
 #ifndef DWT_BWD_TB
 #define DWT_BWD_TB 4          // timesteps of loads in flight per thread in the temporal backward (4 or 8)
 #endif
@@ -1284,6 +1287,139 @@ int launch_dw_temporal_fwd(const DwTemporalFwd& a, int dtype, hipStream_t s) {
     return dtype == DWN_BF16 ? temporal_fwd_t<bf16_t>(a, s) : temporal_fwd_t<float>(a, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// temporal backward without reading y3 (dy_kind == LD_PLAIN: dy.p = dh3, dy.v1..v3 = bn3-backward A1, A2, A3).
+// dy3 = A1*dh3 + A2*y3 + A3 needs y3 = sum_j w[j] z2[t + j - P], and z2 = SiLU(BN2(y2)) is computed here anyway (for dW
+// and SiLU'): y3 is recomputed from a (2P+1)-deep window of z2 that runs 2P frames ahead of the output frame.
+// Three passes over the E-wide tensors (dh3, y2 in; dh2 out) instead of four; 5 extra FMAs per element.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int KT>
+__global__ __launch_bounds__(256, DWT_RC_MINW) void dw_temporal_bwd_rc_kernel(const DwTemporalBwd a) {
+    constexpr int NCV = SL<T>::NCV, CS = SL<T>::CS, LP = SL<T>::LP, P = KT / 2, NW = 2 * P + 1;
+    constexpr int TB = NW;            // frames per unrolled batch == window length: ring indices are compile-time, no shifting
+    static_assert(NW == KT, "ring rotation below assumes an odd kernel: window length == kernel length");
+    typedef typename SL<T>::raw_t raw_t;
+    __shared__ float lstat[2 * CS];
+    __shared__ float lw[KT * CS];
+    const int tid = threadIdx.x;
+    const int cv = tid % NCV, pl = tid / NCV;
+    const int c0 = blockIdx.y * CS;
+    const int chan = c0 + cv * 4;
+    const bool chan_ok = chan < a.C;
+    const int chs = chan_ok ? chan : 0;
+    if (tid < 2 * CS) lstat[tid] = 0.f;
+    for (int i = tid; i < KT * CS; i += 256) lw[i] = 0.f;
+    __syncthreads();
+    float w[KT][4], dwacc[KT][4];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        ldc4(a.w + (i64)k * a.C + chs, w[k]);
+        dwacc[k][0] = dwacc[k][1] = dwacc[k][2] = dwacc[k][3] = 0.f;
+    }
+    float bs[4], bt[4], bm[4], bi[4], a1[4], a2[4], a3[4];
+    ldc4(a.y2.v1 + chs, bs); ldc4(a.y2.v2 + chs, bt); ldc4(a.y2.v3 + chs, bm); ldc4(a.y2.v4 + chs, bi);
+    ldc4(a.dy.v1 + chs, a1); ldc4(a.dy.v2 + chs, a2); ldc4(a.dy.v3 + chs, a3);
+    float st0[4] = {0.f, 0.f, 0.f, 0.f}, st1[4] = {0.f, 0.f, 0.f, 0.f};
+
+    const i64 npos = (i64)a.B * a.HW;
+    T* dhp = reinterpret_cast<T*>(a.dh2);
+    const T* y2p = reinterpret_cast<const T*>(a.y2.p);
+    const T* dpp = reinterpret_cast<const T*>(a.dy.p);
+    const i64 tstride = (i64)a.HW * a.C;
+
+    if (chan_ok) {
+        for (i64 pos = (i64)blockIdx.x * LP + pl; pos < npos; pos += (i64)gridDim.x * LP) {
+            const i64 b = pos / a.HW, hw = pos % a.HW;
+            const i64 e0 = (b * a.T * a.HW + hw) * a.C + chan;
+            // rings of NW = KT slots: at unrolled step u of a batch, frame t + j of (y2, z2, SiLU') lives in slot
+            // (u + j) % NW and dy3(t + k - P) in win[(u + k) % KT].  Frames outside [0, T) are zero slots.
+            float yw[NW][4], zw[NW][4], dsw[NW][4], win[KT][4];
+#pragma unroll
+            for (int j = 0; j < NW; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { yw[j][i] = 0.f; zw[j][i] = 0.f; dsw[j][i] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < KT; ++k) win[k][0] = win[k][1] = win[k][2] = win[k][3] = 0.f;
+            auto activate = [&](const raw_t& raw, float* y, float* z, float* ds) {
+                V4<T>::unpack(raw, y);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float h = fmaf(y[i], bs[i], bt[i]);
+                    const float sg = sigmoidf_(h);
+                    z[i] = h * sg;
+                    ds[i] = sg * (1.0f + h * (1.0f - sg));
+                }
+            };
+            // at virtual frame t = -P the window covers frames -P .. P-1: load frames 0 .. P-1 into slots P .. 2P-1
+#pragma unroll
+            for (int j = 0; j < P; ++j)
+                if (j < a.T) activate(ld4_raw<T>(y2p + e0 + j * tstride), yw[P + j], zw[P + j], dsw[P + j]);
+            for (int t0 = -P; t0 < a.T; t0 += TB) {
+                raw_t rp[TB], ry[TB];
+#pragma unroll
+                for (int u = 0; u < TB; ++u) {
+                    const int td = t0 + u + P, ty = t0 + u + 2 * P;          // frames of dh3 / y2 fetched for output frame t0+u
+                    rp[u] = ld4_raw<T>(dpp + e0 + (td < a.T ? td : 0) * tstride);
+                    ry[u] = ld4_raw<T>(y2p + e0 + (ty < a.T ? ty : 0) * tstride);
+                }
+#pragma unroll
+                for (int u = 0; u < TB; ++u) {
+                    const int t = t0 + u;
+                    if (t >= a.T) break;
+                    // newest window slot: frame t + 2P
+                    const int sn = (u + NW - 1) % NW;                   // newest slot (frame t + 2P)
+                    if (t + 2 * P < a.T) activate(ry[u], yw[sn], zw[sn], dsw[sn]);
+                    else { for (int i = 0; i < 4; ++i) { yw[sn][i] = 0.f; zw[sn][i] = 0.f; dsw[sn][i] = 0.f; } }
+                    const int s0 = u % NW;                              // slot of the output frame t
+                    // dy3(t + P) from dh3 and the recomputed y3(t + P) = sum_j w[j] z2(t + j)
+                    if (t + P < a.T) {
+                        float p[4];
+                        V4<T>::unpack(rp[u], p);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float y3 = 0.f;
+#pragma unroll
+                            for (int j = 0; j < KT; ++j) y3 = fmaf(w[j][i], zw[(u + j) % NW][i], y3);
+                            win[sn][i] = fmaf(a1[i], p[i], fmaf(a2[i], round_t<T>(y3), a3[i]));
+                        }
+                    } else { win[sn][0] = win[sn][1] = win[sn][2] = win[sn][3] = 0.f; }
+                    if (t >= 0) {
+                        float dh[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float dz = 0.f;
+#pragma unroll
+                            for (int k = 0; k < KT; ++k) {
+                                const float gk = win[(u + KT - 1 - k) % KT][i];
+                                dz = fmaf(w[k][i], gk, dz);
+                                dwacc[k][i] = fmaf(zw[s0][i], gk, dwacc[k][i]);
+                            }
+                            dh[i] = dz * dsw[s0][i];
+                        }
+                        st4<T>(dhp + e0 + t * tstride, dh);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float r = round_t<T>(dh[i]);
+                            st0[i] += r;
+                            st1[i] += r * (yw[s0][i] - bm[i]) * bi[i];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(&lw[k * CS + cv * 4 + i], dwacc[k][i]);
+    }
+    __syncthreads();
+    for (int i = tid; i < KT * CS; i += 256) {
+        int k = i / CS, c = c0 + i % CS;
+        if (c < a.C) atomicAdd(a.dw + (i64)c * KT + k, lw[i]);
+    }
+    if (a.stats) block_stats_flush<T>(lstat, st0, st1, cv, c0, a.C, a.stats, blockIdx.x % DWN_NREP);
+}
+
 template <typename T>
 static int temporal_bwd_t(const DwTemporalBwd& a, hipStream_t s) {
     constexpr int CS = SL<T>::CS, LP = SL<T>::LP;
@@ -1292,6 +1428,17 @@ static int temporal_bwd_t(const DwTemporalBwd& a, hipStream_t s) {
     const i64 npos = (i64)a.B * a.HW;
     const i64 work = (npos + LP - 1) / LP;
     const bool dy3 = a.dy_kind == LD_DY3;
+    if (a.dy_kind == LD_PLAIN) {       // dy.p = dh3 only: y3 is recomputed from y2 (three passes instead of four)
+        if (a.kt == 5) {
+            dim3 grid(resident_grid_x(dw_temporal_bwd_rc_kernel<T, 5>, 0, slices, work), slices);
+            hipLaunchKernelGGL((dw_temporal_bwd_rc_kernel<T, 5>), grid, dim3(256), 0, s, a);
+        } else if (a.kt == 3) {
+            dim3 grid(resident_grid_x(dw_temporal_bwd_rc_kernel<T, 3>, 0, slices, work), slices);
+            hipLaunchKernelGGL((dw_temporal_bwd_rc_kernel<T, 3>), grid, dim3(256), 0, s, a);
+        } else return dwn_set_error(-4, "dw_temporal: only temporal_kernel 3 or 5 is built");
+        DWN_CHECK_LAUNCH();
+        return 0;
+    }
     dim3 grid(resident_grid_x(dw_temporal_bwd_kernel<T, 5, LD_AFFINE2, 4>, 0, slices, work), slices);
     if (!dy3 && a.dy_kind != LD_AFFINE2) return dwn_set_error(-3, "dw_temporal_bwd: unsupported dy loader");
     static const int tb8 = getenv("DWN_DWT_TB") ? atoi(getenv("DWN_DWT_TB")) == 8 : (DWT_BWD_TB == 8);
