@@ -133,7 +133,8 @@ typedef struct dwn_dw_temporal_fwd_args {
 } dwn_dw_temporal_fwd_args;
 
 typedef struct dwn_dw_temporal_bwd_args {
-    dwn_load_desc dy; int dy_kind;   /* DWN_LD_DY3 or DWN_LD_AFFINE2 */
+    dwn_load_desc dy; int dy_kind;   /* DWN_LD_AFFINE2: dy3 = v1*p + v2*q + v3 from (dh3, y3); DWN_LD_PLAIN: p = dh3 only and
+                                      * y3 is recomputed from y2 inside the kernel (one E-wide pass less); DWN_LD_DY3 */
     dwn_load_desc y2;                /* p = raw y2; v1..v4 = bn2 scale, shift, mean, invstd */
     const float* w;
     void* dh2;
