@@ -559,12 +559,20 @@ int launch_gemm_nn(const GemmNN& g, int dtype, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // TN (weight gradient): dW[R][Cc] += sum_m P[m][r] Q[m][c]
 // ------------------------------------------------------------------------------------------------
+#ifndef TN_MINW_PLAIN
+#define TN_MINW_PLAIN 3
+#endif
 template <typename T> struct TnCfg;
 template <> struct TnCfg<bf16_t> { static constexpr int PAD = 32; };   // 8 rows x 32 B shift -> conflict-free tr reads
 template <> struct TnCfg<float>  { static constexpr int PAD = 64; };   // 16-bank shift between the two rows of a half-wave
 
+// single-tensor loaders fit three waves per SIMD (the kernel's pace is one global-load latency per 64-row step, so a
+// third resident workgroup per CU is +50 % steps in flight); the two-tensor BatchNorm-backward loader needs the registers
+template <int PLD, int QLD> struct TnOcc {
+    static constexpr int value = (PLD == LD_AFFINE2 || PLD == LD_DY3 || QLD == LD_AFFINE2 || QLD == LD_DY3) ? 2 : TN_MINW_PLAIN;
+};
 template <typename T, int PLD, int QLD>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN g) {
+__global__ __launch_bounds__(256, (TnOcc<PLD, QLD>::value)) void gemm_tn_kernel(const GemmTN g) {
     constexpr int KC = TT<T>::KC;
     constexpr int BR = 128, BC = 128, BMK = TT<T>::IS_BF16 ? 64 : 32;   // M rows per step
     constexpr int RS = BR * (int)sizeof(T) + TnCfg<T>::PAD;      // LDS row stride (bytes), both tiles
