@@ -162,3 +162,20 @@ def test_eval_forward_is_hipgraph_capturable(golden_dir):
         graph.replay()                            # replays must be idempotent (all workspaces re-zeroed inside the graph)
         torch.cuda.synchronize()
         assert rel(static_out, eager) < 1e-5
+
+
+def test_pointer_table_cache_uploads_only_on_change():
+    """optim._TableCache: the device copy of a pointer table is reused while its contents are unchanged."""
+    import numpy as np
+    from sensorium_amd.optim import _ENTRY_DTYPE, _TableCache
+    cache = _TableCache()
+    e = np.zeros(3, dtype=_ENTRY_DTYPE)
+    e["numel"] = [1, 2, 3]
+    a = cache.get(e, dev())
+    b = cache.get(e.copy(), dev())
+    assert b is a
+    e["numel"][0] = 9
+    c = cache.get(e, dev())
+    assert c is not a
+    torch.cuda.synchronize()
+    assert bytes(c.cpu().numpy().tobytes()) == e.view(np.uint8).tobytes()

@@ -150,3 +150,22 @@ def test_corr_and_window_indexes(golden_dir):
     gen = IndexesGenerator(16, 2, "last")
     assert (gen.behind, gen.ahead, gen.width) == (30, 0, 31)
     assert gen.make_indexes(30) == list(range(0, 31, 2)) == orc.window_indexes(30, 16, 2)
+
+
+def test_grad_bucket_layout_for_the_benchmark_model():
+    """Reverse registration order, ~12 MB core buckets, the big readout weight first (ready first in backward)."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    from bench import model_params
+    from sensorium_amd import DwiseNeuro
+    from sensorium_amd.ddp import GradBuckets
+    model = DwiseNeuro(**model_params(7)["nn_module"][1])
+    buckets = GradBuckets(model)
+    sizes = [b["flat"].numel() * 4 / 2 ** 20 for b in buckets.buckets]
+    params = [p for p in model.parameters() if p.requires_grad]
+    assert buckets.buckets[0]["params"][0] is params[-1]                    # last registered parameter leads
+    assert sum(b["flat"].numel() for b in buckets.buckets) == sum(p.numel() for p in params)
+    assert sizes[0] > 60 and all(s < 20 for s in sizes[1:]) and len(sizes) >= 3, sizes
+    assert sizes[-1] < 12, sizes                                            # the only bucket exposed after backward
+
