@@ -16,6 +16,7 @@ instead of a python loop over ``argwhere``; under ``torch.distributed`` gradient
 """
 from __future__ import annotations
 
+import logging
 from typing import Optional
 
 import torch
@@ -24,6 +25,7 @@ import torch.distributed as dist
 from .ddp import GradBuckets
 from .dwiseneuro import DwiseNeuro
 from .ema import ModelEma
+from .engine import Model
 from .losses import MicePoissonLoss
 from .optim import FusedAdamWEma
 
@@ -71,18 +73,21 @@ def fill_distill_targets(distill_prediction, target, distill_ratio: float):
     mice_weights.copy_(torch.where(distill_mask, distill_weight.to(mice_weights.dtype), mice_weights))
 
 
-class MouseModel:
+class MouseModel(Model):
+    """``fit`` / ``validate`` / ``save`` come from ``engine.Model`` (the argus surface train.py:141-145 uses);
+    ``load_model`` finds this class by the ``model_name`` stored in the checkpoint."""
     nn_module = {"dwiseneuro": DwiseNeuro}
     loss = {"mice_poisson": MicePoissonLoss}
     optimizer = {"AdamW": FusedAdamWEma}
 
     def __init__(self, params: dict):
         self.params = params
+        self.logger = logging.getLogger("sensorium_amd")
         name, kwargs = params["nn_module"]
         self.device = torch.device(params.get("device", "cuda:0"))
-        self.nn_module = self.nn_module[name](**kwargs).to(self.device)
-        lname, lkwargs = params.get("loss", ("mice_poisson", {}))
-        self.loss = self.loss[lname](**lkwargs)
+        self.nn_module = MouseModel.nn_module[name](**kwargs).to(self.device)
+        loss_spec = params.get("loss", ("mice_poisson", {}))
+        self.loss = None if loss_spec is None else MouseModel.loss[loss_spec[0]](**loss_spec[1])
         self.iter_size = int(params.get("iter_size", 1))
         self.amp = bool(params.get("amp", False))
         self.grad_scaler = torch.amp.GradScaler("cuda", enabled=False)   # bf16 needs no loss scaling
@@ -100,9 +105,15 @@ class MouseModel:
         self.model_ema = ModelEma(self.nn_module, decay=decay)
         self.optimizer = None
 
+    def get_optimizer(self):
+        self._ensure_optimizer()
+        return self.optimizer
+
     def _ensure_optimizer(self):
         if self.optimizer is not None:
             return
+        if self._opt_spec is None:
+            raise RuntimeError("model has no optimizer (loaded with optimizer=None)")
         oname, okwargs = self._opt_spec
         params = [p for p in self.nn_module.parameters() if p.requires_grad]
         ema_params = None

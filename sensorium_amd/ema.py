@@ -6,6 +6,7 @@ from copy import deepcopy
 import torch
 from torch import nn
 
+from .callbacks import Checkpoint
 from .optim import ema_lerp_state
 
 
@@ -39,3 +40,15 @@ class ModelEma(nn.Module):
     def set(self, model: nn.Module):
         for e, m in zip(self.ema.state_dict().values(), model.state_dict().values()):
             e.copy_(m)
+
+
+class EmaCheckpoint(Checkpoint):
+    """Checkpoint that stores the EMA weights (reference: src/ema.py:60-72), in argus' file format
+    ``{'model_name', 'params', 'nn_state_dict'}`` so ``load_model`` / the predictor read it back unchanged."""
+
+    def save_model(self, state, file_path):
+        nn_module = state.model.model_ema.ema
+        torch.save({"model_name": type(state.model).__name__, "params": state.model.params,
+                    "nn_state_dict": {k: v.detach().to("cpu") for k, v in nn_module.state_dict().items()}},
+                   str(file_path))
+        state.logger.info(f"Model saved to '{file_path}'")
