@@ -228,6 +228,32 @@ typedef struct dwn_tensor_entry {
     long long numel; int is_int64; int pad_;
 } dwn_tensor_entry;
 
+/* ---- batch assembly on the device --------------------------------------------------------
+ * A trial stays resident in HBM in the reference's on-disk layout (src/datasets.py:37-51, src/data.py:59-70):
+ * video [H0][W0][L] (uint8 or float32), behavior [2][L], pupil_center [2][L], responses [N][L] (float32).
+ * `dwn_clip_src` names one window of one trial: frame of window position t = frame_start + t*frame_step
+ * (IndexesGenerator.make_indexes, src/indexes.py:23-30).  The caller guarantees the frames lie inside [0, length). */
+#define DWN_VID_U8 0
+#define DWN_VID_F32 1
+typedef struct dwn_clip_src {
+    const void* video; const float* behavior; const float* pupil_center; const float* responses;
+    long long length;
+    int video_dtype;
+    int frame_start, frame_step;
+    int valid;                       /* 0 = slot unused */
+} dwn_clip_src;
+/* One sample of the batch: `src`, optionally cut-mixed with `mix` (same mouse): rows [bbx1,bbx2) x columns [bby1,bby2)
+ * of all five input channels come from `mix` — the reference pastes its "x" range onto the row axis, mixers.py:63 —
+ * and the target is one_minus_lam*relu(src) + lam*relu(mix) with lam = box area / (H*W) (mixers.py:64-65), both
+ * factors rounded to float by the caller. */
+typedef struct dwn_clip_desc {
+    dwn_clip_src src, mix;
+    int bbx1, bby1, bbx2, bby2;
+    float one_minus_lam, lam;
+    int mouse;                       /* owner: index into the per-mouse target table */
+    int pad_;
+} dwn_clip_desc;
+
 /* opt-in kernel-family timer: HIP events recorded on the launch stream around the block-level kernels.
  * Used by bench.py for the live roofline measurement; disabled (mask 0) by default. */
 enum {
@@ -288,6 +314,19 @@ int dwn_adamw_ema_multi(const dwn_tensor_entry* list, int ntensors, int max_bloc
                         double grad_scale, int device, void* stream);
 int dwn_ema_lerp_multi(const dwn_tensor_entry* list, int ntensors, int max_blocks, double decay, int device,
                        void* stream);
+
+
+/* StackInputsProcessor + CutMix on the inputs (inputs.py:15-36, mixers.py:52-63) for a whole batch:
+ * x [B][5][T][H][W] fp32 = channel 0 the video centre-padded with pad_fill, channels 1-2 behavior, 3-4 pupil_center
+ * broadcast over the frame.  `descs` is a DEVICE array of B entries; every video has the same H0 x W0. */
+int dwn_assemble_inputs(const dwn_clip_desc* descs, int B, int T, int H0, int W0, int H, int W, float pad_fill,
+                        float* x, int device, void* stream);
+/* responses_to_tensor + CutMix target blend + construct_mice_sample + collate (responses.py:25-29, mixers.py:64-66,
+ * datasets.py:172-187): targets[m] (DEVICE table of n_mice pointers) is [B][n_neurons[m]][T] fp32, fully overwritten —
+ * the owner's rows with the target, every other mouse's rows of that sample with zeros; mice_weights [B][n_mice]
+ * one-hot.  `max_neurons` = max over n_neurons (host copy, sizes the grid). */
+int dwn_assemble_targets(const dwn_clip_desc* descs, int B, int T, float* const* targets, const int* n_neurons,
+                         int n_mice, int max_neurons, float* mice_weights, int device, void* stream);
 
 #ifdef __cplusplus
 }

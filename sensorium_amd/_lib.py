@@ -133,12 +133,25 @@ class TensorEntry(C.Structure):
                 ("numel", c_ll), ("is_int64", c_i), ("pad_", c_i)]
 
 
+class ClipSrc(C.Structure):
+    _fields_ = [("video", c_p), ("behavior", c_p), ("pupil_center", c_p), ("responses", c_p), ("length", c_ll),
+                ("video_dtype", c_i), ("frame_start", c_i), ("frame_step", c_i), ("valid", c_i)]
+
+
+class ClipDesc(C.Structure):
+    _fields_ = [("src", ClipSrc), ("mix", ClipSrc), ("bbx1", c_i), ("bby1", c_i), ("bbx2", c_i), ("bby2", c_i),
+                ("one_minus_lam", c_f), ("lam", c_f), ("mouse", c_i), ("pad_", c_i)]
+
+
+VID_U8, VID_F32 = 0, 1
+
 _STRUCTS = {
     "dwn_load_desc": LoadDesc, "dwn_gemm_nn_args": GemmNNArgs, "dwn_gemm_tn_args": GemmTNArgs,
     "dwn_dw_spatial_fwd_args": DwSpatialFwdArgs, "dwn_dw_spatial_bwd_args": DwSpatialBwdArgs,
     "dwn_dw_temporal_fwd_args": DwTemporalFwdArgs, "dwn_dw_temporal_bwd_args": DwTemporalBwdArgs,
     "dwn_bn": BN, "dwn_stem_args": StemArgs, "dwn_block_args": BlockArgs, "dwn_pool_args": PoolArgs,
     "dwn_cortex_args": CortexArgs, "dwn_readout_args": ReadoutArgs, "dwn_tensor_entry": TensorEntry,
+    "dwn_clip_src": ClipSrc, "dwn_clip_desc": ClipDesc,
 }
 
 # every symbol include/dwn.h declares: (restype, argtypes)
@@ -177,6 +190,8 @@ SYMBOLS = {
     "dwn_f64_to_f32": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "dwn_adamw_ema_multi": (c_i, [c_p, c_i, c_i, c_d, c_d, c_d, c_d, c_d, c_ll, c_d, c_d, c_i, c_p]),
     "dwn_ema_lerp_multi": (c_i, [c_p, c_i, c_i, c_d, c_i, c_p]),
+    "dwn_assemble_inputs": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
+    "dwn_assemble_targets": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_p]),
 }
 
 

@@ -193,7 +193,7 @@ int dwn_sizeof(const char* name) {
     SZ(dwn_load_desc); SZ(dwn_gemm_nn_args); SZ(dwn_gemm_tn_args); SZ(dwn_dw_spatial_fwd_args);
     SZ(dwn_dw_spatial_bwd_args); SZ(dwn_dw_temporal_fwd_args); SZ(dwn_dw_temporal_bwd_args); SZ(dwn_bn);
     SZ(dwn_stem_args); SZ(dwn_block_args); SZ(dwn_pool_args); SZ(dwn_cortex_args); SZ(dwn_readout_args);
-    SZ(dwn_tensor_entry);
+    SZ(dwn_tensor_entry); SZ(dwn_clip_src); SZ(dwn_clip_desc);
 #undef SZ
     return -1;
 }
@@ -706,6 +706,25 @@ int dwn_ema_lerp_multi(const dwn_tensor_entry* list, int ntensors, int max_block
                        void* stream) {
     ENTER(device);
     return k_ema_lerp(list, ntensors, max_blocks, (float)decay, (float)(1.0 - decay), (hipStream_t)stream);
+}
+
+int dwn_assemble_inputs(const dwn_clip_desc* descs, int B, int T, int H0, int W0, int H, int W, float pad_fill,
+                        float* x, int device, void* stream) {
+    ENTER(device);
+    if (!descs || !x) return dwn_set_error(-1, "assemble_inputs: null pointer");
+    if (B <= 0 || T <= 0 || H0 <= 0 || W0 <= 0) return dwn_set_error(-2, "assemble_inputs: B, T, H0, W0 must be positive");
+    if (H < H0 || W < W0) return dwn_set_error(-2, "assemble_inputs: output frame smaller than the video");
+    return k_assemble_inputs(descs, B, T, H0, W0, H, W, pad_fill, x, (hipStream_t)stream);
+}
+
+int dwn_assemble_targets(const dwn_clip_desc* descs, int B, int T, float* const* targets, const int* n_neurons,
+                         int n_mice, int max_neurons, float* mice_weights, int device, void* stream) {
+    ENTER(device);
+    if (!descs || !targets || !n_neurons || !mice_weights) return dwn_set_error(-1, "assemble_targets: null pointer");
+    if (B <= 0 || T <= 0 || n_mice <= 0 || max_neurons <= 0)
+        return dwn_set_error(-2, "assemble_targets: B, T, n_mice, max_neurons must be positive");
+    if (B > 65535 || n_mice > 65535) return dwn_set_error(-2, "assemble_targets: B and n_mice are grid dimensions (<= 65535)");
+    return k_assemble_targets(descs, B, T, targets, n_neurons, n_mice, max_neurons, mice_weights, (hipStream_t)stream);
 }
 
 }  // extern "C"
