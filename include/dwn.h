@@ -66,6 +66,7 @@ typedef struct dwn_load_desc {
 #define DWN_EPI_READOUT 1
 #define DWN_EPI_DG 2
 #define DWN_EPI_STORE_CAT 3   /* DWN_EPI_STORE + K-concatenated second A operand (a2, K1) + fp32 bias[N] */
+#define DWN_EPI_DH3 4         /* see gate3 / dps3 / coef3 below */
 
 /* C[M][N] = load(A)[M][K] . B[N][K]^T  (+ BN statistics / readout / SE-grad epilogues).
  * Replaces nn.Conv3d 1x1x1 (dwiseneuro.py:91,118) and grouped nn.Conv1d k=1 (:207,276). */
@@ -89,6 +90,13 @@ typedef struct dwn_gemm_nn_args {
      * b + b*b_sample_stride elements (e.g. W . diag(gate_b): the SE gate folded into conv_pwl).  Needs
      * b_rows_per_sample % 128 == 0, groups == 1 and K > one k-tile; 0 = one weight matrix for every row. */
     long long b_sample_stride; int b_rows_per_sample;
+    /* DWN_EPI_DH3 (conv_pwl data gradient fused with the SE-gate / SiLU / BatchNorm-3 backward prologue,
+     * dwiseneuro.py:113-120 backward): with du = the GEMM result rounded to `dtype`, the kernel stores
+     *   dh3[m][n] = (du*gate3[b][n] + dps3[b][n]) * silu'(coef3[0][n]*y3[m][n] + coef3[1][n])
+     * into c (y3 = the raw temporal-conv output; b = m / rows_per_sample; gate3/dps3 rows are dg_ld apart) and, when
+     * `stats` is set, accumulates sum(dh3) and sum(dh3 * (y3 - coef3[2][n]) * coef3[3][n]) — the two BatchNorm-backward
+     * sums.  coef3 is the [4][coef3_ld] table scale, shift, mean, invstd. */
+    const float* gate3; const float* dps3; const float* coef3; int coef3_ld;
 } dwn_gemm_nn_args;
 
 /* dW[R][Cc] += sum_m load(P)[m][r] * load(Q)[m][c]   (fp32 atomics; dW must be zeroed by the caller) */
@@ -100,6 +108,10 @@ typedef struct dwn_gemm_tn_args {
     int groups;
     int rows_per_split; int nsplit;       /* nsplit <= 0: chosen by the library */
     int R_load;                           /* P columns per group incl. zero padding (>= R; 0 -> R) */
+    /* per-sample products: with rows_per_sample > 0 (M % rows_per_sample == 0, groups == 1) the rows of sample b
+     * accumulate into dw + b*dw_sample_stride — B separate [R][Cc] matrices P_b = load(P)_b^T load(Q)_b.
+     * splits_per_sample is chosen by the library. */
+    int rows_per_sample; int splits_per_sample; long long dw_sample_stride;
 } dwn_gemm_tn_args;
 
 /* depth-wise (1,k,k) conv, stride (1,s,s), pad k/2 — dwiseneuro.py:96-100 */

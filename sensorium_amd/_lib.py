@@ -28,7 +28,7 @@ c_sz = C.c_size_t
 DWN_F32, DWN_BF16 = 0, 1
 DWN_NREP = 32
 LD_PLAIN, LD_PE, LD_BNACT, LD_AFFINE2, LD_DY3, LD_GATE = 0, 1, 2, 3, 4, 5
-EPI_STORE, EPI_READOUT, EPI_DG, EPI_STORE_CAT = 0, 1, 2, 3
+EPI_STORE, EPI_READOUT, EPI_DG, EPI_STORE_CAT, EPI_DH3 = 0, 1, 2, 3, 4
 FAMILIES = ("pw_fwd", "dws_fwd", "dwt_fwd", "se_pool", "pwl_fwd", "resid_fwd", "resid_bwd", "pwl_dgrad", "pwl_wgrad",
             "bn3_reduce", "dwt_bwd", "dws_bwd", "pw_dgrad", "pw_wgrad")
 
@@ -46,13 +46,15 @@ class GemmNNArgs(C.Structure):
                 ("stat_rep_stride_unused", c_i), ("stat_nchan", c_i), ("epi", c_i), ("bias", c_p),
                 ("sp_beta", c_f), ("out_nct", c_p), ("Tn", c_i), ("n_valid", c_i), ("y3", c_p), ("ldy3", c_ll),
                 ("s3", c_p), ("t3", c_p), ("dg", c_p), ("dg_ld", c_i), ("rows_per_sample", c_i),
-                ("a2", c_p), ("a2_ld", c_ll), ("K1", c_i), ("b_sample_stride", c_ll), ("b_rows_per_sample", c_i)]
+                ("a2", c_p), ("a2_ld", c_ll), ("K1", c_i), ("b_sample_stride", c_ll), ("b_rows_per_sample", c_i),
+                ("gate3", c_p), ("dps3", c_p), ("coef3", c_p), ("coef3_ld", c_i)]
 
 
 class GemmTNArgs(C.Structure):
     _fields_ = [("p", LoadDesc), ("p_kind", c_i), ("q", LoadDesc), ("q_kind", c_i), ("M", c_i), ("R", c_i),
                 ("Cc", c_i), ("dw", c_p), ("lddw", c_ll), ("groups", c_i), ("rows_per_split", c_i),
-                ("nsplit", c_i), ("R_load", c_i)]
+                ("nsplit", c_i), ("R_load", c_i), ("rows_per_sample", c_i), ("splits_per_sample", c_i),
+                ("dw_sample_stride", c_ll)]
 
 
 class DwSpatialFwdArgs(C.Structure):

@@ -121,6 +121,7 @@ struct BlockWs {
     float *dgp, *dhp, *dps;
     void* bp; float* r3; float* gacc;                      // conv_pw data-gradient folding (see dwn_elementwise.hip)
     void* wgated;                                          // [B][Cout][Cmid] W2 . diag(gate_b) (forward only)
+    float* pb;                                             // [B][Cout][Cmid] per-sample dy4^T z3 (backward, see pwl_bwd_per_sample)
     char* zero_beg; char* zero_end;
     size_t bytes;
 };
@@ -129,6 +130,17 @@ struct BlockWs {
 static bool pwl_gated_weights(const dwn_block_args& a) {
     const int bk = a.dtype == DWN_BF16 ? 64 : 32;
     return ((a.T * a.Hout * a.Wout) % 128) == 0 && a.Cmid > bk;
+}
+// conv_pwl backward through per-sample products (k_pwl_bwd_reduce) + the recompute-du GEMM epilogue (EPI_DH3): saves
+// three passes over a [Mout][Cmid] tensor at the price of zeroing / accumulating / reading B [Cout][Cmid] fp32 matrices,
+// so it is used when those are small next to one such pass.  DWN_PWL_BWD=old|new forces a path (tests).
+static bool pwl_bwd_per_sample(const dwn_block_args& a) {
+    static const char* force = getenv("DWN_PWL_BWD");
+    if (force && force[0] == 'o') return false;
+    if (force && force[0] == 'n') return true;
+    const double pb = 4.0 * a.B * a.Cout * a.Cmid * sizeof(float);
+    const double pass = (double)a.B * a.T * a.Hout * a.Wout * a.Cmid * tsize(a.dtype);
+    return pb <= pass;
 }
 BlockWs carve_block(const dwn_block_args& a, int backward, void* base, size_t cap) {
     BlockWs w; memset(&w, 0, sizeof(w));
@@ -161,6 +173,7 @@ BlockWs carve_block(const dwn_block_args& a, int backward, void* base, size_t ca
         w.bp = c.take<char>((size_t)a.Cin * (a.Cmid + a.Cin) * ts);
         w.r3 = c.take<float>((size_t)a.Cin);
         w.gacc = c.take<float>((size_t)a.Cin * a.Cin);
+        if (pwl_bwd_per_sample(a)) w.pb = c.take<float>((size_t)a.B * a.Cout * a.Cmid);
     }
     w.bytes = c.off + 256;
     if (base) { w.zero_beg = (char*)base + z0; w.zero_end = (char*)base + z1; }
@@ -419,6 +432,7 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
         ok = ok && pa.zero(a.dw_dws, (size_t)a.Cmid * a.ks * a.ks * sizeof(float));
         ok = ok && pa.zero(a.dw_dwt, (size_t)a.Cmid * a.kt * sizeof(float));
         ok = ok && pa.zero(a.dw_pwl, (size_t)a.Cout * a.Cmid * sizeof(float));
+        if (w.pb) ok = ok && pa.zero(w.pb, (size_t)a.B * a.Cout * a.Cmid * sizeof(float));
         if (!ok) return dwn_set_error(-2, "block_backward: workspace arena and dw_* buffers must be 16-byte aligned");
         TRY(k_prep(pa, dt, s));
     }
@@ -432,6 +446,24 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     PROF(DWN_FAM_RESID_BWD, k_residual_bwd_dy4(a.y4, a.dout, w.abc4, a.drop_scale, gm, a.dy4, dt, s));
     // conv_pwl backward: du = dy4 @ W2 (+ SE gate gradient), dW2 = dy4^T @ u
     void* du = a.buf_a;
+    if (w.pb) {
+        // per-sample products P_b = dy4_b^T z3_b -> dW2 and the SE gate gradient without touching du
+        {
+            GemmTN g = tn_base(ld_plain(a.dy4, a.Cout), LD_PLAIN, ld_plain(a.z3, a.Cmid), LD_PLAIN, (int)Mout, a.Cout,
+                               a.Cmid, w.pb, a.Cmid, 1);
+            g.rows_per_sample = S_out; g.dw_sample_stride = (i64)a.Cout * a.Cmid;
+            PROF(DWN_FAM_PWL_WGRAD, launch_gemm_tn(g, dt, s));
+        }
+        PROF(DWN_FAM_PWL_WGRAD, k_pwl_bwd_reduce(w.pb, a.se_gate, a.w_pwl, a.B, a.Cout, a.Cmid, a.dw_pwl, dg, s));
+        TRY(k_se_mlp_bwd(dg, a.se_gate, a.se_hidpre, a.se_pmean, a.se_wr, a.se_we, a.B, a.Cmid, a.se_r,
+                         1.0f / (float)S_out, w.dgp, w.dhp, w.dps, a.dse_wr, a.dse_br, a.dse_we, a.dse_be, s));
+        // dh3 = (du*gate + dpS) * silu'(bn3(y3)) with du = dy4 . W2 recomputed in the GEMM, plus the bn3 backward sums
+        GemmNN g = nn_base(ld_plain(a.dy4, a.Cout), LD_PLAIN, w.wpwl, a.Cout, du, a.Cmid, (int)Mout, a.Cmid, a.Cout, 1);
+        g.epi = EPI_DH3; g.y3 = a.y3; g.ldy3 = a.Cmid; g.gate3 = a.se_gate; g.dps3 = w.dps; g.dg_ld = a.Cmid;
+        g.coef3 = a.bn3.coef; g.coef3_ld = a.Cmid; g.rows_per_sample = S_out;
+        g.stats = w.st3; g.stat_nchan = a.Cmid;
+        PROF(DWN_FAM_PWL_DGRAD, launch_gemm_nn(g, dt, s));
+    } else {
     {
         GemmNN g = nn_base(ld_plain(a.dy4, a.Cout), LD_PLAIN, w.wpwl, a.Cout, du, a.Cmid, (int)Mout, a.Cmid, a.Cout, 1);
         g.epi = EPI_DG; g.y3 = a.z3; g.ldy3 = a.Cmid; g.s3 = nullptr; g.t3 = nullptr; g.dg = dg;
@@ -454,6 +486,7 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     d3.rows_per_sample = S_out;
     // ... and dh3 replaces du in place, so the temporal kernel reads (dh3, y3) with the plain BN-backward affine
     PROF(DWN_FAM_BN3_REDUCE, k_bn3_bwd_reduce(d3, a.bn3.coef, Mout, a.Cmid, w.st3, du, dt, s));
+    }
     TRY(k_bn_bwd_finalize(w.st3, (double)Mout, a.bn3.coef, a.bn3.dgamma, a.bn3.dbeta, w.abc3, a.Cmid, s));
     // temporal dw backward
     {

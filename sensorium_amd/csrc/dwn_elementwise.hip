@@ -1137,6 +1137,50 @@ int k_bn3_bwd_reduce(const LoadDesc& d, const float* coef3, i64 rows, int C, dou
     return 0;
 }
 
+// conv_pwl backward from per-sample products P_b = dy4_b^T z3_b ([B][K = Cout][N = Cmid], gemm_tn per-sample mode):
+//   dW2[k][n] += sum_b gate[b][n] * P_b[k][n]        (the SE gate is constant over a sample, so it factors out)
+//   dg[b][n]   = sum_k W2[k][n] * P_b[k][n]          (= sum_m du[m][n] * z3[m][n] with du = dy4 . W2)
+// which replaces one full read of z3 and the write + read of du.  grid (N / 64, B / 4); thread = (column, k-lane).
+__global__ __launch_bounds__(256) void pwl_bwd_reduce_kernel(const float* __restrict__ P, const float* __restrict__ gate,
+                                                             const float* __restrict__ W, int B, int K, int N,
+                                                             float* __restrict__ dW, float* __restrict__ dg) {
+    __shared__ float red[4][4][64];
+    const int nl = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + nl, b0 = blockIdx.y * 4;
+    float dgp[4] = {0.f, 0.f, 0.f, 0.f}, gt[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool nok = n < N;
+    if (nok) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+            if (b0 + bb < B) gt[bb] = gate[(i64)(b0 + bb) * N + n];
+#pragma unroll 4
+        for (int k = kl; k < K; k += 4) {
+            const float w = W[(i64)k * N + n];
+            float dwa = 0.f;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const int b = b0 + bb < B ? b0 + bb : B - 1;
+                const float p = P[((i64)b * K + k) * N + n];
+                dgp[bb] = fmaf(w, p, dgp[bb]);
+                dwa = fmaf(gt[bb], p, dwa);          // gt = 0 for the clamped duplicates
+            }
+            atomicAdd(dW + (i64)k * N + n, dwa);
+        }
+    }
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) red[bb][kl][nl] = dgp[bb];
+    __syncthreads();
+    const int bb = kl;                                // wave kl finishes sample b0 + kl
+    if (nok && b0 + bb < B)
+        dg[(i64)(b0 + bb) * N + n] = (red[bb][0][nl] + red[bb][1][nl]) + (red[bb][2][nl] + red[bb][3][nl]);
+}
+int k_pwl_bwd_reduce(const float* P, const float* gate, const float* W, int B, int K, int N, float* dW, float* dg,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(pwl_bwd_reduce_kernel, dim3((N + 63) / 64, (B + 3) / 4), dim3(256), 0, s, P, gate, W, B, K, N, dW, dg);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // H×W average pool (AdaptiveAvgPool3d((None,1,1)), dwiseneuro.py:374,400) and its backward
 // ------------------------------------------------------------------------------------------------

@@ -238,6 +238,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     for (int i = 0; i < KC; ++i) { st0[i] = 0.f; st1[i] = 0.f; dgp[i] = 0.f; }
     [[maybe_unused]] int dg_b = -1;                    // sample whose partial sums dgp currently holds
     T* Cp = reinterpret_cast<T*>(g.c);
+    // EPI_DH3: this thread's column chunk never changes — BatchNorm-3 scale / shift / mean / invstd stay in registers
+    // (scale / shift only; the second BatchNorm-backward sum is accumulated as sum(dh3 * y3) and centred once, when
+    // the workgroup flushes — keeping mean / invstd live through the tile loop spills)
+    [[maybe_unused]] float sc3[KC], sh3[KC];
+    if constexpr (EPI == EPI_DH3) {
+        ld_coef<KC>(g.coef3 + ncol_e, sc3);
+        ld_coef<KC>(g.coef3 + (i64)g.coef3_ld + ncol_e, sh3);
+    }
+    [[maybe_unused]] float gt3[KC], gp3[KC];           // SE gate / pooled-gradient rows of sample gb3
+    [[maybe_unused]] int gb3 = -1;
+    constexpr bool NEEDY = (EPI == EPI_DG || EPI == EPI_DH3);     // the epilogue reads a second [M][N] tensor (g.y3)
 
     // flush dgp (sample dg_b) through LDS: one global atomic per column per workgroup
     auto flush_dg = [&]() {
@@ -271,6 +282,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // EPI_DH3 fast path: the whole tile lies in one sample — its SE gate and pooled-gradient rows are fetched here,
+        // under the MFMAs, not at the head of the epilogue
+        if constexpr (EPI == EPI_DH3 && decltype(fast_c)::value) {
+            const int b = m0 / g.rows_per_sample;
+            if (b != gb3) {
+                ld_coef<KC>(g.gate3 + (i64)b * g.dg_ld + ncol_e, gt3);
+                ld_coef<KC>(g.dps3 + (i64)b * g.dg_ld + ncol_e, gp3);
+                gb3 = b;
+            }
+        }
         if constexpr (single) {
             if constexpr (HN) load_a((mt + 1) * BM, 0);         // in flight under the MFMAs and the epilogue
             mma_tile();
@@ -325,9 +346,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                 // their sums are never flushed) — so the compiler counts the stores exactly and the s_waitcnt of the
                 // next tile's prefetched A rows (issued before these stores) does not drain them.
                 constexpr bool fast = decltype(fast_c)::value;
+                [[maybe_unused]] int pb3 = 0, pbound3 = 0;
+                if constexpr (EPI == EPI_DH3 && !fast) {
+                    pb3 = mp / g.rows_per_sample;
+                    pbound3 = (pb3 + 1) * g.rows_per_sample;
+                }
                 // EPI_DG: fetch this pass's z3 chunks now so they are in flight across the LDS round trip
                 [[maybe_unused]] uint4 zraw[CROWS * CPR / 256];
-                if constexpr (EPI == EPI_DG) {
+                if constexpr (NEEDY) {
                     if constexpr (fast) {
 #pragma unroll
                         for (int it = 0; it < CROWS * CPR / 256; ++it) {
@@ -376,9 +402,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                         const int row = tid / CPR + it * (256 / CPR);
                         const int m = mp + row;
                         const uint4 raw = *reinterpret_cast<const uint4*>(sC + row * CROW + ch_e * 16);
-                        *reinterpret_cast<uint4*>(Cp + (i64)m * g.ldc + ccol0 + ncol_e) = raw;
                         float v[KC];
                         unpack16<T>(raw, v);
+                        if constexpr (EPI == EPI_DH3) {
+                            float y[KC], dh[KC];
+                            unpack16<T>(zraw[it], y);
+#pragma unroll
+                            for (int i = 0; i < KC; ++i) dh[i] = fmaf(v[i], gt3[i], gp3[i]) * silu_gradf_(fmaf(y[i], sc3[i], sh3[i]));
+                            const uint4 packed = pack16<T>(dh);
+                            *reinterpret_cast<uint4*>(Cp + (i64)m * g.ldc + ccol0 + ncol_e) = packed;
+                            if (g.stats) {
+                                float r[KC];
+                                unpack16<T>(packed, r);            // the sums use the stored (rounded) values
+#pragma unroll
+                                for (int i = 0; i < KC; ++i) { st0[i] += r[i]; st1[i] = fmaf(r[i], y[i], st1[i]); }
+                            }
+                            continue;
+                        }
+                        *reinterpret_cast<uint4*>(Cp + (i64)m * g.ldc + ccol0 + ncol_e) = raw;
                         if (g.stats) {
 #pragma unroll
                             for (int i = 0; i < KC; ++i) { st0[i] += v[i]; st1[i] += v[i] * v[i]; }
@@ -397,9 +438,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                     const int m = mp + row;
                     if (m >= g.M || ncol >= g.N) continue;
                     const uint4 raw = *reinterpret_cast<const uint4*>(sC + row * CROW + ch * 16);
-                    *reinterpret_cast<uint4*>(Cp + (i64)m * g.ldc + ccol0 + ncol) = raw;
                     float v[KC];
                     unpack16<T>(raw, v);
+                    if constexpr (EPI == EPI_DH3) {
+                        // sample of this row without a division per row: a pass crosses at most one boundary
+                        // when rows_per_sample >= CROWS (pb3 / pbound3 are per-pass scalars)
+                        const int b = g.rows_per_sample >= CROWS ? pb3 + (m >= pbound3 ? 1 : 0) : m / g.rows_per_sample;
+                        float y[KC], dh[KC];
+                        unpack16<T>(zraw[it], y);
+                        if (b != gb3) {                      // rows of one tile almost always share the sample
+                            gb3 = b;
+                            ld_coef<KC>(g.gate3 + (i64)b * g.dg_ld + ncol, gt3);
+                            ld_coef<KC>(g.dps3 + (i64)b * g.dg_ld + ncol, gp3);
+                        }
+#pragma unroll
+                        for (int i = 0; i < KC; ++i) dh[i] = fmaf(v[i], gt3[i], gp3[i]) * silu_gradf_(fmaf(y[i], sc3[i], sh3[i]));
+                        const uint4 packed = pack16<T>(dh);
+                        *reinterpret_cast<uint4*>(Cp + (i64)m * g.ldc + ccol0 + ncol) = packed;
+                        if (g.stats) {
+                            float r[KC];
+                            unpack16<T>(packed, r);
+#pragma unroll
+                            for (int i = 0; i < KC; ++i) { st0[i] += r[i]; st1[i] = fmaf(r[i], y[i], st1[i]); }
+                        }
+                        continue;
+                    }
+                    *reinterpret_cast<uint4*>(Cp + (i64)m * g.ldc + ccol0 + ncol) = raw;
                     if (g.stats) {
 #pragma unroll
                         for (int i = 0; i < KC; ++i) { st0[i] += v[i]; st1[i] += v[i] * v[i]; }
@@ -445,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     for (int mt = mt_beg; mt < mt_end; ++mt) {
         const int m0_ = mt * BM;
         bool fast = m0_ + BM <= g.M;
-        if constexpr (EPI == EPI_DG) fast = fast && (m0_ / g.rows_per_sample == (m0_ + BM - 1) / g.rows_per_sample);
+        if constexpr (EPI == EPI_DG || EPI == EPI_DH3) fast = fast && (m0_ / g.rows_per_sample == (m0_ + BM - 1) / g.rows_per_sample);
         if constexpr (EPI == EPI_READOUT) fast = false;
         using T_ = std::true_type;
         using F_ = std::false_type;
@@ -458,6 +522,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     }
     if constexpr (EPI != EPI_READOUT) {
         if (g.stats) {
+            if constexpr (EPI == EPI_DH3) {            // sum(dh*(y - mean)*invstd) = invstd * (sum(dh*y) - mean*sum(dh))
+                float mu3[KC], is3[KC];
+                ld_coef<KC>(g.coef3 + 2 * (i64)g.coef3_ld + ncol_e, mu3);
+                ld_coef<KC>(g.coef3 + 3 * (i64)g.coef3_ld + ncol_e, is3);
+#pragma unroll
+                for (int i = 0; i < KC; ++i) st1[i] = is3[i] * fmaf(-mu3[i], st0[i], st1[i]);
+            }
             if (tid < 2 * BN) lred[tid] = 0.f;
             __syncthreads();
             if (ncol < g.N) {
@@ -504,13 +575,16 @@ static int launch_nn_k(const GemmNN& g, hipStream_t s) {
 // point-wise expand conv and the project conv's data gradient); every other combination runs K <= BK through the
 // k-loop variant (one step, no prefetch)
 template <int ALD, int EPI> struct HasSingle {
-    static constexpr bool value = (ALD == LD_PLAIN && (EPI == EPI_STORE || EPI == EPI_DG)) || (ALD == LD_PE && EPI == EPI_STORE);
+    static constexpr bool value = (ALD == LD_PLAIN && (EPI == EPI_STORE || EPI == EPI_DG || EPI == EPI_DH3)) || (ALD == LD_PE && EPI == EPI_STORE);
 };
 
 template <typename T, int ALD, int EPI>
 static int launch_nn_t(const GemmNN& g, hipStream_t s) {
     constexpr int BK = 128 / (int)sizeof(T);
-    const bool n64 = g.N <= 64;
+    // the dh3 epilogue keeps four per-column coefficient vectors live: at 128 columns it spills (88-140 B/lane of
+    // scratch, measured 2.7 TB/s); the 64-column tile fits (224 VGPRs) and the extra A re-reads stay in the XCD's L2
+    static const bool dh3_wide = getenv("DWN_DH3_WIDE") != nullptr;
+    const bool n64 = g.N <= 64 || (EPI == EPI_DH3 && !dh3_wide);
     if constexpr (HasSingle<ALD, EPI>::value) {
         if (g.K <= BK) return n64 ? launch_nn_k<T, ALD, EPI, 64, true>(g, s) : launch_nn_k<T, ALD, EPI, 128, true>(g, s);
     }
@@ -530,6 +604,11 @@ static int launch_nn_d(const GemmNN& g, hipStream_t s) {
         if (g.s3 || g.t3) return dwn_set_error(-3, "gemm_nn: the dg epilogue reads the activated z3; s3/t3 must be NULL");
         if (g.a_kind == LD_PLAIN && g.groups == 1) return launch_nn_t<T, LD_PLAIN, EPI_DG>(g, s);
         return dwn_set_error(-3, "gemm_nn: unsupported loader for dg epilogue");
+    }
+    if (g.epi == EPI_DH3) {
+        if (g.a_kind != LD_PLAIN || g.groups != 1 || !g.y3 || !g.gate3 || !g.dps3 || !g.coef3 || g.rows_per_sample <= 0)
+            return dwn_set_error(-3, "gemm_nn: the dh3 epilogue needs a plain loader, groups == 1, y3, gate3, dps3, coef3, rows_per_sample");
+        return launch_nn_t<T, LD_PLAIN, EPI_DH3>(g, s);
     }
     if (g.epi == EPI_STORE_CAT) {
         if (g.a_kind != LD_PLAIN || g.groups != 1 || g.K1 <= 0 || g.K1 % TT<T>::KC || !g.a2 || !g.bias)
@@ -600,9 +679,18 @@ __global__ __launch_bounds__(256, (TnOcc<PLD, QLD>::value)) void gemm_tn_kernel(
     const int grp = blockIdx.z;
     const int Rl = g.R_load > 0 ? g.R_load : g.R;
     const int pcol0 = grp * Rl, qcol0 = grp * g.Cc;
-    const i64 mbeg = (i64)split_id * g.rows_per_split;
+    i64 mbeg = (i64)split_id * g.rows_per_split;
     i64 mend = mbeg + g.rows_per_split;
     if (mend > g.M) mend = g.M;
+    i64 dw_off = 0;
+    if (g.rows_per_sample > 0) {           // per-sample products: split = (sample, part of the sample)
+        const int b = split_id / g.splits_per_sample, j = split_id % g.splits_per_sample;
+        mbeg = (i64)b * g.rows_per_sample + (i64)j * g.rows_per_split;
+        mend = mbeg + g.rows_per_split;
+        const i64 send = (i64)(b + 1) * g.rows_per_sample;
+        if (mend > send) mend = send;
+        dw_off = (i64)b * g.dw_sample_stride;
+    }
 
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
@@ -734,7 +822,7 @@ __global__ __launch_bounds__(256, (TnOcc<PLD, QLD>::value)) void gemm_tn_kernel(
         }
     }
     if (mbeg >= mend) return;
-    float* dw = g.dw + (i64)grp * g.R * g.lddw;
+    float* dw = g.dw + (i64)grp * g.R * g.lddw + dw_off;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -750,7 +838,25 @@ __global__ __launch_bounds__(256, (TnOcc<PLD, QLD>::value)) void gemm_tn_kernel(
 template <typename T, int PLD, int QLD>
 static int launch_tn_t(const GemmTN& g_in, hipStream_t s) {
     GemmTN g = g_in;
-    if (g.nsplit <= 0) {
+    if (g.rows_per_sample > 0) {
+        if (g.groups != 1 || g.M % g.rows_per_sample) return dwn_set_error(-2, "gemm_tn: per-sample mode needs groups == 1 and M % rows_per_sample == 0");
+        int bpc = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, gemm_tn_kernel<T, PLD, QLD>, 256, 0) != hipSuccess || bpc < 1) {
+            (void)hipGetLastError();
+            bpc = 1;
+        }
+        const int nb = g.M / g.rows_per_sample;
+        const int tiles = ((g.R + 127) / 128) * ((g.Cc + 127) / 128);
+        int J = (256 * bpc) / (tiles * nb);
+        const int maxj = (g.rows_per_sample + 511) / 512;
+        if (J > maxj) J = maxj;
+        if (J < 1) J = 1;
+        int rows = (g.rows_per_sample + J - 1) / J;
+        rows = (rows + 63) / 64 * 64;
+        g.rows_per_split = rows;
+        g.splits_per_sample = (g.rows_per_sample + rows - 1) / rows;
+        g.nsplit = nb * g.splits_per_sample;
+    } else if (g.nsplit <= 0) {
         // one resident round: tiles x splits = the workgroups the chip holds at once (a partial second round costs a
         // whole workgroup duration, and every split adds 64 KB of fp32 atomics per tile)
         int bpc = 0;

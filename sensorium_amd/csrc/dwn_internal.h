@@ -2,7 +2,7 @@
 #pragma once
 #include "dwn_common.h"
 
-enum { EPI_STORE = DWN_EPI_STORE, EPI_READOUT = DWN_EPI_READOUT, EPI_DG = DWN_EPI_DG, EPI_STORE_CAT = DWN_EPI_STORE_CAT };
+enum { EPI_STORE = DWN_EPI_STORE, EPI_READOUT = DWN_EPI_READOUT, EPI_DG = DWN_EPI_DG, EPI_STORE_CAT = DWN_EPI_STORE_CAT, EPI_DH3 = DWN_EPI_DH3 };
 typedef dwn_gemm_nn_args GemmNN;
 typedef dwn_gemm_tn_args GemmTN;
 typedef dwn_dw_spatial_fwd_args DwSpatialFwd;

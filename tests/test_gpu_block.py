@@ -136,3 +136,19 @@ def test_block_eval_forward(dtype):
     assert rel(out.float(), ref) < (1e-3 if dtype == torch.float32 else 4e-2)
     for k, v in blk.state_dict().items():      # eval must not touch the BN buffers
         assert torch.equal(v, before[k]), k
+
+
+@pytest.mark.parametrize("path", ["old", "new"])
+def test_block_backward_both_project_conv_paths(path):
+    """The conv_pwl backward has two implementations (per-sample products + recompute epilogue, or the materialised du),
+    chosen per shape; DWN_PWL_BWD forces one (read once per process), so the block and model parity tests are re-run in a
+    child process under each."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DWN_PWL_BWD=path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_block.py",
+                          "tests/test_gpu_model.py", "-k", "not both_project_conv_paths"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]

@@ -212,3 +212,77 @@ def test_gemm_nn_per_sample_weights(L, dtype):
     torch.cuda.synchronize()
     ref = torch.cat([a[i * rps:(i + 1) * rps].double() @ w[i].double().t() for i in range(nb)])
     assert rel(c, ref) < tol(dtype, 1e-5, 6e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,S,R,Cc", [(4, 256, 64, 448), (3, 200, 24, 40), (32, 1280, 128, 136), (2, 64, 8, 8)])
+def test_gemm_tn_per_sample_products(L, dtype, B, S, R, Cc):
+    """rows_per_sample > 0: B separate [R][Cc] products P_b = P_b^T Q_b (conv_pwl backward, dwn_api.hip)."""
+    torch.manual_seed(S)
+    M = B * S
+    p = torch.randint(-2, 3, (M, R), device=dev()).float().to(dtype)
+    q = torch.randint(-2, 3, (M, Cc), device=dev()).float().to(dtype)
+    stride = R * Cc + 16                                   # padded sample stride
+    dw = torch.zeros(B * stride, device=dev())
+    g = L.GemmTNArgs()
+    g.p = load_desc(L, p, R); g.p_kind = L.LD_PLAIN
+    g.q = load_desc(L, q, Cc); g.q_kind = L.LD_PLAIN
+    g.M, g.R, g.Cc = M, R, Cc
+    g.dw = dw.data_ptr(); g.lddw = Cc; g.groups = 1; g.nsplit = 0
+    g.rows_per_sample = S; g.dw_sample_stride = stride
+    L.check(L.lib.dwn_gemm_tn(C.byref(g), _dt(L, dtype), 0, stream()), "gemm_tn")
+    torch.cuda.synchronize()
+    got = dw.view(B, stride)
+    ref = torch.einsum("bsr,bsc->brc", p.float().view(B, S, R), q.float().view(B, S, Cc))      # small integers: exact
+    assert torch.equal(got[:, :R * Cc].reshape(B, R, Cc), ref)
+    assert not got[:, R * Cc:].any()
+    g.M = M - 1
+    assert L.lib.dwn_gemm_tn(C.byref(g), _dt(L, dtype), 0, stream()) < 0       # M must be whole samples
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,S,N,K", [(4, 256, 448, 64), (3, 200, 40, 24), (2, 640, 896, 128), (2, 128, 136, 256),
+                                     (5, 100, 64, 16)])
+def test_gemm_nn_dh3_epilogue(L, dtype, B, S, N, K):
+    """DWN_EPI_DH3: dh3 = (round(A.B^T)*gate + dps) * silu'(scale*y3 + shift) stored, plus the two BatchNorm-backward
+    sums — against the same formula in fp64 on the rounded product (whole-tile and ragged shapes, resident and k-loop)."""
+    torch.manual_seed(N + K)
+    M = B * S
+    a = (torch.randn(M, K, device=dev()) * 0.5).to(dtype)
+    b = (torch.randn(N, K, device=dev()) * 0.2).to(dtype)
+    y3 = torch.randn(M, N, device=dev()).to(dtype)
+    gate = torch.rand(B, N, device=dev())
+    dps = torch.randn(B, N, device=dev()) * 0.1
+    coef = torch.stack([torch.rand(N, device=dev()) + 0.5, torch.randn(N, device=dev()) * 0.3,
+                        torch.randn(N, device=dev()) * 0.2, torch.rand(N, device=dev()) + 0.5]).contiguous()
+    out = torch.full((M, N), float("nan"), device=dev()).to(dtype)
+    st = stats_buffer(N)
+    g = L.GemmNNArgs()
+    g.a = load_desc(L, a, K); g.a_kind = L.LD_PLAIN
+    g.b = b.data_ptr(); g.ldb = K; g.c = out.data_ptr(); g.ldc = N
+    g.M, g.N, g.K, g.groups = M, N, K, 1
+    g.epi = L.EPI_DH3
+    g.y3 = y3.data_ptr(); g.ldy3 = N; g.gate3 = gate.data_ptr(); g.dps3 = dps.data_ptr(); g.dg_ld = N
+    g.coef3 = coef.data_ptr(); g.coef3_ld = N; g.rows_per_sample = S
+    g.stats = st.data_ptr(); g.stat_nchan = N
+    L.check(L.lib.dwn_gemm_nn(C.byref(g), _dt(L, dtype), 0, stream()), "gemm_nn dh3")
+    torch.cuda.synchronize()
+    du = (a.double() @ b.double().t()).to(dtype).double()                      # the product is rounded to the storage type
+    yd = y3.double()
+    h = yd * coef[0].double() + coef[1].double()
+    sg = torch.sigmoid(h)
+    gb = gate.double().repeat_interleave(S, 0)
+    pb = dps.double().repeat_interleave(S, 0)
+    dh = (du * gb + pb) * (sg * (1 + h * (1 - sg)))
+    t = 1e-5 if dtype == torch.float32 else 1e-2
+    assert torch.isfinite(out.float()).all()
+    assert rel(out, dh) < t
+    r = out.double()                                                             # the sums use the stored (rounded) values
+    s0, s1 = read_stats(st, N)
+    want0 = r.sum(0)
+    want1 = (r * (yd - coef[2].double()) * coef[3].double()).sum(0)
+    scale = r.abs().sum(0).max()
+    assert float((s0 - want0).abs().max() / scale) < 1e-5
+    assert float((s1 - want1).abs().max() / scale) < 1e-5
+    g.gate3 = None
+    assert L.lib.dwn_gemm_nn(C.byref(g), _dt(L, dtype), 0, stream()) < 0
