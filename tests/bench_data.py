@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Batch assembly at the metric shape (B=32 clips of T=32 frames, 36x64, ten mice): device kernels vs the numpy oracle
+"""Measurement tool, not a test (kept under tests/ because its CPU leg times the oracle, which only tests/, smoke() and
+bench.py may import).  Batch assembly at the metric shape (B=32 clips of T=32 frames, 36x64, ten mice): device kernels vs the numpy oracle
 (the reference's per-sample CPU work, restated) on this host.  Prints one JSON line.
 
-    python tools/bench_data.py [--iters 50] [--mice 10]
+    python tests/bench_data.py [--iters 50] [--mice 10]
 """
 import argparse
 import json
@@ -13,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 
 NUM_NEURONS = [7863, 7908, 8202, 7939, 8122, 7440, 7928, 8285, 7671, 7495]        # src/constants.py:24,31
 
