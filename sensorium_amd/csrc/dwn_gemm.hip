@@ -64,7 +64,7 @@ __device__ __forceinline__ uint4 load_op_packed(const LoadDesc& d, i64 row, int 
 //     flushed once per workgroup — per-tile global atomics on the same few hundred addresses serialise at
 //     the memory side (MI355X_MICROARCH.md § Global float atomics, "contention").
 // ------------------------------------------------------------------------------------------------
-template <typename T, int ALD, int EPI, int BN, bool SINGLE>
+template <typename T, int ALD, int EPI, int BN, int SINGLE>
 __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     constexpr int KC = TT<T>::KC;
     constexpr int BM = 128;
@@ -77,9 +77,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     constexpr int CROWS = TT<T>::IS_BF16 ? 128 : 32;   // rows staged per epilogue pass (bf16: whole tile, one pass)
     constexpr int NPASS = BM / CROWS;
     constexpr int CPR = BN / KC;                       // 16-byte chunks per output row
-    __shared__ __attribute__((aligned(16))) unsigned char sA[BM * ROWB];
-    __shared__ __attribute__((aligned(16))) unsigned char sB[BN * ROWB];
-    __shared__ __attribute__((aligned(16))) unsigned char sC[CROWS * CROW];
+    // resident variants hold NKT k-tiles of both operands (SINGLE == 2: K <= two k-tiles); with 128 columns the
+    // epilogue staging then aliases the A tiles (two workgroups per CU need <= 80 KB each) — the next tile's A rows
+    // wait in registers until the epilogue is over, so nothing else touches that memory meanwhile
+    constexpr int NKT = SINGLE == 2 ? 2 : 1;
+    constexpr int SA_BYTES = NKT * BM * ROWB, SB_BYTES = NKT * BN * ROWB, SC_BYTES = CROWS * CROW;
+    constexpr bool ALIAS_C = (NKT == 2 && BN == 128);
+    constexpr int R0_BYTES = ALIAS_C ? (SA_BYTES > SC_BYTES ? SA_BYTES : SC_BYTES) : SA_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_nn[R0_BYTES + SB_BYTES + (ALIAS_C ? 0 : SC_BYTES)];
+    unsigned char* const sA = smem_nn;
+    unsigned char* const sB = smem_nn + R0_BYTES;
+    unsigned char* const sC = ALIAS_C ? smem_nn : smem_nn + R0_BYTES + SB_BYTES;
     __shared__ float lred[2 * BN];
 
     const int tid = threadIdx.x;
@@ -110,12 +118,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     const int ccol0 = grp * g.N;
     // SINGLE (K <= one k-tile) is a separate instantiation: sharing one loop nest between the resident-B and the
     // k-loop variants made the compiler merge their s_waitcnt scoreboards and drain every prefetch early
-    constexpr bool single = SINGLE;
+    constexpr bool single = SINGLE != 0;
 
     // Staging is split in two (cdna_hip_programming.md "Async-STAGE split"): load_* only ISSUES the global loads into
     // raw registers; the prologue math, the bounds select and the ds_write happen in store_*, after the MFMAs of the
     // current tile.  (Selecting / converting inside load_* makes the compiler wait for the data before the MFMAs.)
-    uint4 rp[A_CH], rq[A_CH], rb[B_CH];
+    uint4 rp[NKT * A_CH], rq[NKT * A_CH], rb[NKT * B_CH];
     int ld_m0 = 0, ld_k0 = 0, ldb_k0 = 0;
     // A staging: this thread's 16-byte column chunk (kc = tid & 7) is the same for its A_CH rows, so the
     // per-channel prologue coefficients are loaded once per k-tile, not once per chunk
@@ -146,12 +154,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
         } else {
             if (kok && k != cf_k) { cf.load(g.a, acol0 + k); cf_k = k; }
 #pragma unroll
-            for (int i = 0; i < A_CH; ++i) {
-                int m = m0 + (tid >> 3) + 32 * i;
-                const bool ok = m < g.M && kok;
-                const i64 off = ok ? (i64)m * g.a.ld + acol0 + k : 0;
-                rp[i] = *reinterpret_cast<const uint4*>(Ap + off);
-                if constexpr (decltype(cf)::two_tensors) rq[i] = *reinterpret_cast<const uint4*>(Aq + off);
+            for (int kt = 0; kt < NKT; ++kt) {
+                const int kq = k + kt * BK;                  // NKT == 2: plain loaders only (no per-k coefficients)
+                const bool kqok = kq < g.K;
+#pragma unroll
+                for (int i = 0; i < A_CH; ++i) {
+                    int m = m0 + (tid >> 3) + 32 * i;
+                    const bool ok = m < g.M && kqok;
+                    const i64 off = ok ? (i64)m * g.a.ld + acol0 + kq : 0;
+                    rp[kt * A_CH + i] = *reinterpret_cast<const uint4*>(Ap + off);
+                    if constexpr (decltype(cf)::two_tensors) rq[kt * A_CH + i] = *reinterpret_cast<const uint4*>(Aq + off);
+                }
             }
         }
     };
@@ -161,16 +174,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
         const T* Bt = Bp;
         if (g.b_sample_stride) Bt += (i64)(m0b / g.b_rows_per_sample) * g.b_sample_stride;
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) {
-            int c = tid + 256 * i;
-            int row = c >> 3, kc = c & 7;
-            int n = n0 + row, k = k0 + kc * KC;
-            const bool ok = n < g.N && k < g.K;
-            rb[i] = *reinterpret_cast<const uint4*>(Bt + (ok ? (i64)n * g.ldb + k : 0));
-        }
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i) {
+                int c = tid + 256 * i;
+                int row = c >> 3, kc = c & 7;
+                int n = n0 + row, k = k0 + kt * BK + kc * KC;
+                const bool ok = n < g.N && k < g.K;
+                rb[kt * B_CH + i] = *reinterpret_cast<const uint4*>(Bt + (ok ? (i64)n * g.ldb + k : 0));
+            }
     };
     auto store_a = [&]() {
-        const int kk = ld_k0 + (tid & 7) * KC;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+        const int kk = ld_k0 + kt * BK + (tid & 7) * KC;
         const bool kok = kk < g.K;
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
@@ -179,23 +196,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
             const int m = ld_m0 + row;
             const bool ok = m < g.M && kok;
             uint4 v;
-            if constexpr (ALD == LD_PE) v = rp[i];
-            else if (EPI == EPI_STORE_CAT && kk >= g.K1) v = ok ? rp[i] : make_uint4(0, 0, 0, 0);
+            if constexpr (ALD == LD_PE) v = rp[kt * A_CH + i];
+            else if (EPI == EPI_STORE_CAT && kk >= g.K1) v = ok ? rp[kt * A_CH + i] : make_uint4(0, 0, 0, 0);
             else {
-                if constexpr (decltype(cf)::two_tensors) v = ok ? cf.apply(g.a, (unsigned)m, rp[i], rq[i]) : make_uint4(0, 0, 0, 0);
-                else v = ok ? cf.apply(g.a, (unsigned)m, rp[i], make_uint4(0, 0, 0, 0)) : make_uint4(0, 0, 0, 0);
+                if constexpr (decltype(cf)::two_tensors) v = ok ? cf.apply(g.a, (unsigned)m, rp[kt * A_CH + i], rq[kt * A_CH + i]) : make_uint4(0, 0, 0, 0);
+                else v = ok ? cf.apply(g.a, (unsigned)m, rp[kt * A_CH + i], make_uint4(0, 0, 0, 0)) : make_uint4(0, 0, 0, 0);
             }
-            *reinterpret_cast<uint4*>(sA + row * ROWB + ((kc ^ (row & 7)) << 4)) = v;
+            *reinterpret_cast<uint4*>(sA + kt * (BM * ROWB) + row * ROWB + ((kc ^ (row & 7)) << 4)) = v;
+        }
         }
     };
     auto store_b = [&]() {
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) {
-            int c = tid + 256 * i;
-            int row = c >> 3, kc = c & 7;
-            const bool ok = (n0 + row) < g.N && (ldb_k0 + kc * KC) < g.K;
-            *reinterpret_cast<uint4*>(sB + row * ROWB + ((kc ^ (row & 7)) << 4)) = ok ? rb[i] : make_uint4(0, 0, 0, 0);
-        }
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i) {
+                int c = tid + 256 * i;
+                int row = c >> 3, kc = c & 7;
+                const bool ok = (n0 + row) < g.N && (ldb_k0 + kt * BK + kc * KC) < g.K;
+                *reinterpret_cast<uint4*>(sB + kt * (BN * ROWB) + row * ROWB + ((kc ^ (row & 7)) << 4)) =
+                    ok ? rb[kt * B_CH + i] : make_uint4(0, 0, 0, 0);
+            }
     };
 
     const int wave = tid >> 6, lane = tid & 63;
@@ -205,18 +226,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
 
     auto mma_tile = [&]() {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2 * NKT; ++kb) {
             uint4 af[4], bfr[NJ];
-            const int chunk = kb * 4 + lg;
+            const int chunk = (kb & 1) * 4 + lg;
+            const unsigned char* tA = sA + (kb >> 1) * (BM * ROWB);
+            const unsigned char* tB = sB + (kb >> 1) * (BN * ROWB);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int row = wm * 64 + i * 16 + lr;
-                af[i] = *reinterpret_cast<const uint4*>(sA + row * ROWB + ((chunk ^ (row & 7)) << 4));
+                af[i] = *reinterpret_cast<const uint4*>(tA + row * ROWB + ((chunk ^ (row & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 int row = wn * (BN / 2) + j * 16 + lr;
-                bfr[j] = *reinterpret_cast<const uint4*>(sB + row * ROWB + ((chunk ^ (row & 7)) << 4));
+                bfr[j] = *reinterpret_cast<const uint4*>(tB + row * ROWB + ((chunk ^ (row & 7)) << 4));
             }
             // swapped roles: D[n = 4*lg + r][m = lr] — acc[i][j][r] = C[m = i*16 + lr][n = j*16 + 4*lg + r]
 #pragma unroll
@@ -369,6 +392,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                         }
                     }
                 }
+                if constexpr (ALIAS_C) { if (pass == 0) __syncthreads(); }    // every wave is done reading the A tiles
                 if (CROWS >= 64 ? (wm == prow0 / 64 || CROWS == 128) : (wm == prow0 / 64)) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -548,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     }
 }
 
-template <typename T, int ALD, int EPI, int BNv, bool SINGLE>
+template <typename T, int ALD, int EPI, int BNv, int SINGLE>
 static int launch_nn_k(const GemmNN& g, hipStream_t s) {
     const int BM = 128;
     const int ntm = (g.M + BM - 1) / BM;
@@ -577,6 +601,10 @@ static int launch_nn_k(const GemmNN& g, hipStream_t s) {
 template <int ALD, int EPI> struct HasSingle {
     static constexpr bool value = (ALD == LD_PLAIN && (EPI == EPI_STORE || EPI == EPI_DG || EPI == EPI_DH3)) || (ALD == LD_PE && EPI == EPI_STORE);
 };
+// ... and resident two-k-tile instantiations (K <= 2 k-tiles: the 128-channel blocks) for the plain-loader hot shapes
+template <int ALD, int EPI> struct HasSingle2 {
+    static constexpr bool value = ALD == LD_PLAIN && (EPI == EPI_STORE || EPI == EPI_DG || EPI == EPI_DH3);
+};
 
 template <typename T, int ALD, int EPI>
 static int launch_nn_t(const GemmNN& g, hipStream_t s) {
@@ -586,9 +614,14 @@ static int launch_nn_t(const GemmNN& g, hipStream_t s) {
     static const bool dh3_wide = getenv("DWN_DH3_WIDE") != nullptr;
     const bool n64 = g.N <= 64 || (EPI == EPI_DH3 && !dh3_wide);
     if constexpr (HasSingle<ALD, EPI>::value) {
-        if (g.K <= BK) return n64 ? launch_nn_k<T, ALD, EPI, 64, true>(g, s) : launch_nn_k<T, ALD, EPI, 128, true>(g, s);
+        if (g.K <= BK) return n64 ? launch_nn_k<T, ALD, EPI, 64, 1>(g, s) : launch_nn_k<T, ALD, EPI, 128, 1>(g, s);
     }
-    return n64 ? launch_nn_k<T, ALD, EPI, 64, false>(g, s) : launch_nn_k<T, ALD, EPI, 128, false>(g, s);
+    if constexpr (HasSingle2<ALD, EPI>::value) {
+        static const bool no_s2 = getenv("DWN_NN_NO_S2") != nullptr;
+        if (g.K <= 2 * BK && !g.b_sample_stride && !no_s2)
+            return n64 ? launch_nn_k<T, ALD, EPI, 64, 2>(g, s) : launch_nn_k<T, ALD, EPI, 128, 2>(g, s);
+    }
+    return n64 ? launch_nn_k<T, ALD, EPI, 64, 0>(g, s) : launch_nn_k<T, ALD, EPI, 128, 0>(g, s);
 }
 
 template <typename T>

@@ -27,7 +27,7 @@ def _dt(L, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(128, 64, 64), (300, 448, 64), (257, 24, 8), (1000, 128, 448), (64, 256, 1792),
-                                   (513, 896, 128)])
+                                   (513, 896, 128), (1300, 136, 72), (640, 56, 128), (2000, 448, 40)])
 def test_gemm_nn_plain_with_stats(L, dtype, M, N, K):
     torch.manual_seed(M + N + K)
     a = torch.randn(M, K, device=dev()).to(dtype)

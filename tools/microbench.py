@@ -214,6 +214,11 @@ if __name__ == "__main__":
         dwt_bwd(32, 32, 5 * 8, 1792)
     if "dwtb1" in which:
         dwt_bwd(32, 32, 18 * 32, 448)
+    if "nnx" in which:                      # python tools/microbench.py nnx M N K [M N K ...]
+        nums = [int(v) for v in which[which.index("nnx") + 1:]]
+        for i in range(0, len(nums) - 2, 3):
+            gemm_nn(nums[i], nums[i + 1], nums[i + 2], "plain", True)
+        sys.exit(0)
     if "nndeep" in which:
         gemm_nn(589824, 896, 128, "plain", True)
         gemm_nn(589824, 896, 128, "plain", False)
