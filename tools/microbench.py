@@ -78,10 +78,11 @@ def gemm_nn(M, N, K, kind="plain", stats=False, S=None, T=32, H=36, W=64):
     report(f"gemm_nn M={M} N={N} K={K} {kind} stats={int(stats)}", ms, nb)
 
 
-def gemm_tn(M, R, Cc, pk="plain", qk="plain"):
+def gemm_tn(M, R, Cc, pk="plain", qk="plain", rows_per_sample=0):
     p = torch.randn(M, R, device=dev).to(BF)
     q = torch.randn(M, Cc, device=dev).to(BF)
-    dw = torch.zeros(R, Cc, device=dev)
+    nb_ = M // rows_per_sample if rows_per_sample else 1
+    dw = torch.zeros(nb_ * R, Cc, device=dev)
     keep = []
     dp, kp = desc(p, R), L.LD_PLAIN
     if pk == "affine2":
@@ -94,9 +95,10 @@ def gemm_tn(M, R, Cc, pk="plain", qk="plain"):
     g.p = dp; g.p_kind = kp; g.q = dq; g.q_kind = kq
     g.M, g.R, g.Cc = M, R, Cc
     g.dw = dw.data_ptr(); g.lddw = Cc; g.groups = 1; g.nsplit = 0
+    g.rows_per_sample = rows_per_sample; g.dw_sample_stride = R * Cc
     ms = timeit(lambda: L.check(L.lib.dwn_gemm_tn(C.byref(g), L.DWN_BF16, 0, stream()), "tn"))
     nb = (M * R * (2 if pk == "affine2" else 1) + M * Cc) * 2
-    report(f"gemm_tn M={M} R={R} Cc={Cc} {pk}/{qk}", ms, nb)
+    report(f"gemm_tn M={M} R={R} Cc={Cc} {pk}/{qk} rps={rows_per_sample}", ms, nb)
 
 
 def copy(nbytes):
@@ -214,6 +216,15 @@ if __name__ == "__main__":
         dwt_bwd(32, 32, 5 * 8, 1792)
     if "dwtb1" in which:
         dwt_bwd(32, 32, 18 * 32, 448)
+    if "tnps" in which:
+        gemm_tn(589824, 64, 448, "plain")
+        gemm_tn(589824, 64, 448, "plain", rows_per_sample=18432)
+        gemm_tn(589824, 128, 448, "plain")
+        gemm_tn(589824, 128, 448, "plain", rows_per_sample=18432)
+        gemm_tn(147456, 128, 896, "plain")
+        gemm_tn(147456, 128, 896, "plain", rows_per_sample=4608)
+        gemm_tn(147456, 256, 896, "plain")
+        gemm_tn(147456, 256, 896, "plain", rows_per_sample=4608)
     if "nnx" in which:                      # python tools/microbench.py nnx M N K [M N K ...]
         nums = [int(v) for v in which[which.index("nnx") + 1:]]
         for i in range(0, len(nums) - 2, 3):
