@@ -16,7 +16,8 @@ from pathlib import Path
 import torch  # noqa: F401,E402
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "csrc" / "libdwiseneuro_hip.so"
+# DWN_LIB_PATH: development override (A/B runs of two builds of the same ABI on one box)
+LIB_PATH = Path(os.environ["DWN_LIB_PATH"]) if os.environ.get("DWN_LIB_PATH") else _HERE / "csrc" / "libdwiseneuro_hip.so"
 
 c_p = C.c_void_p
 c_i = C.c_int

@@ -98,6 +98,18 @@ int bn_finalize(const double* stats, int stat_c, double count, const dwn_bn& bn,
     return k_bn_finalize_eval(bn.gamma, bn.beta, bn.running_mean, bn.running_var, eps, bn.coef, C, s);
 }
 
+BnFinJob fin_job(const double* stats, int stat_c, double count, const dwn_bn& bn, int C) {
+    BnFinJob j; memset(&j, 0, sizeof(j));
+    j.stats = stats; j.stat_c = stat_c; j.count = count; j.gamma = bn.gamma; j.beta = bn.beta;
+    j.running_mean = bn.running_mean; j.running_var = bn.running_var; j.nbt = bn.num_batches_tracked; j.coef = bn.coef; j.C = C;
+    return j;
+}
+BnBwdJob bwd_job(const double* stats, double count, const dwn_bn& bn, float* abc, int C) {
+    BnBwdJob j; memset(&j, 0, sizeof(j));
+    j.stats = stats; j.count = count; j.coef = bn.coef; j.dgamma = bn.dgamma; j.dbeta = bn.dbeta; j.abc = abc; j.C = C;
+    return j;
+}
+
 GemmNN nn_base(const LoadDesc& a, int a_kind, const void* b, i64 ldb, void* c, i64 ldc, int M, int N, int K, int groups) {
     GemmNN g; memset(&g, 0, sizeof(g));
     g.a = a; g.a_kind = a_kind; g.b = b; g.ldb = ldb; g.c = c; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
@@ -142,6 +154,8 @@ static bool pwl_bwd_per_sample(const dwn_block_args& a) {
     const double pass = (double)a.B * a.T * a.Hout * a.Wout * a.Cmid * tsize(a.dtype);
     return pb <= pass;
 }
+// floats of the conv_pw data-gradient folding scratch: G accumulator [Cin][Cin] and r3 [Cin]
+static size_t pw_fold_floats(int Cin) { return (size_t)Cin * Cin + Cin; }
 BlockWs carve_block(const dwn_block_args& a, int backward, void* base, size_t cap) {
     BlockWs w; memset(&w, 0, sizeof(w));
     Carver c(base, cap);
@@ -171,8 +185,8 @@ BlockWs carve_block(const dwn_block_args& a, int backward, void* base, size_t ca
         w.dhp = c.take<float>((size_t)a.B * a.se_r);
         w.dps = c.take<float>((size_t)a.B * a.Cmid);
         w.bp = c.take<char>((size_t)a.Cin * (a.Cmid + a.Cin) * ts);
-        w.r3 = c.take<float>((size_t)a.Cin);
-        w.gacc = c.take<float>((size_t)a.Cin * a.Cin);
+        w.gacc = c.take<float>(pw_fold_floats(a.Cin));                  // one zeroed range: G accumulator, r3
+        w.r3 = w.gacc + (size_t)a.Cin * a.Cin;
         if (pwl_bwd_per_sample(a)) w.pb = c.take<float>((size_t)a.B * a.Cout * a.Cmid);
     }
     w.bytes = c.off + 256;
@@ -397,11 +411,13 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
         g.stats = tr ? w.st4 : nullptr; g.stat_nchan = a.Cout;
         PROF(DWN_FAM_PWL_FWD, launch_gemm_nn(g, dt, s));
     }
-    if (tr) TRY(bn_finalize(w.st4, a.Cout, (double)Mout, a.bn4, a.Cout, tr, a.momentum, a.eps, s));
-    // shortcut (:125-134) + residual (:143)
+    // shortcut (:125-134) + residual (:143); the two linear BatchNorms (conv_pwl.1.bn, bn_sc.bn) finalise in one launch
     ResGeom gm = geom_of(a);
-    if (tr) PROF(DWN_FAM_RESID_FWD, k_shortcut_stats(xin, gm, w.stsc, dt, s));
-    if (tr) TRY(bn_finalize(w.stsc, a.Cin, (double)Mout, a.bnsc, a.Cout, tr, a.momentum, a.eps, s));
+    if (tr) {
+        PROF(DWN_FAM_RESID_FWD, k_shortcut_stats(xin, gm, w.stsc, dt, s));
+        TRY(k_bn_finalize_train2(fin_job(w.st4, a.Cout, (double)Mout, a.bn4, a.Cout),
+                                 fin_job(w.stsc, a.Cin, (double)Mout, a.bnsc, a.Cout), a.momentum, a.eps, s));
+    }
     PROF(DWN_FAM_RESID_FWD, k_residual_fwd(xin, a.y4, a.bn4.coef, a.bnsc.coef, a.drop_scale, gm, a.out_pe_t, a.out_pe_h,
                                            a.out_pe_w, a.out, dt, s));
     return 0;
@@ -433,6 +449,7 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
         ok = ok && pa.zero(a.dw_dwt, (size_t)a.Cmid * a.kt * sizeof(float));
         ok = ok && pa.zero(a.dw_pwl, (size_t)a.Cout * a.Cmid * sizeof(float));
         if (w.pb) ok = ok && pa.zero(w.pb, (size_t)a.B * a.Cout * a.Cmid * sizeof(float));
+        ok = ok && pa.zero(w.gacc, pw_fold_floats(a.Cin) * sizeof(float));
         if (!ok) return dwn_set_error(-2, "block_backward: workspace arena and dw_* buffers must be 16-byte aligned");
         TRY(k_prep(pa, dt, s));
     }
@@ -441,8 +458,8 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     ResGeom gm = geom_of(a);
     // residual + the two linear BNs (bn4 = conv_pwl.1.bn, bnsc = bn_sc.bn)
     PROF(DWN_FAM_RESID_BWD, k_residual_bwd_reduce(xin, a.y4, a.dout, a.bn4.coef, a.bnsc.coef, a.drop_scale, gm, w.st4, w.stsc, dt, s));
-    TRY(k_bn_bwd_finalize(w.st4, (double)Mout, a.bn4.coef, a.bn4.dgamma, a.bn4.dbeta, w.abc4, a.Cout, s));
-    TRY(k_bn_bwd_finalize(w.stsc, (double)Mout, a.bnsc.coef, a.bnsc.dgamma, a.bnsc.dbeta, w.abcsc, a.Cout, s));
+    TRY(k_bn_bwd_finalize2(bwd_job(w.st4, (double)Mout, a.bn4, w.abc4, a.Cout),
+                           bwd_job(w.stsc, (double)Mout, a.bnsc, w.abcsc, a.Cout), s));
     PROF(DWN_FAM_RESID_BWD, k_residual_bwd_dy4(a.y4, a.dout, w.abc4, a.drop_scale, gm, a.dy4, dt, s));
     // conv_pwl backward: du = dy4 @ W2 (+ SE gate gradient), dW2 = dy4^T @ u
     void* du = a.buf_a;
@@ -587,9 +604,14 @@ int dwn_cortex_forward(const dwn_cortex_args* ap, int device, void* stream) {
     GemmNN g = nn_base(ld_plain(a.x, a.Cin), LD_PLAIN, w.wp, Kg, a.y, a.C, M, Ng, Kg, a.groups);
     g.stats = tr ? w.st : nullptr; g.stat_nchan = a.C;
     TRY(launch_gemm_nn(g, dt, s));
-    TRY(bn_finalize(w.st, a.C, (double)M, a.bn, a.C, tr, a.momentum, a.eps, s));
-    if (tr) TRY(k_colstats(ld_plain(a.x, a.Cin), LD_PLAIN, M, a.Cin, w.stsc, dt, s));
-    TRY(bn_finalize(w.stsc, a.Cin, (double)M, a.bnsc, a.C, tr, a.momentum, a.eps, s));
+    if (tr) {
+        TRY(k_colstats(ld_plain(a.x, a.Cin), LD_PLAIN, M, a.Cin, w.stsc, dt, s));
+        TRY(k_bn_finalize_train2(fin_job(w.st, a.C, (double)M, a.bn, a.C), fin_job(w.stsc, a.Cin, (double)M, a.bnsc, a.C),
+                                 a.momentum, a.eps, s));
+    } else {
+        TRY(bn_finalize(w.st, a.C, (double)M, a.bn, a.C, tr, a.momentum, a.eps, s));
+        TRY(bn_finalize(w.stsc, a.Cin, (double)M, a.bnsc, a.C, tr, a.momentum, a.eps, s));
+    }
     return k_cortex_residual_fwd(a.y, a.x, a.bn.coef, a.bnsc.coef, a.drop_scale, M, a.T, a.Cin, a.C, a.groups, a.out,
                                  dt, s);
 }
@@ -610,8 +632,7 @@ int dwn_cortex_backward(const dwn_cortex_args* ap, int device, void* stream) {
     }
     TRY(k_cortex_bwd_reduce(a.y, a.x, a.dout, a.dout_mask, a.dout_mask_ld, a.bn.coef, a.bnsc.coef, a.drop_scale, M, a.T,
                             a.Cin, a.C, a.groups, w.st, w.stsc, dt, s));
-    TRY(k_bn_bwd_finalize(w.st, (double)M, a.bn.coef, a.bn.dgamma, a.bn.dbeta, w.abc, a.C, s));
-    TRY(k_bn_bwd_finalize(w.stsc, (double)M, a.bnsc.coef, a.bnsc.dgamma, a.bnsc.dbeta, w.abcsc, a.C, s));
+    TRY(k_bn_bwd_finalize2(bwd_job(w.st, (double)M, a.bn, w.abc, a.C), bwd_job(w.stsc, (double)M, a.bnsc, w.abcsc, a.C), s));
     TRY(k_cortex_bwd_dy(a.y, a.dout, a.dout_mask, a.dout_mask_ld, a.bn.coef, w.abc, a.drop_scale, M, a.T, a.C, a.groups,
                         w.dy, dt, s));
     {

@@ -92,12 +92,12 @@ __device__ __forceinline__ void rep_reduce(const double* stats, int stat_c, int 
     for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_train_kernel(const double* stats, int stat_c, double count,
-                                                                const float* gamma, const float* beta,
-                                                                float* running_mean, float* running_var, long long* nbt,
-                                                                float momentum, float eps, float* coef, int C) {
+__device__ __forceinline__ void bn_finalize_train_body(const int blk, const double* stats, int stat_c, double count,
+                                                       const float* gamma, const float* beta, float* running_mean,
+                                                       float* running_var, long long* nbt, float momentum, float eps,
+                                                       float* coef, int C) {
     const int r = threadIdx.x & 31;
-    const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int c = blk * 8 + (threadIdx.x >> 5);
     if (c == 0 && r == 0 && nbt) *nbt += 1;
     const bool ok = c < C;
     const int sc = ok ? c % stat_c : 0;      // shortcut BN: out channel c uses the stats of in channel c % C_in
@@ -119,6 +119,20 @@ __global__ __launch_bounds__(256) void bn_finalize_train_kernel(const double* st
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
 }
+__global__ __launch_bounds__(256) void bn_finalize_train_kernel(const double* stats, int stat_c, double count,
+                                                                const float* gamma, const float* beta,
+                                                                float* running_mean, float* running_var, long long* nbt,
+                                                                float momentum, float eps, float* coef, int C) {
+    bn_finalize_train_body(blockIdx.x, stats, stat_c, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, coef, C);
+}
+// two independent BatchNorms in one launch (conv_pwl.1.bn + bn_sc.bn; the cortex pair): every tiny launch costs ~4.5 us
+// of GPU timeline on this part whatever its size
+__global__ __launch_bounds__(256) void bn_finalize_train2_kernel(BnFinJob j0, BnFinJob j1, float momentum, float eps) {
+    const bool first = (int)blockIdx.x < j0.nblocks;
+    const BnFinJob& j = first ? j0 : j1;
+    bn_finalize_train_body(first ? blockIdx.x : blockIdx.x - j0.nblocks, j.stats, j.stat_c, j.count, j.gamma, j.beta,
+                           j.running_mean, j.running_var, j.nbt, momentum, eps, j.coef, j.C);
+}
 
 __global__ void bn_finalize_eval_kernel(const float* gamma, const float* beta, const float* running_mean,
                                         const float* running_var, float eps, float* coef, int C) {
@@ -133,10 +147,10 @@ __global__ void bn_finalize_eval_kernel(const float* gamma, const float* beta, c
 }
 
 // backward: stats = [NREP][2][C] with Σdh and Σdh·ŷ.  dy = A1*dh + A2*y + A3 (y raw), dgamma = Σdh·ŷ, dbeta = Σdh
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* stats, double count, const float* coef,
-                                                              float* dgamma, float* dbeta, float* abc, int C) {
+__device__ __forceinline__ void bn_bwd_finalize_body(const int blk, const double* stats, double count, const float* coef,
+                                                     float* dgamma, float* dbeta, float* abc, int C) {
     const int r = threadIdx.x & 31;
-    const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int c = blk * 8 + (threadIdx.x >> 5);
     const bool ok = c < C;
     double s1, s2;
     rep_reduce(stats, C, ok ? c : 0, r, ok, s1, s2);
@@ -149,12 +163,33 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* stat
     abc[C + c] = (float)(-(double)scale * invstd * m2);
     abc[2 * C + c] = (float)((double)scale * (-m1 + (double)mean * invstd * m2));
 }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* stats, double count, const float* coef,
+                                                              float* dgamma, float* dbeta, float* abc, int C) {
+    bn_bwd_finalize_body(blockIdx.x, stats, count, coef, dgamma, dbeta, abc, C);
+}
+__global__ __launch_bounds__(256) void bn_bwd_finalize2_kernel(BnBwdJob j0, BnBwdJob j1) {
+    const bool first = (int)blockIdx.x < j0.nblocks;
+    const BnBwdJob& j = first ? j0 : j1;
+    bn_bwd_finalize_body(first ? blockIdx.x : blockIdx.x - j0.nblocks, j.stats, j.count, j.coef, j.dgamma, j.dbeta, j.abc, j.C);
+}
 
 int k_bn_finalize_train(const double* stats, int stat_c, double count, const float* gamma, const float* beta,
                         float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef, int C,
                         hipStream_t s) {
     hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 7) / 8), dim3(256), 0, s, stats, stat_c, count,
                        gamma, beta, rm, rv, nbt, momentum, eps, coef, C);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_bn_finalize_train2(BnFinJob j0, BnFinJob j1, float momentum, float eps, hipStream_t s) {
+    j0.nblocks = (j0.C + 7) / 8; j1.nblocks = (j1.C + 7) / 8;
+    hipLaunchKernelGGL(bn_finalize_train2_kernel, dim3(j0.nblocks + j1.nblocks), dim3(256), 0, s, j0, j1, momentum, eps);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_bn_bwd_finalize2(BnBwdJob j0, BnBwdJob j1, hipStream_t s) {
+    j0.nblocks = (j0.C + 7) / 8; j1.nblocks = (j1.C + 7) / 8;
+    hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3(j0.nblocks + j1.nblocks), dim3(256), 0, s, j0, j1);
     DWN_CHECK_LAUNCH();
     return 0;
 }
@@ -1720,40 +1755,44 @@ int k_bn_bwd_reduce_plain(const void* g, const void* y, const float* coef, i64 r
 // The GEMM then reads dh1 (and the small a0) only: half the HBM traffic of reading (dh1, y1).
 // Bp[n][k] (T, ld = E + C): k < E: A1[k]*W1[k][n];  k = E + c': G[c'][n].   W1 is used as rounded to T (forward's values).
 // ------------------------------------------------------------------------------------------------
+// One launch: blocks [0, nscale) write the diag(A1) W1 part of Bp; the others accumulate 64-row chunks of E into
+// gacc[C][C] / r3[C] with fp32 atomics (zeroed by the caller's prep launch); a second launch converts G into Bp.  Was five dependent tiny launches on the dws_bwd -> pw_dgrad critical path.
 template <typename T>
-__global__ __launch_bounds__(256) void pw_bwd_scale_kernel(const float* w1, const float* abc, int E, int C, T* bp) {
-    const i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void pw_bwd_prep_kernel(const float* w1, const float* abc, int E, int C, T* bp, float* gacc,
+                                                          float* r3, int nscale, int gx, int gy) {
     const i64 ld = (i64)E + C;
-    if (idx < (i64)E * C) {
-        const int k = (int)(idx / C), n = (int)(idx % C);
-        bp[n * ld + k] = from_f<T>(abc[k] * round_t<T>(w1[idx]));
+    int bid = blockIdx.x;
+    if (bid < nscale) {
+        const i64 idx = (i64)bid * 256 + threadIdx.x;
+        if (idx < (i64)E * C) {
+            const int k = (int)(idx / C), n = (int)(idx % C);
+            bp[n * ld + k] = from_f<T>(abc[k] * round_t<T>(w1[idx]));
+        }
+        return;
     }
-}
-// partial sums over one 64-row chunk of E (blockIdx.z), accumulated with fp32 atomics into gacc[C][C] and r3[C]:
-//   gacc[c'][c] += sum_e A2[e] W1[e][c'] W1[e][c]        r3[c] += sum_e A3[e] W1[e][c]
-template <typename T>
-__global__ __launch_bounds__(256) void pw_bwd_gram_kernel(const float* w1, const float* abc, int E, int C, float* gacc,
-                                                          float* r3) {
-    const int cp = blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int c = blockIdx.y * 16 + (threadIdx.x & 15);
-    const int e0 = blockIdx.z * 64;
-    const int e1 = e0 + 64 < E ? e0 + 64 : E;
-    if (cp >= C || c >= C) return;
-    const float* A2 = abc + E;
-    const float* A3 = abc + 2 * E;
-    float acc = 0.f, acc3 = 0.f;
-    (void)e1;
+    bid -= nscale;
+    const int bx = bid % gx, by = (bid / gx) % gy, bz = bid / (gx * gy);
+    const int cp = bx * 16 + (threadIdx.x >> 4);
+    const int c = by * 16 + (threadIdx.x & 15);
+    const int e0 = bz * 64;
+    if (cp < C && c < C) {
+        const float* A2 = abc + E;
+        const float* A3 = abc + 2 * E;
+        float acc = 0.f, acc3 = 0.f;
 #pragma unroll 16
-    for (int i = 0; i < 64; ++i) {            // fixed trip count + clamped index: 16 x 4 independent loads in flight
-        const int e = e0 + i < E ? e0 + i : E - 1;
-        const float on = e0 + i < E ? 1.f : 0.f;
-        const float wc = round_t<T>(w1[(i64)e * C + c]) * on;
-        acc = fmaf(A2[e] * round_t<T>(w1[(i64)e * C + cp]), wc, acc);
-        acc3 = fmaf(A3[e], wc, acc3);
+        for (int i = 0; i < 64; ++i) {            // fixed trip count + clamped index: 16 x 4 independent loads in flight
+            const int e = e0 + i < E ? e0 + i : E - 1;
+            const float on = e0 + i < E ? 1.f : 0.f;
+            const float wc = round_t<T>(w1[(i64)e * C + c]) * on;
+            acc = fmaf(A2[e] * round_t<T>(w1[(i64)e * C + cp]), wc, acc);
+            acc3 = fmaf(A3[e], wc, acc3);
+        }
+        atomicAdd(gacc + (i64)cp * C + c, acc);
+        if (bx == 0 && (threadIdx.x >> 4) == 0) atomicAdd(r3 + c, acc3);
     }
-    atomicAdd(gacc + (i64)cp * C + c, acc);
-    if (blockIdx.x == 0 && (threadIdx.x >> 4) == 0) atomicAdd(r3 + c, acc3);
 }
+// (a "last block converts G" tail instead of this second launch was measured 4x slower than the whole chain it replaced:
+// an agent-scope release fence per block means an L2 write-back on this 8-XCD part)
 template <typename T>
 __global__ __launch_bounds__(256) void pw_bwd_gram_store_kernel(const float* gacc, int E, int C, T* bp) {
     const i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -1761,23 +1800,17 @@ __global__ __launch_bounds__(256) void pw_bwd_gram_store_kernel(const float* gac
     const int cp = (int)(idx / C), c = (int)(idx % C);
     bp[(i64)c * ((i64)E + C) + E + cp] = from_f<T>(gacc[idx]);       // Bp[n = c][E + c'] = G[c'][c]
 }
-// gacc: [C*C] fp32 scratch, r3: [C] fp32 — both zeroed here
+// gacc [C*C] fp32 and r3 [C] fp32 must be zero on entry (the block backward's prep launch clears them)
 int k_pw_bwd_prep(const float* w1, const float* abc, int E, int C, void* bp, float* gacc, float* r3, int dtype,
                   hipStream_t s) {
-    int rc = k_fill_f32(gacc, 0.f, C * C, s);
-    if (rc) return rc;
-    rc = k_fill_f32(r3, 0.f, C, s);
-    if (rc) return rc;
-    dim3 g1((unsigned)(((i64)E * C + 255) / 256)), g2((C + 15) / 16, (C + 15) / 16, (E + 63) / 64);
+    const int nscale = (int)(((i64)E * C + 255) / 256);
+    const int gx = (C + 15) / 16, gy = (C + 15) / 16, gz = (E + 63) / 64;
+    const int ngram = gx * gy * gz;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((pw_bwd_prep_kernel<bf16_t>), dim3(nscale + ngram), dim3(256), 0, s, w1, abc, E, C, (bf16_t*)bp, gacc, r3, nscale, gx, gy),
+        hipLaunchKernelGGL((pw_bwd_prep_kernel<float>), dim3(nscale + ngram), dim3(256), 0, s, w1, abc, E, C, (float*)bp, gacc, r3, nscale, gx, gy));
+    DWN_CHECK_LAUNCH();
     dim3 g3((unsigned)(((i64)C * C + 255) / 256));
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL((pw_bwd_scale_kernel<bf16_t>), g1, dim3(256), 0, s, w1, abc, E, C, (bf16_t*)bp),
-        hipLaunchKernelGGL((pw_bwd_scale_kernel<float>), g1, dim3(256), 0, s, w1, abc, E, C, (float*)bp));
-    DWN_CHECK_LAUNCH();
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL((pw_bwd_gram_kernel<bf16_t>), g2, dim3(256), 0, s, w1, abc, E, C, gacc, r3),
-        hipLaunchKernelGGL((pw_bwd_gram_kernel<float>), g2, dim3(256), 0, s, w1, abc, E, C, gacc, r3));
-    DWN_CHECK_LAUNCH();
     DISPATCH_T(dtype,
         hipLaunchKernelGGL((pw_bwd_gram_store_kernel<bf16_t>), g3, dim3(256), 0, s, gacc, E, C, (bf16_t*)bp),
         hipLaunchKernelGGL((pw_bwd_gram_store_kernel<float>), g3, dim3(256), 0, s, gacc, E, C, (float*)bp));

@@ -10,6 +10,13 @@ struct ResGeom {
 
 typedef dwn_tensor_entry TensorListEntry;
 
+struct BnFinJob {
+    const double* stats; int stat_c; double count; const float* gamma; const float* beta;
+    float* running_mean; float* running_var; long long* nbt; float* coef; int C; int nblocks;
+};
+struct BnBwdJob { const double* stats; double count; const float* coef; float* dgamma; float* dbeta; float* abc; int C; int nblocks; };
+int k_bn_finalize_train2(BnFinJob j0, BnFinJob j1, float momentum, float eps, hipStream_t s);
+int k_bn_bwd_finalize2(BnBwdJob j0, BnBwdJob j1, hipStream_t s);
 int k_bn_finalize_train(const double* stats, int stat_c, double count, const float* gamma, const float* beta,
                         float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef, int C,
                         hipStream_t s);
@@ -84,7 +91,7 @@ int k_pw_bwd_prep(const float* w1, const float* abc, int E, int C, void* bp, flo
 
 // ---- fused per-call preparation (k_prep): zero ranges, constant fills and weight packs in one launch
 enum { PREP_ZERO = 0, PREP_FILL = 1, PREP_PACKW = 2, PREP_PACKDW = 3, PREP_BNEVAL = 4 };
-#define PREP_MAX_OPS 12
+#define PREP_MAX_OPS 16
 struct PrepOp {
     int kind, nblocks;
     const float* src; void* dst;
