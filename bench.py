@@ -29,6 +29,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 NUM_NEURONS_MOUSE0 = 7863          # src/constants.py:26 (first mouse)
+NUM_NEURONS_ALL = (7863, 7908, 8202, 7939, 8122, 7440, 7928, 8285, 7671, 7495)     # src/constants.py:24,31
 CORE_FEATURES = (64, 64, 64, 64, 128, 128, 128, 256, 256)
 STRIDES = (2, 1, 1, 1, 2, 1, 1, 2, 1)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -45,6 +46,17 @@ def model_params(expansion=7, readouts=(NUM_NEURONS_MOUSE0,)):
         "optimizer": ("AdamW", {"lr": 3e-4 * 32 / 4, "weight_decay": 0.05}),
         "amp": True, "iter_size": 1,
     }
+
+
+def workload_name(args):
+    if args.distill:
+        return (f"configs/distillation_001.py step (NOT the metric config): expansion-6 student, {args.mice} readout(s), "
+                "frozen expansion-7 teacher forward + soft-label fill (ratio 0.36), AdamW + EMA")
+    if args.mice != 1:
+        return (f"configs/true_batch_001.py with {args.mice} readouts (NOT the metric config), expansion {args.expansion}, "
+                "AdamW + EMA")
+    return ("configs/true_batch_001.py single-mouse training (expansion 7, 1 readout x 7863 neurons, dropout 0.4, "
+            "drop-path 0.1), AdamW + EMA")
 
 
 def block_shapes(batch, frames, height, width, expansion):
@@ -131,6 +143,10 @@ def main():
     ap.add_argument("--expansion", type=int, default=7)
     ap.add_argument("--no-fwd-bwd", action="store_true", help="skip the extra forward+backward-only timing loop")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--mice", type=int, default=1, help="readouts (1 = the metric config; 10 = the ten-mouse model, "
+                    "configs/true_batch_001.py:23 with constants.num_neurons) — other workloads are labelled as such")
+    ap.add_argument("--distill", action="store_true", help="configs/distillation_001.py step: frozen expansion-7 teacher "
+                    "forward + soft-label fill (ratio 0.36) + expansion-6 student step")
     ap.add_argument("--roofline-family", default="dws_bwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel family (adds event overhead)")
@@ -157,7 +173,9 @@ def main():
     from sensorium_amd.argus_models import MouseModel
     from sensorium_amd.synthetic import make_batch
 
-    params = model_params(args.expansion)
+    num_neurons = NUM_NEURONS_ALL[:args.mice]
+    expansion = 6 if args.distill else args.expansion          # distillation_001.py: student expansion 6
+    params = model_params(expansion, num_neurons)
     params["device"] = str(dev)
     params["amp"] = args.dtype == "bf16"
     torch.manual_seed(1234)            # identical init on every rank (GradBuckets also broadcasts rank 0)
@@ -171,8 +189,22 @@ def main():
             if m.bias is not None:
                 torch.nn.init.zeros_(m.bias)
     model.set_ema(0.999)
-    batch = make_batch(args.batch, args.frames, args.height, args.width, (NUM_NEURONS_MOUSE0,),
-                       seed=20231122 + rank, device=dev)
+    if args.distill:
+        tparams = model_params(7, num_neurons)
+        tparams["device"] = str(dev)
+        teacher = MouseModel(tparams)
+        teacher.eval()
+        model.distill_model = teacher.nn_module
+        model.distill_ratio = 0.36                            # distillation_001.py:67-70
+    batch0 = make_batch(args.batch, args.frames, args.height, args.width, num_neurons,
+                        seed=20231122 + rank, device=dev)
+
+    def next_batch():
+        if not args.distill:
+            return batch0
+        # the soft-label fill writes into targets / weights in place (argus_models.py:37-41): every step gets a fresh copy
+        x0, (t0, w0) = batch0
+        return x0, ([t.clone() for t in t0], w0.clone())
 
     def sync():
         if world > 1:
@@ -180,7 +212,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        model.train_step(batch, sync_loss=False)
+        model.train_step(next_batch(), sync_loss=False)
     fam_names = L.FAMILIES
     if args.profile_all:
         mask = (1 << len(fam_names)) - 1
@@ -191,7 +223,7 @@ def main():
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
-        last = model.train_step(batch, sync_loss=False)
+        last = model.train_step(next_batch(), sync_loss=False)
     sync()
     elapsed = time.perf_counter() - t0
     loss_value = float(last["loss"])
@@ -205,8 +237,8 @@ def main():
     L.check(L.lib.dwn_profile_enable(0, local_rank), "profile_disable")
     # SURVEY.md §8d asks for both figures: the same steps without optimizer / EMA (forward + loss + backward only)
     fwd_bwd_clips = None
-    if world == 1 and not args.no_fwd_bwd:
-        net, inp, tgt = model.nn_module, batch[0], batch[1]
+    if world == 1 and not args.no_fwd_bwd and not args.distill:
+        net, inp, tgt = model.nn_module, batch0[0], batch0[1]
         n_fb = max(3, args.steps // 2)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -228,7 +260,7 @@ def main():
         clips = args.batch * world * args.steps
         value = clips / elapsed
         esize = 2 if args.dtype == "bf16" else 4
-        shapes = block_shapes(args.batch, args.frames, args.height, args.width, args.expansion)
+        shapes = block_shapes(args.batch, args.frames, args.height, args.width, expansion)
         alg = family_algorithmic_elems(shapes)
         roof = None
         fam = args.roofline_family
@@ -245,8 +277,8 @@ def main():
             # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected inside the timed
             # run): read from the committed summary of the same command at the default metric shape, see
             # tools/pmc_traffic.py; expressed like `achieved` (bytes per launch / this run's launch duration)
-            default_shape = (args.batch, args.frames, args.height, args.width, args.expansion, args.dtype) == \
-                            (32, 32, 36, 64, 7, "bf16")
+            default_shape = (args.batch, args.frames, args.height, args.width, expansion, args.dtype, args.mice) == \
+                            (32, 32, 36, 64, 7, "bf16", 1)
             tpath = ROOT / "profiles" / "r1c_pmc_traffic.json"
             if default_shape and tpath.exists():
                 try:
@@ -264,8 +296,7 @@ def main():
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "configs/true_batch_001.py single-mouse training (expansion 7, 1 readout x 7863 "
-                                   "neurons, dropout 0.4, drop-path 0.1), AdamW + EMA",
+            "config": {"workload": workload_name(args),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "frames": args.frames,
                        "height": args.height, "width": args.width, "parallelism": f"dp{world}"},
             "clips_per_s_per_gpu": round(value / world, 2), "loss": round(loss_value, 3),
@@ -274,7 +305,7 @@ def main():
         }
         if args.profile_all:
             out["family_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in fam_ms.items()}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.mice == 1 and not args.distill:
             out["cpu_baseline"] = cpu_baseline(args.frames, args.height, args.width, args.expansion)
         print(json.dumps(out), flush=True)
     if world > 1:
