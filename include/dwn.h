@@ -328,6 +328,19 @@ int dwn_ema_lerp_multi(const dwn_tensor_entry* list, int ntensors, int max_block
                        void* stream);
 
 
+/* conv_pw backward (dwiseneuro.py:90-93 backward) of a 64-channel block in ONE pass over dh1 / y1:
+ *   dy1 = abc[0]*dh1 + abc[1]*y1 + abc[2]  (BatchNorm-backward affine, per channel of E; abc is [3][E]),
+ *   da0[M][Cin] = dy1 . W1,   dw[E][Cin] += dy1^T . a0   (dw fp32, accumulated: zero it first).
+ * w1t = W1^T as [Cin][E] in `dtype`.  Built for dtype == DWN_BF16, Cin == 64, E == 448, M % 128 == 0
+ * (dwn_pw_bwd_fused_supported); anything else returns -3 and the caller uses dwn_gemm_nn + dwn_gemm_tn. */
+typedef struct dwn_pw_bwd_args {
+    const void* dh1; const void* y1; const void* a0; const void* w1t; const float* abc;
+    void* da0; float* dw;
+    long long M; int E; int Cin;
+} dwn_pw_bwd_args;
+int dwn_pw_bwd_fused_supported(int dtype, long long M, int E, int Cin);
+int dwn_pw_bwd_fused(const dwn_pw_bwd_args* a, int dtype, int device, void* stream);
+
 /* StackInputsProcessor + CutMix on the inputs (inputs.py:15-36, mixers.py:52-63) for a whole batch:
  * x [B][5][T][H][W] fp32 = channel 0 the video centre-padded with pad_fill, channels 1-2 behavior, 3-4 pupil_center
  * broadcast over the frame.  `descs` is a DEVICE array of B entries; every video has the same H0 x W0. */

@@ -146,6 +146,11 @@ class ClipDesc(C.Structure):
                 ("one_minus_lam", c_f), ("lam", c_f), ("mouse", c_i), ("pad_", c_i)]
 
 
+class PwBwdArgs(C.Structure):
+    _fields_ = [("dh1", c_p), ("y1", c_p), ("a0", c_p), ("w1t", c_p), ("abc", c_p), ("da0", c_p), ("dw", c_p),
+                ("M", c_ll), ("E", c_i), ("Cin", c_i)]
+
+
 VID_U8, VID_F32 = 0, 1
 
 _STRUCTS = {
@@ -154,7 +159,7 @@ _STRUCTS = {
     "dwn_dw_temporal_fwd_args": DwTemporalFwdArgs, "dwn_dw_temporal_bwd_args": DwTemporalBwdArgs,
     "dwn_bn": BN, "dwn_stem_args": StemArgs, "dwn_block_args": BlockArgs, "dwn_pool_args": PoolArgs,
     "dwn_cortex_args": CortexArgs, "dwn_readout_args": ReadoutArgs, "dwn_tensor_entry": TensorEntry,
-    "dwn_clip_src": ClipSrc, "dwn_clip_desc": ClipDesc,
+    "dwn_clip_src": ClipSrc, "dwn_clip_desc": ClipDesc, "dwn_pw_bwd_args": PwBwdArgs,
 }
 
 # every symbol include/dwn.h declares: (restype, argtypes)
@@ -193,6 +198,8 @@ SYMBOLS = {
     "dwn_f64_to_f32": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "dwn_adamw_ema_multi": (c_i, [c_p, c_i, c_i, c_d, c_d, c_d, c_d, c_d, c_ll, c_d, c_d, c_i, c_p]),
     "dwn_ema_lerp_multi": (c_i, [c_p, c_i, c_i, c_d, c_i, c_p]),
+    "dwn_pw_bwd_fused_supported": (c_i, [c_i, c_ll, c_i, c_i]),
+    "dwn_pw_bwd_fused": (c_i, [_P(PwBwdArgs), c_i, c_i, c_p]),
     "dwn_assemble_inputs": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     "dwn_assemble_targets": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_p]),
 }

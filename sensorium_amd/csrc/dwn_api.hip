@@ -220,7 +220,7 @@ int dwn_sizeof(const char* name) {
     SZ(dwn_load_desc); SZ(dwn_gemm_nn_args); SZ(dwn_gemm_tn_args); SZ(dwn_dw_spatial_fwd_args);
     SZ(dwn_dw_spatial_bwd_args); SZ(dwn_dw_temporal_fwd_args); SZ(dwn_dw_temporal_bwd_args); SZ(dwn_bn);
     SZ(dwn_stem_args); SZ(dwn_block_args); SZ(dwn_pool_args); SZ(dwn_cortex_args); SZ(dwn_readout_args);
-    SZ(dwn_tensor_entry); SZ(dwn_clip_src); SZ(dwn_clip_desc);
+    SZ(dwn_tensor_entry); SZ(dwn_clip_src); SZ(dwn_clip_desc); SZ(dwn_pw_bwd_args);
 #undef SZ
     return -1;
 }
@@ -449,7 +449,9 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
         ok = ok && pa.zero(a.dw_dwt, (size_t)a.Cmid * a.kt * sizeof(float));
         ok = ok && pa.zero(a.dw_pwl, (size_t)a.Cout * a.Cmid * sizeof(float));
         if (w.pb) ok = ok && pa.zero(w.pb, (size_t)a.B * a.Cout * a.Cmid * sizeof(float));
-        ok = ok && pa.zero(w.gacc, pw_fold_floats(a.Cin) * sizeof(float));
+        const bool pw_fused = dwn_pw_bwd_fused_supported(dt, Min, a.Cmid, a.Cin) != 0;
+        if (pw_fused) ok = ok && pa.packw(a.w_pw, w.wpw, 1, a.Cmid, a.Cin, 1, a.Cin, a.Cmid);       // W1^T [Cin][Cmid]
+        else ok = ok && pa.zero(w.gacc, pw_fold_floats(a.Cin) * sizeof(float));
         if (!ok) return dwn_set_error(-2, "block_backward: workspace arena and dw_* buffers must be 16-byte aligned");
         TRY(k_prep(pa, dt, s));
     }
@@ -530,17 +532,22 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     TRY(k_bn_bwd_finalize(w.st1, (double)Min, a.bn1.coef, a.bn1.dgamma, a.bn1.dbeta, w.abc1, a.Cmid, s));
     // conv_pw backward.  Data gradient: dy1 = A1*dh1 + A2*y1 + A3 with y1 = a0.W1^T, so the y1 term folds into a
     // Cin x Cin matrix and the GEMM reads dh1 (+ the small a0) only:  da0 = [dh1 | a0] . [diag(A1) W1 ; G] + r3
-    TRY(k_pw_bwd_prep(a.w_pw, w.abc1, a.Cmid, a.Cin, w.bp, w.gacc, w.r3, dt, s));
-    {
-        GemmNN g = nn_base(ld_plain(dh1, a.Cmid), LD_PLAIN, w.bp, (i64)a.Cmid + a.Cin, a.da0, a.Cin, (int)Min, a.Cin,
-                           a.Cmid + a.Cin, 1);
-        g.epi = EPI_STORE_CAT; g.a2 = xin.p; g.a2_ld = a.Cin; g.K1 = a.Cmid; g.bias = w.r3;
-        PROF(DWN_FAM_PW_DGRAD, launch_gemm_nn(g, dt, s));
-    }
-    {   // weight gradient: dW1 = dy1^T a0 with the BatchNorm-backward affine applied while loading (dh1, y1)
-        LoadDesc dy1 = ld_affine2(dh1, a.y1, a.Cmid, w.abc1, a.Cmid);
-        GemmTN g = tn_base(dy1, LD_AFFINE2, xin, LD_PLAIN, (int)Min, a.Cmid, a.Cin, a.dw_pw, a.Cin, 1);
-        PROF(DWN_FAM_PW_WGRAD, launch_gemm_tn(g, dt, s));
+    if (dwn_pw_bwd_fused_supported(dt, Min, a.Cmid, a.Cin)) {
+        // 64-channel blocks: data gradient and weight gradient from one pass over (dh1, y1)
+        PROF(DWN_FAM_PW_DGRAD, launch_pw_bwd_fused(dh1, a.y1, xin.p, w.wpw, w.abc1, a.da0, a.dw_pw, Min, a.Cmid, a.Cin, dt, s));
+    } else {
+        TRY(k_pw_bwd_prep(a.w_pw, w.abc1, a.Cmid, a.Cin, w.bp, w.gacc, w.r3, dt, s));
+        {
+            GemmNN g = nn_base(ld_plain(dh1, a.Cmid), LD_PLAIN, w.bp, (i64)a.Cmid + a.Cin, a.da0, a.Cin, (int)Min, a.Cin,
+                               a.Cmid + a.Cin, 1);
+            g.epi = EPI_STORE_CAT; g.a2 = xin.p; g.a2_ld = a.Cin; g.K1 = a.Cmid; g.bias = w.r3;
+            PROF(DWN_FAM_PW_DGRAD, launch_gemm_nn(g, dt, s));
+        }
+        {   // weight gradient: dW1 = dy1^T a0 with the BatchNorm-backward affine applied while loading (dh1, y1)
+            LoadDesc dy1 = ld_affine2(dh1, a.y1, a.Cmid, w.abc1, a.Cmid);
+            GemmTN g = tn_base(dy1, LD_AFFINE2, xin, LD_PLAIN, (int)Min, a.Cmid, a.Cin, a.dw_pw, a.Cin, 1);
+            PROF(DWN_FAM_PW_WGRAD, launch_gemm_tn(g, dt, s));
+        }
     }
     PROF(DWN_FAM_RESID_BWD, k_residual_bwd_dx(xin, a.da0, a.dout, w.abcsc, gm, a.dx, dt, s));
     return 0;
@@ -760,6 +767,18 @@ int dwn_ema_lerp_multi(const dwn_tensor_entry* list, int ntensors, int max_block
                        void* stream) {
     ENTER(device);
     return k_ema_lerp(list, ntensors, max_blocks, (float)decay, (float)(1.0 - decay), (hipStream_t)stream);
+}
+
+int dwn_pw_bwd_fused_supported(int dtype, long long M, int E, int Cin) {
+    static const bool off = getenv("DWN_PW_FUSED_OFF") != nullptr;
+    return (!off && pw_bwd_fused_supported(dtype, M, E, Cin)) ? 1 : 0;
+}
+int dwn_pw_bwd_fused(const dwn_pw_bwd_args* a, int dtype, int device, void* stream) {
+    ENTER(device);
+    if (!a || !a->dh1 || !a->y1 || !a->a0 || !a->w1t || !a->abc || !a->da0 || !a->dw)
+        return dwn_set_error(-1, "pw_bwd_fused: null pointer");
+    return launch_pw_bwd_fused(a->dh1, a->y1, a->a0, a->w1t, a->abc, a->da0, a->dw, a->M, a->E, a->Cin, dtype,
+                               (hipStream_t)stream);
 }
 
 int dwn_assemble_inputs(const dwn_clip_desc* descs, int B, int T, int H0, int W0, int H, int W, float pad_fill,

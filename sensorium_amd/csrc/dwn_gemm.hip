@@ -943,3 +943,182 @@ int launch_gemm_tn(const GemmTN& g_in, int dtype, hipStream_t s) {
     const GemmTN& g = g_in;
     return dtype == DWN_BF16 ? launch_tn_d<bf16_t>(g, s) : launch_tn_d<float>(g, s);
 }
+
+// ------------------------------------------------------------------------------------------------
+// conv_pw backward of the 64-channel blocks (Cin = 64, E = 448) reading dh1 / y1 ONCE: per 128-row tile and 64-column chunk
+// of E the BatchNorm-backward affine dy1 = A1*dh1 + A2*y1 + A3 is built in LDS (rounded to bf16 like the TN loader does)
+// and feeds both products — da0 += dy1 . W1 (row-major fragments, W1^T resident in LDS) and dW1[chunk] += dy1^T . a0
+// (ds_read_tr16_b64 fragments; 7 x 8 accumulator registers per thread) — with one fp32 atomic flush of dW1 per workgroup.
+// 512 threads, one workgroup per CU (143 KB of LDS), persistent over the tiles.  Replaces gemm_nn (K-concat folding) +
+// gemm_tn (affine2), which each streamed dh1: 1083 us instead of 645 + 875 us at M = 2.36 M rows (4.4 TB/s).
+// ------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ unsigned pwb_pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+namespace pwb {
+constexpr int E = 448, CIN = 64, BM = 128, NKC = E / 64;
+constexpr int RS = 160;                       // LDS row stride of the [128][64] bf16 tiles (128 B + 32 B shift)
+constexpr int WRS = E * 2 + 16;               // row stride of the resident W1^T [64][448]
+constexpr int SW_BYTES = CIN * WRS, SD_BYTES = BM * RS, SX_BYTES = BM * RS;
+constexpr int SABC_BYTES = 3 * E * 4;          // the affine coefficients live in LDS: read per chunk, not hoisted into 168 registers
+constexpr int LDS_BYTES = SW_BYTES + 2 * SD_BYTES + 2 * SX_BYTES + SABC_BYTES;
+
+}  // namespace pwb
+__global__ __launch_bounds__(512, 2) void pw_bwd_fused_kernel(const bf16_t* __restrict__ dh1, const bf16_t* __restrict__ y1,
+                                                       const bf16_t* __restrict__ a0, const bf16_t* __restrict__ w1t,
+                                                       const float* __restrict__ abc, bf16_t* __restrict__ da0,
+                                                       float* __restrict__ dW, int M) {
+    using namespace pwb;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pwb_smem[];
+    unsigned char* const smem = pwb_smem;
+    unsigned char* sW = smem;
+    unsigned char* sD = smem + SW_BYTES;
+    unsigned char* sX = sD + 2 * SD_BYTES;
+    float* sABC = reinterpret_cast<float*>(sX + 2 * SX_BYTES);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int wm = wave & 3, wn = wave >> 2;
+    for (int c = tid; c < 3 * E; c += 512) sABC[c] = abc[c];
+    // resident W1^T: [n][k], 16-byte chunks
+    for (int c = tid; c < CIN * (E / 8); c += 512) {
+        const int n = c / (E / 8), kc8 = c % (E / 8);
+        *reinterpret_cast<uint4*>(sW + n * WRS + kc8 * 16) = *reinterpret_cast<const uint4*>(w1t + (size_t)n * E + kc8 * 8);
+    }
+    __syncthreads();
+    f32x4_t acc_dw[NKC][2];
+#pragma unroll
+    for (int k = 0; k < NKC; ++k) { acc_dw[k][0] = f32x4_t{0, 0, 0, 0}; acc_dw[k][1] = f32x4_t{0, 0, 0, 0}; }
+    const int ntiles = M / BM;
+    const int ch = tid & 7;                   // this thread's 16-byte column chunk inside a 64-column chunk (fixed)
+    const int row_a = tid >> 3;               // rows row_a and row_a + 64
+    uint4 rd[2], ry[2], rx[2];
+    int tpar = 0, step = 0;                  // step: running chunk counter (LDS buffer parity continues across tiles)
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, tpar ^= 1) {
+        const size_t m0 = (size_t)tile * BM;
+        unsigned char* sXt = sX + tpar * SX_BYTES;
+        // a0 tile + first chunk of dh1 / y1
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const size_t m = m0 + row_a + 64 * u;
+            rx[u] = *reinterpret_cast<const uint4*>(a0 + m * CIN + ch * 8);
+            rd[u] = *reinterpret_cast<const uint4*>(dh1 + m * E + ch * 8);
+            ry[u] = *reinterpret_cast<const uint4*>(y1 + m * E + ch * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<uint4*>(sXt + (row_a + 64 * u) * RS + ch * 16) = rx[u];
+        f32x4_t acc_da[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { acc_da[i][0] = f32x4_t{0, 0, 0, 0}; acc_da[i][1] = f32x4_t{0, 0, 0, 0}; }
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            unsigned char* sDk = sD + ((step + kc) & 1) * SD_BYTES;
+            // BatchNorm-backward affine of this chunk -> LDS (bf16, as the library's loader rounds it)
+            {
+                float A1[8], A2[8], A3[8];
+                const int e0 = kc * 64 + ch * 8;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { A1[q] = sABC[e0 + q]; A2[q] = sABC[E + e0 + q]; A3[q] = sABC[2 * E + e0 + q]; }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const unsigned d4[4] = {rd[u].x, rd[u].y, rd[u].z, rd[u].w}, y4[4] = {ry[u].x, ry[u].y, ry[u].z, ry[u].w};
+                    unsigned o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float dl = __uint_as_float(d4[q] << 16), dhi = __uint_as_float(d4[q] & 0xffff0000u);
+                        const float yl = __uint_as_float(y4[q] << 16), yh = __uint_as_float(y4[q] & 0xffff0000u);
+                        o[q] = pwb_pack2(fmaf(A1[2 * q], dl, fmaf(A2[2 * q], yl, A3[2 * q])),
+                                     fmaf(A1[2 * q + 1], dhi, fmaf(A2[2 * q + 1], yh, A3[2 * q + 1])));
+                    }
+                    *reinterpret_cast<uint4*>(sDk + (row_a + 64 * u) * RS + ch * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            }
+            __syncthreads();
+            if (kc + 1 < NKC) {               // next chunk in flight under the MFMAs
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const size_t m = m0 + row_a + 64 * u;
+                    rd[u] = *reinterpret_cast<const uint4*>(dh1 + m * E + (kc + 1) * 64 + ch * 8);
+                    ry[u] = *reinterpret_cast<const uint4*>(y1 + m * E + (kc + 1) * 64 + ch * 8);
+                }
+            }
+            // ---- data gradient: acc_da[m][n] += sum_k dy1[m][k] W1t[n][k]   (swapped roles: lanes own 4 consecutive n)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bf16x8_t af[2], wf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8_t*>(sDk + (wm * 32 + i * 16 + lr) * RS + (kb * 4 + lg) * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    wf[j] = *reinterpret_cast<const bf16x8_t*>(sW + (wn * 32 + j * 16 + lr) * WRS + (kc * 64 + kb * 32 + lg * 8) * 2);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc_da[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc_da[i][j], 0, 0, 0);
+            }
+            // ---- weight gradient: acc_dw[kc][e][c] += sum_rows dy1[row][e] a0[row][c]   (transposed fragments)
+            {
+                const int q = lr >> 2, p = lr & 3;
+#pragma unroll
+                for (int kb = 0; kb < BM / 32; ++kb) {
+                    const int rb = kb * 32 + 8 * lg + q;
+                    bf16x8_t ef, cf[2];
+                    {
+                        const int colb = (wm * 16 + 4 * p) * 2;
+                        auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(sDk + rb * RS + colb));
+                        auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(sDk + (rb + 4) * RS + colb));
+                        ef = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int colb = (wn * 32 + j * 16 + 4 * p) * 2;
+                        auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(sXt + rb * RS + colb));
+                        auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(sXt + (rb + 4) * RS + colb));
+                        cf[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc_dw[kc][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, cf[j], acc_dw[kc][j], 0, 0, 0);
+                }
+            }
+        }
+        step += NKC;
+        // da0 tile: acc_da[i][j][r] = da0[m = wm*32 + i*16 + lr][n = wn*32 + j*16 + 4*lg + r]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const size_t m = m0 + wm * 32 + i * 16 + lr;
+                const int n = wn * 32 + j * 16 + 4 * lg;
+                uint2 v = make_uint2(pwb_pack2(acc_da[i][j][0], acc_da[i][j][1]), pwb_pack2(acc_da[i][j][2], acc_da[i][j][3]));
+                *reinterpret_cast<uint2*>(da0 + m * CIN + n) = v;
+            }
+    }
+    // acc_dw[kc][j][r] = dW[e = kc*64 + wm*16 + 4*lg + r][c = wn*32 + j*16 + lr]
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                atomicAdd(dW + (size_t)(kc * 64 + wm * 16 + 4 * lg + r) * CIN + wn * 32 + j * 16 + lr, acc_dw[kc][j][r]);
+}
+
+
+bool pw_bwd_fused_supported(int dtype, long long M, int E, int Cin) {
+    return dtype == DWN_BF16 && E == pwb::E && Cin == pwb::CIN && M > 0 && M % pwb::BM == 0 && M <= 0x7fffffffLL;
+}
+int launch_pw_bwd_fused(const void* dh1, const void* y1, const void* a0, const void* w1t, const float* abc, void* da0,
+                        float* dw, long long M, int E, int Cin, int dtype, hipStream_t s) {
+    if (!pw_bwd_fused_supported(dtype, M, E, Cin))
+        return dwn_set_error(-3, "pw_bwd_fused: built for bf16, Cin = 64, E = 448, M % 128 == 0 only");
+    {   // > 64 KB of dynamic LDS needs the opt-in; per device, so it is (cheaply) repeated on every call
+        hipError_t e = hipFuncSetAttribute((const void*)pw_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pwb::LDS_BYTES);
+        if (e != hipSuccess) return dwn_set_error((int)e, hipGetErrorString(e));
+    }
+    int grid = 256;
+    if (grid > (int)(M / pwb::BM)) grid = (int)(M / pwb::BM);
+    hipLaunchKernelGGL(pw_bwd_fused_kernel, dim3(grid), dim3(512), pwb::LDS_BYTES, s, (const bf16_t*)dh1, (const bf16_t*)y1,
+                       (const bf16_t*)a0, (const bf16_t*)w1t, abc, (bf16_t*)da0, dw, (int)M);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}

@@ -286,3 +286,50 @@ def test_gemm_nn_dh3_epilogue(L, dtype, B, S, N, K):
     assert float((s1 - want1).abs().max() / scale) < 1e-5
     g.gate3 = None
     assert L.lib.dwn_gemm_nn(C.byref(g), _dt(L, dtype), 0, stream()) < 0
+
+
+@pytest.mark.parametrize("M", [128, 128 * 37, 128 * 513])
+def test_pw_bwd_fused_matches_two_products(L, M):
+    """dwn_pw_bwd_fused (conv_pw backward of the 64-channel blocks in one pass over dh1 / y1): exact on small-integer data,
+    and within bf16 tolerance on random data, against dy1 = round(A1*dh1 + A2*y1 + A3); da0 = dy1 @ W1; dW += dy1^T @ a0."""
+    E, Cin = 448, 64
+    assert L.lib.dwn_pw_bwd_fused_supported(L.DWN_BF16, M, E, Cin) == 1
+    for integer in (True, False):
+        g = torch.Generator(device="cuda").manual_seed(M + integer)
+        if integer:
+            dh1 = torch.randint(-2, 3, (M, E), generator=g, device=dev()).float()
+            y1 = torch.randint(-1, 2, (M, E), generator=g, device=dev()).float()
+            a0 = torch.randint(-1, 2, (M, Cin), generator=g, device=dev()).float()
+            w1 = torch.randint(-2, 3, (E, Cin), generator=g, device=dev()).float() * 0.25
+            abc = torch.stack([torch.arange(E, device=dev()) % 2 + 1.0, torch.arange(E, device=dev()) % 3 - 1.0,
+                               torch.arange(E, device=dev()) % 2 + 0.0]).float().contiguous()
+        else:
+            dh1 = torch.randn(M, E, generator=g, device=dev())
+            y1 = torch.randn(M, E, generator=g, device=dev())
+            a0 = torch.randn(M, Cin, generator=g, device=dev())
+            w1 = torch.randn(E, Cin, generator=g, device=dev()) * 0.1
+            abc = torch.randn(3, E, generator=g, device=dev()).contiguous()
+        bf = torch.bfloat16
+        dh1b, y1b, a0b, w1t = dh1.to(bf), y1.to(bf), a0.to(bf), w1.t().contiguous().to(bf)
+        da0 = torch.full((M, Cin), float("nan"), device=dev()).to(bf)
+        dw = torch.full((E, Cin), 0.5, device=dev())                      # accumulated into, not overwritten
+        a = L.PwBwdArgs()
+        a.dh1, a.y1, a.a0, a.w1t, a.abc = dh1b.data_ptr(), y1b.data_ptr(), a0b.data_ptr(), w1t.data_ptr(), abc.data_ptr()
+        a.da0, a.dw, a.M, a.E, a.Cin = da0.data_ptr(), dw.data_ptr(), M, E, Cin
+        L.check(L.lib.dwn_pw_bwd_fused(C.byref(a), L.DWN_BF16, 0, stream()), "pw_bwd_fused")
+        torch.cuda.synchronize()
+        dy = (abc[0] * dh1b.float() + (abc[1] * y1b.float() + abc[2])).to(bf)      # fma(A1, dh, fma(A2, y, A3)) rounded
+        want_da = dy.double() @ w1t.double().t()
+        want_dw = dy.double().t() @ a0b.double() + 0.5
+        if integer:
+            assert torch.equal(da0.double(), want_da.to(bf).double())
+            assert torch.equal(dw.double(), want_dw)
+        else:
+            assert rel(da0, want_da) < 6e-3
+            assert rel(dw, want_dw) < 2e-4
+    assert L.lib.dwn_pw_bwd_fused_supported(L.DWN_BF16, M + 64, E, Cin) == 0
+    assert L.lib.dwn_pw_bwd_fused_supported(L.DWN_F32, M, E, Cin) == 0
+    a.E = 896
+    assert L.lib.dwn_pw_bwd_fused(C.byref(a), L.DWN_BF16, 0, stream()) == -3
+    a.E, a.dw = E, None
+    assert L.lib.dwn_pw_bwd_fused(C.byref(a), L.DWN_BF16, 0, stream()) < 0
