@@ -43,9 +43,9 @@ def report(name, ms, nbytes):
     print(f"{name:58s} {ms*1e3:9.1f} us  {nbytes/ms/1e6:8.1f} GB/s", flush=True)
 
 
-def gemm_nn(M, N, K, kind="plain", stats=False, S=None, T=32, H=36, W=64):
+def gemm_nn(M, N, K, kind="plain", stats=False, S=None, T=32, H=36, W=64, bsample=0):
     a = torch.randn(M, K, device=dev).to(BF)
-    b = (torch.randn(N, K, device=dev) / K ** 0.5).to(BF)
+    b = (torch.randn((M // bsample if bsample else 1) * N, K, device=dev) / K ** 0.5).to(BF)
     c = torch.empty(M, N, dtype=BF, device=dev)
     st = torch.zeros(32 * 2 * N, dtype=torch.float64, device=dev)
     keep = []
@@ -73,9 +73,11 @@ def gemm_nn(M, N, K, kind="plain", stats=False, S=None, T=32, H=36, W=64):
     g.a = d; g.a_kind = k; g.b = b.data_ptr(); g.ldb = K; g.c = c.data_ptr(); g.ldc = N
     g.M, g.N, g.K, g.groups = M, N, K, 1
     g.stats = st.data_ptr() if stats else None; g.stat_nchan = N; g.epi = L.EPI_STORE
+    if bsample:
+        g.b_sample_stride = N * K; g.b_rows_per_sample = bsample
     ms = timeit(lambda: L.check(L.lib.dwn_gemm_nn(C.byref(g), L.DWN_BF16, 0, stream()), "nn"))
     nb = (M * K * (2 if kind == "affine2" else 1) + M * N) * 2
-    report(f"gemm_nn M={M} N={N} K={K} {kind} stats={int(stats)}", ms, nb)
+    report(f"gemm_nn M={M} N={N} K={K} {kind} stats={int(stats)} bsample={bsample}", ms, nb)
 
 
 def gemm_tn(M, R, Cc, pk="plain", qk="plain", rows_per_sample=0):
@@ -216,6 +218,11 @@ if __name__ == "__main__":
         dwt_bwd(32, 32, 5 * 8, 1792)
     if "dwtb1" in which:
         dwt_bwd(32, 32, 18 * 32, 448)
+    if "nnps" in which:
+        for (M, N, K, S) in ((589824, 64, 448, 18432), (589824, 128, 448, 18432), (147456, 128, 896, 4608),
+                             (147456, 256, 896, 4608), (40960, 256, 1792, 1280)):
+            gemm_nn(M, N, K, "plain", True)
+            gemm_nn(M, N, K, "plain", True, bsample=S)
     if "tnps" in which:
         gemm_tn(589824, 64, 448, "plain")
         gemm_tn(589824, 64, 448, "plain", rows_per_sample=18432)
