@@ -279,14 +279,14 @@ def main():
             # tools/pmc_traffic.py; expressed like `achieved` (bytes per launch / this run's launch duration)
             default_shape = (args.batch, args.frames, args.height, args.width, expansion, args.dtype, args.mice) == \
                             (32, 32, 36, 64, 7, "bf16", 1)
-            tpath = ROOT / "profiles" / "r1c_pmc_traffic.json"
+            tpath = ROOT / "profiles" / "r1f_pmc_traffic.json"
             if default_shape and tpath.exists():
                 try:
                     tf = json.loads(tpath.read_text())["families"].get(fam)
                     if tf:
                         roof["traffic"] = round(tf["traffic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, 1)
                         roof["traffic_bytes_per_launch"] = int(tf["traffic_bytes_per_launch"])
-                        roof["traffic_source"] = "profiles/r1c_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
+                        roof["traffic_source"] = "profiles/r1f_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
                 except (ValueError, KeyError):
                     pass
         out = {
