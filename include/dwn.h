@@ -341,6 +341,30 @@ typedef struct dwn_pw_bwd_args {
 int dwn_pw_bwd_fused_supported(int dtype, long long M, int E, int Cin);
 int dwn_pw_bwd_fused(const dwn_pw_bwd_args* a, int dtype, int device, void* stream);
 
+/* ---- spat_covn_dw WITHOUT a materialised conv_pw output (dwiseneuro.py:90-102; bf16 storage, 3x3, stride 1 or 2,
+ * Cin in {64, 128}, E % 64 == 0).  y1 = a0 . W1^T is the widest tensor at input resolution although it is a Cin-deep
+ * product of a tensor E/Cin times narrower: the kernel rebuilds each y1 tile from the a0 tile with MFMAs while it
+ * stages the stencil's LDS tile, so the forward reads a0 (once per tile, all E/64 channel slices are produced from
+ * the LDS-resident copy) and writes y2.  `blob` holds, per 64-channel slice, the LDS images the kernel copies by
+ * LDS-DMA: the W1 rows (bf16, bank-swizzled), the pair-packed bf16 stencil weights and the BatchNorm-1 scale / shift;
+ * dwn_dw_spatial_rc_prep builds it (after the BatchNorm-1 coefficients are final).
+ * round_y1 != 0 rounds the rebuilt y1 to bf16 before the BatchNorm (bit-identical to reading a stored bf16 y1). */
+typedef struct dwn_dw_spatial_rc_fwd_args {
+    const void* a0; long long a0_ld;   /* block input incl. its positional encoding [planes*Hin*Win][Cin] */
+    const void* blob;                  /* dwn_dw_spatial_rc_blob_bytes(E, Cin) bytes */
+    void* out;                         /* y2 [planes*Hout*Wout][E] */
+    int planes, Hin, Win, Hout, Wout, Cin, E, stride;
+    double* stats;                     /* double[DWN_NREP][2][E] sum / sum of squares of y2, or null */
+    int rows_band;                     /* output rows per tile; <= 0: chosen by the library */
+    int round_y1;
+} dwn_dw_spatial_rc_fwd_args;
+size_t dwn_dw_spatial_rc_blob_bytes(int E, int Cin);
+/* w_pw [E][Cin] fp32 (conv_pw.0.weight), w_dws [9][E] fp32 tap-major, bn1_coef [>=2][E] scale, shift */
+int dwn_dw_spatial_rc_prep(const float* w_pw, const float* w_dws, const float* bn1_coef, int E, int Cin, void* blob,
+                           int device, void* stream);
+int dwn_dw_spatial_rc_supported(int dtype, int Cin, int E, int ks, int stride, int Hin, int Win);
+int dwn_dw_spatial_fwd_rc(const dwn_dw_spatial_rc_fwd_args* a, int device, void* stream);
+
 /* StackInputsProcessor + CutMix on the inputs (inputs.py:15-36, mixers.py:52-63) for a whole batch:
  * x [B][5][T][H][W] fp32 = channel 0 the video centre-padded with pad_fill, channels 1-2 behavior, 3-4 pupil_center
  * broadcast over the frame.  `descs` is a DEVICE array of B entries; every video has the same H0 x W0. */

@@ -151,6 +151,12 @@ class PwBwdArgs(C.Structure):
                 ("M", c_ll), ("E", c_i), ("Cin", c_i)]
 
 
+class DwSpatialRcFwdArgs(C.Structure):
+    _fields_ = [("a0", c_p), ("a0_ld", c_ll), ("blob", c_p), ("out", c_p), ("planes", c_i), ("Hin", c_i),
+                ("Win", c_i), ("Hout", c_i), ("Wout", c_i), ("Cin", c_i), ("E", c_i), ("stride", c_i),
+                ("stats", c_p), ("rows_band", c_i), ("round_y1", c_i)]
+
+
 VID_U8, VID_F32 = 0, 1
 
 _STRUCTS = {
@@ -160,6 +166,7 @@ _STRUCTS = {
     "dwn_bn": BN, "dwn_stem_args": StemArgs, "dwn_block_args": BlockArgs, "dwn_pool_args": PoolArgs,
     "dwn_cortex_args": CortexArgs, "dwn_readout_args": ReadoutArgs, "dwn_tensor_entry": TensorEntry,
     "dwn_clip_src": ClipSrc, "dwn_clip_desc": ClipDesc, "dwn_pw_bwd_args": PwBwdArgs,
+    "dwn_dw_spatial_rc_fwd_args": DwSpatialRcFwdArgs,
 }
 
 # every symbol include/dwn.h declares: (restype, argtypes)
@@ -200,6 +207,10 @@ SYMBOLS = {
     "dwn_ema_lerp_multi": (c_i, [c_p, c_i, c_i, c_d, c_i, c_p]),
     "dwn_pw_bwd_fused_supported": (c_i, [c_i, c_ll, c_i, c_i]),
     "dwn_pw_bwd_fused": (c_i, [_P(PwBwdArgs), c_i, c_i, c_p]),
+    "dwn_dw_spatial_rc_blob_bytes": (c_sz, [c_i, c_i]),
+    "dwn_dw_spatial_rc_prep": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_p]),
+    "dwn_dw_spatial_rc_supported": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
+    "dwn_dw_spatial_fwd_rc": (c_i, [_P(DwSpatialRcFwdArgs), c_i, c_p]),
     "dwn_assemble_inputs": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_i, c_p]),
     "dwn_assemble_targets": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_p]),
 }

@@ -8,6 +8,14 @@
 
 static thread_local char g_err[512] = "";
 
+// y1-recomputing spatial forward (dwn_dwrc.hip): used by the eval-mode block forward, where neither the BatchNorm-1
+// statistics nor a saved y1 are needed, so conv_pw never runs as a pass of its own
+extern "C" size_t dwn_dw_spatial_rc_blob_bytes(int E, int Cin);
+extern "C" int dwn_dw_spatial_rc_supported(int dtype, int Cin, int E, int ks, int stride, int Hin, int Win);
+extern "C" int dwn_dw_spatial_rc_prep(const float* w_pw, const float* w_dws, const float* bn1_coef, int E, int Cin, void* blob,
+                                      int device, void* stream);
+extern "C" int dwn_dw_spatial_fwd_rc(const dwn_dw_spatial_rc_fwd_args* a, int device, void* stream);
+
 int dwn_set_error(int code, const char* msg) {
     snprintf(g_err, sizeof(g_err), "dwn error %d: %s", code, msg ? msg : "");
     return code;
@@ -133,6 +141,7 @@ struct BlockWs {
     float *dgp, *dhp, *dps;
     void* bp; float* r3; float* gacc;                      // conv_pw data-gradient folding (see dwn_elementwise.hip)
     void* wgated;                                          // [B][Cout][Cmid] W2 . diag(gate_b) (forward only)
+    void* rcblob;                                          // eval forward: slice images of the y1-recomputing stencil
     float* pb;                                             // [B][Cout][Cmid] per-sample dy4^T z3 (backward, see pwl_bwd_per_sample)
     char* zero_beg; char* zero_end;
     size_t bytes;
@@ -154,6 +163,10 @@ static bool pwl_bwd_per_sample(const dwn_block_args& a) {
     const double pass = (double)a.B * a.T * a.Hout * a.Wout * a.Cmid * tsize(a.dtype);
     return pb <= pass;
 }
+// eval-mode forward without conv_pw as its own pass (DWN_RC_OFF=1 disables it)
+static bool block_fwd_rc(const dwn_block_args& a) {
+    return !a.training && dwn_dw_spatial_rc_supported(a.dtype, a.Cin, a.Cmid, a.ks, a.stride, a.Hin, a.Win) != 0;
+}
 // floats of the conv_pw data-gradient folding scratch: G accumulator [Cin][Cin] and r3 [Cin]
 static size_t pw_fold_floats(int Cin) { return (size_t)Cin * Cin + Cin; }
 BlockWs carve_block(const dwn_block_args& a, int backward, void* base, size_t cap) {
@@ -165,6 +178,7 @@ BlockWs carve_block(const dwn_block_args& a, int backward, void* base, size_t ca
     w.wdws = c.take<float>((size_t)a.ks * a.ks * a.Cmid);
     w.wdwt = c.take<float>((size_t)a.kt * a.Cmid);
     if (!backward && pwl_gated_weights(a)) w.wgated = c.take<char>((size_t)a.B * a.Cout * a.Cmid * ts);
+    if (!backward && block_fwd_rc(a)) w.rcblob = c.take<char>(dwn_dw_spatial_rc_blob_bytes(a.Cmid, a.Cin));
     c.take<char>(0);
     size_t z0 = (c.off + 255) & ~(size_t)255;
     w.st1 = c.take<double>(nstat(a.Cmid));
@@ -220,7 +234,7 @@ int dwn_sizeof(const char* name) {
     SZ(dwn_load_desc); SZ(dwn_gemm_nn_args); SZ(dwn_gemm_tn_args); SZ(dwn_dw_spatial_fwd_args);
     SZ(dwn_dw_spatial_bwd_args); SZ(dwn_dw_temporal_fwd_args); SZ(dwn_dw_temporal_bwd_args); SZ(dwn_bn);
     SZ(dwn_stem_args); SZ(dwn_block_args); SZ(dwn_pool_args); SZ(dwn_cortex_args); SZ(dwn_readout_args);
-    SZ(dwn_tensor_entry); SZ(dwn_clip_src); SZ(dwn_clip_desc); SZ(dwn_pw_bwd_args);
+    SZ(dwn_tensor_entry); SZ(dwn_clip_src); SZ(dwn_clip_desc); SZ(dwn_pw_bwd_args); SZ(dwn_dw_spatial_rc_fwd_args);
 #undef SZ
     return -1;
 }
@@ -367,6 +381,16 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     }
     // conv_pw (dwiseneuro.py:90-93): y1 = a0 @ W1^T, Σ/Σ² for bn1
     LoadDesc xin = ld_plain(a0, a.Cin);
+    if (block_fwd_rc(a)) {
+        // eval: BatchNorm-1 needs no batch statistics and nobody reads y1 again, so the stencil kernel rebuilds its y1
+        // tiles from a0 (MFMA) and conv_pw disappears as a pass (a.y1 is not written)
+        TRY(dwn_dw_spatial_rc_prep(a.w_pw, w.wdws, a.bn1.coef, a.Cmid, a.Cin, w.rcblob, device, stream));
+        dwn_dw_spatial_rc_fwd_args r; memset(&r, 0, sizeof(r));
+        r.a0 = a0; r.a0_ld = a.Cin; r.blob = w.rcblob; r.out = a.y2; r.planes = a.B * a.T; r.Hin = a.Hin; r.Win = a.Win;
+        r.Hout = a.Hout; r.Wout = a.Wout; r.Cin = a.Cin; r.E = a.Cmid; r.stride = a.stride; r.stats = nullptr;
+        r.rows_band = 0; r.round_y1 = 1;
+        PROF(DWN_FAM_DWS_FWD, dwn_dw_spatial_fwd_rc(&r, device, stream));
+    } else {
     {
         GemmNN g = nn_base(xin, LD_PLAIN, w.wpw, a.Cin, a.y1, a.Cmid, (int)Min, a.Cmid, a.Cin, 1);
         g.stats = tr ? w.st1 : nullptr; g.stat_nchan = a.Cmid;
@@ -380,6 +404,7 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
         d.w = w.wdws; d.out = a.y2; d.planes = a.B * a.T; d.Hin = a.Hin; d.Win = a.Win; d.Hout = a.Hout;
         d.Wout = a.Wout; d.C = a.Cmid; d.stride = a.stride; d.ks = a.ks; d.stats = tr ? w.st2 : nullptr;
         PROF(DWN_FAM_DWS_FWD, launch_dw_spatial_fwd(d, dt, s));
+    }
     }
     if (tr) TRY(bn_finalize(w.st2, a.Cmid, (double)Mout, a.bn2, a.Cmid, tr, a.momentum, a.eps, s));
     // temp_covn_dw (:105-111)

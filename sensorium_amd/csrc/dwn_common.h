@@ -24,6 +24,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(bf16_t, b);
 }
+// two floats -> one dword of two bf16 (lo in bits 0-15): ONE v_cvt_pk_bf16_f32 (RNE, NaN-preserving).  Packing two
+// separately converted halves with shift/or costs four VALU instructions instead.
+typedef float dwn_f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 dwn_bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(dwn_f32x2_t{lo, hi}, dwn_bf16x2_t));
+}
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
@@ -51,10 +58,10 @@ template <> __device__ __forceinline__ uint4 pack16<float>(const float* v) {
 }
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* v) {
     uint4 r;
-    r.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-    r.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-    r.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-    r.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    r.x = pk_bf16(v[0], v[1]);
+    r.y = pk_bf16(v[2], v[3]);
+    r.z = pk_bf16(v[4], v[5]);
+    r.w = pk_bf16(v[6], v[7]);
     return r;
 }
 template <typename T> __device__ __forceinline__ void ld_vec(const T* p, float* o) {
@@ -144,8 +151,8 @@ template <> struct V4<bf16_t> {
     }
     static __device__ __forceinline__ raw_t pack(const float* v) {
         uint2 r;
-        r.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        r.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        r.x = pk_bf16(v[0], v[1]);
+        r.y = pk_bf16(v[2], v[3]);
         return r;
     }
     static __device__ __forceinline__ raw_t zero() { return make_uint2(0, 0); }

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NT, 4) void dw_spatial_fwd_kernel(const DwSpatialFw
                             const f2_t y = f2_t{__uint_as_float(rw[i] << 16), __uint_as_float(rw[i] & 0xffff0000u)};
                             const f2_t h = y * s8[i] + t8[i];
                             const f2_t z = h * f2_t{sigmoidf_(h.x), sigmoidf_(h.y)};
-                            o[i] = (uint32_t)f2bf(z.x) | ((uint32_t)f2bf(z.y) << 16);
+                            o[i] = pk_bf16(z.x, z.y);
                         }
                         tile16[f * SV + scv] = okv[u] ? make_uint4(o[0], o[1], o[2], o[3]) : make_uint4(0, 0, 0, 0);
                     }
@@ -261,7 +261,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float c) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
 }
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return pk_bf16(lo, hi); }
 
 template <int ST, int NT>
 __global__ __launch_bounds__(NT, 4) void dw_spatial_fwd_pair_kernel(const DwSpatialFwd a) {

@@ -408,8 +408,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                                 }
                                 if constexpr (TT<T>::IS_BF16) {
                                     uint2 v;
-                                    v.x = (uint32_t)f2bf(acc[i][j][0]) | ((uint32_t)f2bf(acc[i][j][1]) << 16);
-                                    v.y = (uint32_t)f2bf(acc[i][j][2]) | ((uint32_t)f2bf(acc[i][j][3]) << 16);
+                                    v.x = pk_bf16(acc[i][j][0], acc[i][j][1]);
+                                    v.y = pk_bf16(acc[i][j][2], acc[i][j][3]);
                                     *reinterpret_cast<uint2*>(dst) = v;
                                 } else {
                                     *reinterpret_cast<float4*>(dst) =
@@ -952,7 +952,7 @@ int launch_gemm_tn(const GemmTN& g_in, int dtype, hipStream_t s) {
 // 512 threads, one workgroup per CU (143 KB of LDS), persistent over the tiles.  Replaces gemm_nn (K-concat folding) +
 // gemm_tn (affine2), which each streamed dh1: 1083 us instead of 645 + 875 us at M = 2.36 M rows (4.4 TB/s).
 // ------------------------------------------------------------------------------------------------
-static __device__ __forceinline__ unsigned pwb_pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+static __device__ __forceinline__ unsigned pwb_pack2(float a, float b) { return pk_bf16(a, b); }
 namespace pwb {
 constexpr int E = 448, CIN = 64, BM = 128, NKC = E / 64;
 constexpr int RS = 160;                       // LDS row stride of the [128][64] bf16 tiles (128 B + 32 B shift)
