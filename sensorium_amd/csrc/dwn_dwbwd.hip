@@ -1,0 +1,632 @@
+// spat_covn_dw backward (reference: src/models/dwiseneuro.py:96-102), bf16 storage, 3x3 — "row walk" kernels.
+//
+//   dh1 = (dwS^T dL/dy2) * SiLU'(BN1(y1)),  dW += z1 (x) dL/dy2,  Σdh1, Σdh1·ŷ1      with dL/dy2 = A1*dh2 + A2*y2 + A3
+//
+// Same arithmetic as dw_spatial_bwd_pair_kernel (x-pair-packed gradient tile in LDS, v_dot2c_f32_bf16 taps) but organised
+// so that almost no integer index math is left in the loops — on this part the stencils are VALU-issue-bound (SQ counters:
+// one VALU instruction per 6-8 cycles and SIMD at 3.5 TB/s), and 40 % of the pair kernel's instructions were flat-index
+// decodes (exact division, per-pixel bounds, masks):
+//   * a thread owns ONE pixel-pair column of its plane and walks down the rows: addresses advance by constants, the column's
+//     halo mask is a per-thread constant, row validity is a scalar;
+//   * the three gradient-tile rows a centre row needs live in a register window that slides by one row per step (2 LDS
+//     reads per step instead of 6);
+//   * planes narrower than 32 pixels put several planes side by side in one tile (16 / (W/2) lane groups), so the 9x16 and
+//     5x8 planes of the deep blocks fill every lane and one barrier serves a whole multi-plane tile;
+//   * the weight-gradient partials are folded across a wave's four pixel lanes with v_permlane16/32_swap before the
+//     (slow) LDS float atomics.
+// dh1 is bit-identical to the pair kernel's (same dot2 order); dW and the BatchNorm sums differ in summation order only.
+#include "dwn_internal.h"
+#include <stdlib.h>
+#include <type_traits>
+
+#ifndef WK_MINW
+#define WK_MINW 3          // waves per SIMD the walk kernels are compiled for (three 256-thread workgroups per CU)
+#endif
+#ifndef WK_MINW2
+#define WK_MINW2 3         // ... the stride-2 kernel (a thread owns four pixels: more registers)
+#endif
+
+extern __shared__ __attribute__((aligned(16))) unsigned char wk_smem[];
+
+typedef float wk_f2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(2))) __bf16 wk_bf16x2_t;
+typedef unsigned wk_u32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float wk_dot2(unsigned a, unsigned b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wk_bf16x2_t, a), __builtin_bit_cast(wk_bf16x2_t, b), c, false);
+}
+__device__ __forceinline__ void wk_unpack(const uint2& r, wk_f2_t& lo, wk_f2_t& hi) {
+    lo = wk_f2_t{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)};
+    hi = wk_f2_t{__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+}
+__device__ __forceinline__ uint2 wk_ld8(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+
+// fold n (even) per-thread partial sums over the 4 lanes {l, l+16, l+32, l+48} of a wave: afterwards lane row r = lane/16
+// holds the totals of value indices j*4 + sel(r) ... see the caller; two transposing swaps halve the value count each.
+// in: v[4k] ; out: o[k] where o[j] (j < k) is the total of v[4*?]: value index = j + k*((r&1)*2 + (r>>1))  (documented below)
+template <int K>
+__device__ __forceinline__ void wk_fold4(const float* v, float* o, int /*lane*/) {
+    // v has 4K values; step 1 pairs (v[i], v[i + 2K]), step 2 pairs (c[i], c[i + K])
+    float c[2 * K];
+#pragma unroll
+    for (int i = 0; i < 2 * K; ++i) {
+        const wk_u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 2 * K]), false, false);
+        c[i] = __uint_as_float(r.x) + __uint_as_float(r.y);      // rows 0/2: sums of v[i]; rows 1/3: sums of v[i + 2K]
+    }
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const wk_u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[i]), __float_as_uint(c[i + K]), false, false);
+        o[i] = __uint_as_float(r.x) + __uint_as_float(r.y);      // rows 0,1: totals of c[i]; rows 2,3: totals of c[i + K]
+    }
+    // lane row r holds o[i] = total of value index i + K*(r>>1) + 2K*(r&1)
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gradient tile staging shared by both strides.  The tile covers output rows ho_lo .. ho_lo + rows_q - 1 of NG planes,
+// x-pair-packed: tile[plane][row][k][c] = (g[wo = 2k-1], g[wo = 2k]) with g = A1*dh2 + A2*y2 + A3 rounded to bf16 and zero
+// outside the plane.  A thread stages its own pair column k = jj for every row (constant halo mask, addresses advance by
+// one output row), then the extra last column k = LPW = Wout/2 is spread over the rows.
+// ------------------------------------------------------------------------------------------------
+template <int LPW>
+__device__ __forceinline__ void wk_stage(const DwSpatialBwd& a, unsigned* tile, const int grp, const int jj, const int cv,
+                                         const int chs, const int psafe, const bool pvalid, const int ho_lo, const int rows_q,
+                                         const int rows_qmax) {
+    typedef bf16_t T;
+    constexpr int CS = 64, Wqp = LPW + 1;
+    const int Hout = a.Hout, Wout = a.Wout;
+    const int rowdw = Wqp * CS;
+    unsigned* tcol = tile + (grp * rows_qmax * Wqp + jj) * CS + cv * 4;
+    const unsigned cmask = (jj > 0 ? 0x0000ffffu : 0u) | 0xffff0000u;          // pair jj = (wo = 2jj-1, wo = 2jj)
+    const unsigned dyrow = (unsigned)Wout * (unsigned)a.dy.ld;                  // elements per gradient row
+    float a1[4], a2[4], a3[4];
+    ldc4(a.dy.v1 + chs, a1); ldc4(a.dy.v2 + chs, a2); ldc4(a.dy.v3 + chs, a3);
+    const wk_f2_t a1v[2] = {wk_f2_t{a1[0], a1[1]}, wk_f2_t{a1[2], a1[3]}}, a2v[2] = {wk_f2_t{a2[0], a2[1]}, wk_f2_t{a2[2], a2[3]}};
+    const wk_f2_t a3v[2] = {wk_f2_t{a3[0], a3[1]}, wk_f2_t{a3[2], a3[3]}};
+    const i64 pbase = (i64)psafe * Hout * Wout * a.dy.ld + chs;
+    const T* dp0 = reinterpret_cast<const T*>(a.dy.p) + pbase;
+    const T* dq0 = reinterpret_cast<const T*>(a.dy.q) + pbase;
+    auto affine_pack = [&](const uint2& plo, const uint2& qlo, const uint2& phi, const uint2& qhi) {
+        wk_f2_t p0, p1, q0, q1, gl0, gl1, gh0, gh1;
+        wk_unpack(plo, p0, p1); wk_unpack(qlo, q0, q1);
+        gl0 = a1v[0] * p0 + (a2v[0] * q0 + a3v[0]); gl1 = a1v[1] * p1 + (a2v[1] * q1 + a3v[1]);
+        wk_unpack(phi, p0, p1); wk_unpack(qhi, q0, q1);
+        gh0 = a1v[0] * p0 + (a2v[0] * q0 + a3v[0]); gh1 = a1v[1] * p1 + (a2v[1] * q1 + a3v[1]);
+        return make_uint4(pk_bf16(gl0.x, gh0.x), pk_bf16(gl0.y, gh0.y), pk_bf16(gl1.x, gh1.x), pk_bf16(gl1.y, gh1.y));
+    };
+    // own column: pixels (ho, 2jj-1) and (ho, 2jj) for every staged row, 4 rows of loads in flight
+    constexpr int NB = 4;
+    const unsigned colhi = (unsigned)(2 * jj) * (unsigned)a.dy.ld;
+    const unsigned lodelta = jj > 0 ? (unsigned)a.dy.ld : 0u;          // jj == 0: the low pixel is the halo (masked)
+    for (int r0 = 0; r0 < rows_q; r0 += NB) {
+        uint2 rp[NB][2], rq[NB][2];
+        bool ok[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int ho = ho_lo + r0 + u;
+            ok[u] = pvalid && r0 + u < rows_q && (unsigned)ho < (unsigned)Hout;
+            const unsigned off = ok[u] ? (unsigned)ho * dyrow + colhi : lodelta;
+            rp[u][1] = wk_ld8(dp0 + off); rq[u][1] = wk_ld8(dq0 + off);
+            rp[u][0] = wk_ld8(dp0 + off - lodelta); rq[u][0] = wk_ld8(dq0 + off - lodelta);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            if (r0 + u < rows_q) {
+                uint4 o = affine_pack(rp[u][0], rq[u][0], rp[u][1], rq[u][1]);
+                const unsigned m = ok[u] ? cmask : 0u;
+                o.x &= m; o.y &= m; o.z &= m; o.w &= m;
+                *reinterpret_cast<uint4*>(tcol + (r0 + u) * rowdw) = o;
+            }
+        }
+    }
+    // last pair column (wo = Wout-1, halo): row r = jj, jj + LPW, ... of this plane
+    const unsigned collast = (unsigned)(Wout - 1) * (unsigned)a.dy.ld;
+    for (int r = jj; r < rows_q; r += LPW) {
+        const int ho = ho_lo + r;
+        const bool okr = pvalid && (unsigned)ho < (unsigned)Hout;
+        const unsigned off = okr ? (unsigned)ho * dyrow + collast : 0u;
+        const uint2 p = wk_ld8(dp0 + off), q = wk_ld8(dq0 + off);
+        uint4 o = affine_pack(p, q, p, q);
+        const unsigned m = okr ? 0x0000ffffu : 0u;
+        o.x &= m; o.y &= m; o.z &= m; o.w &= m;
+        *reinterpret_cast<uint4*>(tile + ((grp * rows_qmax + r) * Wqp + LPW) * CS + cv * 4) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stride 1.  LPW = pixel pairs per plane row (Win == 2*LPW in {32, 16, 8}); NG = 16/LPW planes side by side in one tile.
+// ------------------------------------------------------------------------------------------------
+template <int LPW>
+__global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1_kernel(const DwSpatialBwd a, const int R, const int rows_qmax) {
+    typedef bf16_t T;
+    constexpr int NT = 256, CS = 64, NG = 16 / LPW, Wqp = LPW + 1;
+    __shared__ float lstat[2 * CS];
+    __shared__ __attribute__((aligned(16))) unsigned lwp[3 * 4 * CS];        // packed weights [dy][combo][channel]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int cv = tid & 15, pl = tid >> 4;
+    const int grp = pl / LPW, jj = pl % LPW;
+    const int c0 = blockIdx.y * CS;
+    const int chan = c0 + cv * 4;
+    const bool chan_ok = chan < a.C;
+    const int chs = chan_ok ? chan : 0;
+    if (tid < 2 * CS) lstat[tid] = 0.f;
+    for (int i = tid; i < 3 * CS; i += NT) {
+        const int dy = i / CS, cc = i % CS, c = c0 + cc;
+        float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+        if (c < a.C) { w0 = a.w[(i64)(dy * 3 + 0) * a.C + c]; w1 = a.w[(i64)(dy * 3 + 1) * a.C + c]; w2 = a.w[(i64)(dy * 3 + 2) * a.C + c]; }
+        lwp[(dy * 4 + 0) * CS + cc] = pk_bf16(w2, w1);
+        lwp[(dy * 4 + 1) * CS + cc] = pk_bf16(w0, 0.f);
+        lwp[(dy * 4 + 2) * CS + cc] = pk_bf16(0.f, w2);
+        lwp[(dy * 4 + 3) * CS + cc] = pk_bf16(w1, w0);
+    }
+    __syncthreads();
+
+    float dwp[9][4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { dwp[k][0] = dwp[k][1] = dwp[k][2] = dwp[k][3] = 0.f; }
+    float bs[4], bt[4];
+    ldc4(a.y1.v1 + chs, bs); ldc4(a.y1.v2 + chs, bt);
+    const wk_f2_t bs2[2] = {wk_f2_t{bs[0], bs[1]}, wk_f2_t{bs[2], bs[3]}}, bt2[2] = {wk_f2_t{bt[0], bt[1]}, wk_f2_t{bt[2], bt[3]}};
+    // the second BatchNorm-backward sum is accumulated as sum(dh1 * y1) and centred once at the end:
+    // sum(dh1 * yhat) = invstd * (sum(dh1 * y1) - mean * sum(dh1))   (two coefficient vectors less in the loop)
+    wk_f2_t sp0[2] = {wk_f2_t{0.f, 0.f}, wk_f2_t{0.f, 0.f}}, sp1[2] = {wk_f2_t{0.f, 0.f}, wk_f2_t{0.f, 0.f}};
+
+    const int Win = a.Win, Hin = a.Hin;             // stride 1: Hout == Hin, Wout == Win == 2*LPW
+    const int nbands = (Hin + R - 1) / R;
+    const int ngroups = (a.planes + NG - 1) / NG;
+    const int ntiles = ngroups * nbands;
+    T* dhp = reinterpret_cast<T*>(a.dh1);
+    const T* y1p = reinterpret_cast<const T*>(a.y1.p);
+    unsigned* tile = reinterpret_cast<unsigned*>(wk_smem);        // [NG][rows_qmax][Wqp][64] dwords
+    const int rowdw = Wqp * CS;
+    unsigned* tcol = tile + (grp * rows_qmax * Wqp + jj) * CS + cv * 4;      // this thread's pair column, tile row 0
+    const unsigned y1row = (unsigned)Win * (unsigned)a.y1.ld, dhrow = (unsigned)Win * (unsigned)a.C;
+
+    for (int tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+        const int pg = tile_id / nbands, band = tile_id - pg * nbands;
+        const int plane = pg * NG + grp;
+        const bool pvalid = plane < a.planes && chan_ok;
+        const int psafe = plane < a.planes ? plane : 0;
+        const int hi0 = band * R;
+        const int nri = (Hin - hi0 < R) ? Hin - hi0 : R;
+        const int ho_lo = hi0 - 1;
+        const int rows_q = nri + 2;
+        // ---------------- stage dL/dy2 (BatchNorm-backward affine), x-pair-packed, zero halo
+        wk_stage<LPW>(a, tile, grp, jj, cv, chs, psafe, pvalid, ho_lo, rows_q, rows_qmax);
+        __syncthreads();
+        // ---------------- walk down the rows of this thread's pixel-pair column
+        if (pvalid) {
+            const i64 prow = (i64)plane * Hin * Win;
+            const T* y10 = y1p + prow * a.y1.ld + chs + (unsigned)(hi0 * Win + 2 * jj) * (unsigned)a.y1.ld;
+            T* dh0 = dhp + prow * a.C + chan + (unsigned)(hi0 * Win + 2 * jj) * (unsigned)a.C;
+            uint4 gw[3][2];                              // gradient-tile rows iy, iy+1, iy+2 (pairs jj, jj+1)
+            gw[0][0] = *reinterpret_cast<const uint4*>(tcol); gw[0][1] = *reinterpret_cast<const uint4*>(tcol + CS);
+            gw[1][0] = *reinterpret_cast<const uint4*>(tcol + rowdw); gw[1][1] = *reinterpret_cast<const uint4*>(tcol + rowdw + CS);
+            uint2 ryn[2] = {wk_ld8(y10), wk_ld8(y10 + a.y1.ld)};
+            auto row_step = [&](const int iy, uint4 (&g0)[2], uint4 (&g1)[2], uint4 (&g2)[2]) {
+                // g0, g1, g2: tile rows iy, iy+1, iy+2; g2 is loaded here
+                g2[0] = *reinterpret_cast<const uint4*>(tcol + (iy + 2) * rowdw);
+                g2[1] = *reinterpret_cast<const uint4*>(tcol + (iy + 2) * rowdw + CS);
+                const uint2 ry[2] = {ryn[0], ryn[1]};
+                if (iy + 1 < nri) {                      // next row's y1 in flight under this row's math
+                    const T* yn = y10 + (unsigned)(iy + 1) * y1row;
+                    ryn[0] = wk_ld8(yn); ryn[1] = wk_ld8(yn + a.y1.ld);
+                }
+                wk_f2_t y[2][2], z1[2][2], dsl[2][2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    wk_unpack(ry[h], y[h][0], y[h][1]);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const wk_f2_t hh = y[h][q] * bs2[q] + bt2[q];
+                        const wk_f2_t sg = wk_f2_t{sigmoidf_(hh.x), sigmoidf_(hh.y)};
+                        z1[h][q] = hh * sg;
+                        dsl[h][q] = sg * (1.0f + hh * (1.0f - sg));
+                    }
+                }
+                const unsigned Z[4] = {pk_bf16(z1[0][0].x, z1[1][0].x), pk_bf16(z1[0][0].y, z1[1][0].y),
+                                       pk_bf16(z1[0][1].x, z1[1][1].x), pk_bf16(z1[0][1].y, z1[1][1].y)};
+                float dz0[4] = {0.f, 0.f, 0.f, 0.f}, dz1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    __builtin_amdgcn_sched_barrier(0);        // one stencil row's weight vectors live at a time (registers)
+                    // tile row iy + (2 - dy): output row ho = hi + 1 - dy
+                    const uint4 G0 = dy == 0 ? g2[0] : dy == 1 ? g1[0] : g0[0];
+                    const uint4 G1 = dy == 0 ? g2[1] : dy == 1 ? g1[1] : g0[1];
+                    const uint4 Wa = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 0) * CS + cv * 4]);
+                    const uint4 Wb = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 1) * CS + cv * 4]);
+                    const uint4 Wc = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 2) * CS + cv * 4]);
+                    const uint4 Wd = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 3) * CS + cv * 4]);
+                    const unsigned ga[4] = {G0.x, G0.y, G0.z, G0.w}, gb[4] = {G1.x, G1.y, G1.z, G1.w};
+                    const unsigned wa[4] = {Wa.x, Wa.y, Wa.z, Wa.w}, wb[4] = {Wb.x, Wb.y, Wb.z, Wb.w};
+                    const unsigned wc[4] = {Wc.x, Wc.y, Wc.z, Wc.w}, wd[4] = {Wd.x, Wd.y, Wd.z, Wd.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        dz0[q] = wk_dot2(ga[q], wa[q], dz0[q]);
+                        dz0[q] = wk_dot2(gb[q], wb[q], dz0[q]);
+                        dz1[q] = wk_dot2(ga[q], wc[q], dz1[q]);
+                        dz1[q] = wk_dot2(gb[q], wd[q], dz1[q]);
+                        const unsigned gm = __builtin_amdgcn_alignbit(gb[q], ga[q], 16);      // (G0.hi, G1.lo)
+                        dwp[dy * 3 + 2][q] = wk_dot2(Z[q], ga[q], dwp[dy * 3 + 2][q]);
+                        dwp[dy * 3 + 1][q] = wk_dot2(Z[q], gm, dwp[dy * 3 + 1][q]);
+                        dwp[dy * 3 + 0][q] = wk_dot2(Z[q], gb[q], dwp[dy * 3 + 0][q]);
+                    }
+                }
+                T* dst = dh0 + (unsigned)iy * dhrow;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float* dz = h == 0 ? dz0 : dz1;
+                    const wk_f2_t d0 = wk_f2_t{dz[0], dz[1]} * dsl[h][0], d1 = wk_f2_t{dz[2], dz[3]} * dsl[h][1];
+                    const uint2 packed = make_uint2(pk_bf16(d0.x, d0.y), pk_bf16(d1.x, d1.y));
+                    *reinterpret_cast<uint2*>(dst + h * a.C) = packed;
+                    wk_f2_t r0, r1;
+                    wk_unpack(packed, r0, r1);                    // statistics of the values as stored
+                    sp0[0] += r0; sp0[1] += r1;
+                    sp1[0] += r0 * y[h][0];
+                    sp1[1] += r1 * y[h][1];
+                }
+            };
+            for (int iy0 = 0; iy0 < nri; iy0 += 3) {
+                row_step(iy0, gw[0], gw[1], gw[2]);
+                if (iy0 + 1 < nri) row_step(iy0 + 1, gw[1], gw[2], gw[0]);
+                if (iy0 + 2 < nri) row_step(iy0 + 2, gw[2], gw[0], gw[1]);
+            }
+        }
+        __syncthreads();
+    }
+    // ---------------- weight gradient: fold the wave's four pixel lanes (36 values -> 9 per lane), then LDS / global atomics
+    float* lw = reinterpret_cast<float*>(wk_smem);               // [9][64], the gradient tile is dead
+    for (int i = tid; i < 9 * CS; i += NT) lw[i] = 0.f;
+    __syncthreads();
+    {
+        float v[36], o[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[k * 4 + q] = dwp[k][q];
+        wk_fold4<9>(v, o, lane);
+        const int r = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int vi = i + 9 * (r >> 1) + 18 * (r & 1);          // value index = tap*4 + q
+            atomicAdd(&lw[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * CS; i += NT) {
+        const int k = i / CS, c = c0 + i % CS;
+        if (c < a.C) atomicAdd(&a.dw[(i64)c * 9 + k], lw[i]);
+    }
+    if (a.stats) {
+        float bm[4], bi[4];
+        ldc4(a.y1.v3 + chs, bm); ldc4(a.y1.v4 + chs, bi);
+        float v[8] = {sp0[0].x, sp0[0].y, sp0[1].x, sp0[1].y,
+                      bi[0] * fmaf(-bm[0], sp0[0].x, sp1[0].x), bi[1] * fmaf(-bm[1], sp0[0].y, sp1[0].y),
+                      bi[2] * fmaf(-bm[2], sp0[1].x, sp1[1].x), bi[3] * fmaf(-bm[3], sp0[1].y, sp1[1].y)}, o[2];
+        wk_fold4<2>(v, o, lane);
+        const int r = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int vi = i + 2 * (r >> 1) + 4 * (r & 1);           // 0..3: Σdh1 of channel vi; 4..7: Σdh1·ŷ1 of channel vi-4
+            atomicAdd(&lstat[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
+        }
+        __syncthreads();
+        if (tid < 2 * CS) {
+            const int which = tid / CS, c = c0 + tid % CS;
+            if (c < a.C) stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.C, which, c, lstat[tid]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stride 2.  A thread owns one QUAD of input pixels (columns 4m .. 4m+3) of an input row and walks down the rows.
+// With the output-column pairs Gq[k] = (g[wo = 2k-1], g[wo = 2k]) and M = (g[wo = 2m], g[wo = 2m+1]) = align(Gq[m], Gq[m+1]),
+// a tap row (dy, output row ho) contributes
+//   dz[4m]   = dot2(M, (w1, 0))      dz[4m+1] = dot2(M, (w2, w0))      dz[4m+2] = dot2(M, (0, w1))      dz[4m+3] = dot2(Gq[m+1], (w2, w0))
+//   dW[dy][1] += dot2((z0, z2), M)   dW[dy][2] += dot2((z1, z3), M)    dW[dy][0] += dot2((z1, z3), Gq[m+1])
+// Even input rows meet one tap row (dy = 1, ho = hi/2), odd rows two (dy = 0 at ho = (hi+1)/2, dy = 2 at ho = (hi-1)/2):
+// the two gradient rows in use slide down in registers (one tile row read per two input rows).
+// LPW = quads per input row = output pairs per row (Win == 4*LPW in {64, 32, 16}); NG = 16/LPW planes per tile.
+// ------------------------------------------------------------------------------------------------
+template <int LPW>
+__global__ __launch_bounds__(256, WK_MINW2) void dw_spatial_bwd_s2_kernel(const DwSpatialBwd a, const int R, const int rows_qmax) {
+    typedef bf16_t T;
+    constexpr int NT = 256, CS = 64, NG = 16 / LPW, Wqp = LPW + 1;
+    __shared__ float lstat[2 * CS];
+    __shared__ __attribute__((aligned(16))) unsigned lwp[3 * 3 * CS];        // packed weights [dy][combo][channel]
+    __shared__ __attribute__((aligned(16))) float lcoef[2 * CS];             // BatchNorm-1 scale, shift (re-read per row: registers)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int cv = tid & 15, pl = tid >> 4;
+    const int grp = pl / LPW, jj = pl % LPW;
+    const int c0 = blockIdx.y * CS;
+    const int chan = c0 + cv * 4;
+    const bool chan_ok = chan < a.C;
+    const int chs = chan_ok ? chan : 0;
+    if (tid < 2 * CS) {
+        lstat[tid] = 0.f;
+        const int c = c0 + (tid & (CS - 1));
+        lcoef[tid] = c < a.C ? (tid < CS ? a.y1.v1[c] : a.y1.v2[c]) : 0.f;
+    }
+    for (int i = tid; i < 3 * CS; i += NT) {
+        const int dy = i / CS, cc = i % CS, c = c0 + cc;
+        float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+        if (c < a.C) { w0 = a.w[(i64)(dy * 3 + 0) * a.C + c]; w1 = a.w[(i64)(dy * 3 + 1) * a.C + c]; w2 = a.w[(i64)(dy * 3 + 2) * a.C + c]; }
+        lwp[(dy * 3 + 0) * CS + cc] = pk_bf16(w1, 0.f);
+        lwp[(dy * 3 + 1) * CS + cc] = pk_bf16(w2, w0);
+        lwp[(dy * 3 + 2) * CS + cc] = pk_bf16(0.f, w1);
+    }
+    __syncthreads();
+
+    float dwp[9][4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { dwp[k][0] = dwp[k][1] = dwp[k][2] = dwp[k][3] = 0.f; }
+    wk_f2_t sp0[2] = {wk_f2_t{0.f, 0.f}, wk_f2_t{0.f, 0.f}}, sp1[2] = {wk_f2_t{0.f, 0.f}, wk_f2_t{0.f, 0.f}};   // Σdh1, Σdh1·y1
+
+    const int Win = a.Win, Hin = a.Hin;             // Win == 4*LPW; R is even: bands start on even input rows
+    const int nbands = (Hin + R - 1) / R;
+    const int ngroups = (a.planes + NG - 1) / NG;
+    const int ntiles = ngroups * nbands;
+    T* dhp = reinterpret_cast<T*>(a.dh1);
+    const T* y1p = reinterpret_cast<const T*>(a.y1.p);
+    unsigned* tile = reinterpret_cast<unsigned*>(wk_smem);        // [NG][rows_qmax][Wqp][64] dwords
+    const int rowdw = Wqp * CS;
+    const unsigned* tcol = tile + (grp * rows_qmax * Wqp + jj) * CS + cv * 4;
+    const unsigned y1row = (unsigned)Win * (unsigned)a.y1.ld, dhrow = (unsigned)Win * (unsigned)a.C;
+
+    for (int tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+        const int pg = tile_id / nbands, band = tile_id - pg * nbands;
+        const int plane = pg * NG + grp;
+        const bool pvalid = plane < a.planes && chan_ok;
+        const int psafe = plane < a.planes ? plane : 0;
+        const int hi0 = band * R;
+        const int nri = (Hin - hi0 < R) ? Hin - hi0 : R;
+        const int ho_lo = hi0 >> 1;
+        const int rows_q = ((hi0 + nri) >> 1) - ho_lo + 1;
+        wk_stage<LPW>(a, tile, grp, jj, cv, chs, psafe, pvalid, ho_lo, rows_q, rows_qmax);
+        __syncthreads();
+        if (pvalid) {
+            const i64 prow = (i64)plane * Hin * Win;
+            const T* y10 = y1p + prow * a.y1.ld + chs + (unsigned)(hi0 * Win + 4 * jj) * (unsigned)a.y1.ld;
+            T* dh0 = dhp + prow * a.C + chan + (unsigned)(hi0 * Win + 4 * jj) * (unsigned)a.C;
+            uint4 gA[2], gB[2];                          // gradient rows in use: pairs jj, jj+1
+            gA[0] = *reinterpret_cast<const uint4*>(tcol); gA[1] = *reinterpret_cast<const uint4*>(tcol + CS);
+            // one input row: NTAP tap rows (dy, gradient row) — even rows (dy 1, gcur), odd rows (dy 0, gnext) and (dy 2, gcur)
+            auto row_step = [&](const int iy, auto odd_c, const uint4 (&gcur)[2], const uint4 (&gnext)[2]) {
+                constexpr bool ODD = decltype(odd_c)::value;
+                uint2 ry[4];
+                {
+                    const T* yn = y10 + (unsigned)iy * y1row;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) ry[p] = wk_ld8(yn + p * a.y1.ld);       // in flight under the data-gradient taps
+                }
+                // 1) data-gradient taps (need only the gradient rows): dz of the four pixels
+                float dz[4][4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) dz[p][0] = dz[p][1] = dz[p][2] = dz[p][3] = 0.f;
+                auto tap_dz = [&](const int dy, const uint4 (&g)[2]) {
+                    const uint4 W0 = *reinterpret_cast<const uint4*>(&lwp[(dy * 3 + 0) * CS + cv * 4]);
+                    const uint4 W1 = *reinterpret_cast<const uint4*>(&lwp[(dy * 3 + 1) * CS + cv * 4]);
+                    const uint4 W2 = *reinterpret_cast<const uint4*>(&lwp[(dy * 3 + 2) * CS + cv * 4]);
+                    const unsigned ga[4] = {g[0].x, g[0].y, g[0].z, g[0].w}, gb[4] = {g[1].x, g[1].y, g[1].z, g[1].w};
+                    const unsigned w0[4] = {W0.x, W0.y, W0.z, W0.w}, w1[4] = {W1.x, W1.y, W1.z, W1.w}, w2[4] = {W2.x, W2.y, W2.z, W2.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned gm = __builtin_amdgcn_alignbit(gb[q], ga[q], 16);      // (g[wo=2m], g[wo=2m+1])
+                        dz[0][q] = wk_dot2(gm, w0[q], dz[0][q]);
+                        dz[1][q] = wk_dot2(gm, w1[q], dz[1][q]);
+                        dz[2][q] = wk_dot2(gm, w2[q], dz[2][q]);
+                        dz[3][q] = wk_dot2(gb[q], w1[q], dz[3][q]);
+                    }
+                };
+                if constexpr (ODD) { tap_dz(0, gnext); __builtin_amdgcn_sched_barrier(0); tap_dz(2, gcur); } else { tap_dz(1, gcur); }
+                __builtin_amdgcn_sched_barrier(0);
+                // 2) activation, pixel by pixel (order 0, 2, 1, 3 so that (z0, z2) and (z1, z3) pack as soon as possible);
+                //    each pixel is finished at once: dh1 = dz * SiLU', store, BatchNorm-backward sums
+                T* dst = dh0 + (unsigned)iy * dhrow;
+                const float4 s4 = *reinterpret_cast<const float4*>(&lcoef[cv * 4]), t4 = *reinterpret_cast<const float4*>(&lcoef[CS + cv * 4]);
+                const wk_f2_t bs2[2] = {wk_f2_t{s4.x, s4.y}, wk_f2_t{s4.z, s4.w}}, bt2[2] = {wk_f2_t{t4.x, t4.y}, wk_f2_t{t4.z, t4.w}};
+                wk_f2_t zk[2][2];
+                unsigned Zev[4], Zod[4];
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    const int p = pp == 0 ? 0 : pp == 1 ? 2 : pp == 2 ? 1 : 3;
+                    wk_f2_t y[2], z[2], dsl[2];
+                    wk_unpack(ry[p], y[0], y[1]);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const wk_f2_t hh = y[q] * bs2[q] + bt2[q];
+                        const wk_f2_t sg = wk_f2_t{sigmoidf_(hh.x), sigmoidf_(hh.y)};
+                        z[q] = hh * sg;
+                        dsl[q] = sg * (1.0f + hh * (1.0f - sg));
+                    }
+                    const wk_f2_t d0 = wk_f2_t{dz[p][0], dz[p][1]} * dsl[0], d1 = wk_f2_t{dz[p][2], dz[p][3]} * dsl[1];
+                    const uint2 packed = make_uint2(pk_bf16(d0.x, d0.y), pk_bf16(d1.x, d1.y));
+                    *reinterpret_cast<uint2*>(dst + p * a.C) = packed;
+                    wk_f2_t r0, r1;
+                    wk_unpack(packed, r0, r1);                    // statistics of the values as stored
+                    sp0[0] += r0; sp0[1] += r1;
+                    sp1[0] += r0 * y[0];
+                    sp1[1] += r1 * y[1];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if ((pp & 1) == 0) { zk[0][0] = z[0]; zk[0][1] = z[1]; }
+                    else {
+                        unsigned* Zp = pp == 1 ? Zev : Zod;
+                        Zp[0] = pk_bf16(zk[0][0].x, z[0].x); Zp[1] = pk_bf16(zk[0][0].y, z[0].y);
+                        Zp[2] = pk_bf16(zk[0][1].x, z[1].x); Zp[3] = pk_bf16(zk[0][1].y, z[1].y);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // 3) weight-gradient taps
+                auto tap_dw = [&](const int dy, const uint4 (&g)[2]) {
+                    const unsigned ga[4] = {g[0].x, g[0].y, g[0].z, g[0].w}, gb[4] = {g[1].x, g[1].y, g[1].z, g[1].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned gm = __builtin_amdgcn_alignbit(gb[q], ga[q], 16);
+                        dwp[dy * 3 + 1][q] = wk_dot2(Zev[q], gm, dwp[dy * 3 + 1][q]);
+                        dwp[dy * 3 + 2][q] = wk_dot2(Zod[q], gm, dwp[dy * 3 + 2][q]);
+                        dwp[dy * 3 + 0][q] = wk_dot2(Zod[q], gb[q], dwp[dy * 3 + 0][q]);
+                    }
+                };
+                if constexpr (ODD) { tap_dw(0, gnext); tap_dw(2, gcur); } else { tap_dw(1, gcur); }
+            };
+            using T_ = std::true_type;
+            using F_ = std::false_type;
+            // input rows in pairs (even, odd); gA = gradient row of the even row, gB = the next one
+            for (int iy = 0; iy < nri; iy += 2) {
+                row_step(iy, F_{}, gA, gB);
+                if (iy + 1 < nri) {
+                    gB[0] = *reinterpret_cast<const uint4*>(tcol + ((iy >> 1) + 1) * rowdw);
+                    gB[1] = *reinterpret_cast<const uint4*>(tcol + ((iy >> 1) + 1) * rowdw + CS);
+                    row_step(iy + 1, T_{}, gA, gB);
+                    gA[0] = gB[0]; gA[1] = gB[1];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---------------- weight gradient: fold the wave's four pixel lanes (36 values -> 9 per lane), then LDS / global atomics
+    float* lw = reinterpret_cast<float*>(wk_smem);               // [9][64], the gradient tile is dead
+    for (int i = tid; i < 9 * CS; i += NT) lw[i] = 0.f;
+    __syncthreads();
+    {
+        float v[36], o[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[k * 4 + q] = dwp[k][q];
+        wk_fold4<9>(v, o, lane);
+        const int r = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int vi = i + 9 * (r >> 1) + 18 * (r & 1);          // value index = tap*4 + q
+            atomicAdd(&lw[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * CS; i += NT) {
+        const int k = i / CS, c = c0 + i % CS;
+        if (c < a.C) atomicAdd(&a.dw[(i64)c * 9 + k], lw[i]);
+    }
+    if (a.stats) {
+        float bm[4], bi[4];
+        ldc4(a.y1.v3 + chs, bm); ldc4(a.y1.v4 + chs, bi);
+        float v[8] = {sp0[0].x, sp0[0].y, sp0[1].x, sp0[1].y,
+                      bi[0] * fmaf(-bm[0], sp0[0].x, sp1[0].x), bi[1] * fmaf(-bm[1], sp0[0].y, sp1[0].y),
+                      bi[2] * fmaf(-bm[2], sp0[1].x, sp1[1].x), bi[3] * fmaf(-bm[3], sp0[1].y, sp1[1].y)}, o[2];
+        wk_fold4<2>(v, o, lane);
+        const int r = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int vi = i + 2 * (r >> 1) + 4 * (r & 1);
+            atomicAdd(&lstat[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
+        }
+        __syncthreads();
+        if (tid < 2 * CS) {
+            const int which = tid / CS, c = c0 + tid % CS;
+            if (c < a.C) stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.C, which, c, lstat[tid]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launcher
+// ------------------------------------------------------------------------------------------------
+#ifndef WK_LDS_BUDGET
+#define WK_LDS_BUDGET (50 * 1024)          // three workgroups per CU
+#endif
+
+bool dw_spatial_bwd_walk_supported(const DwSpatialBwd& a, int dtype) {
+    const char* off = getenv("DWN_DWS_WALK_OFF");          // read per call: lets one process A/B the two implementations
+    if ((off && off[0] == '1') || dtype != DWN_BF16 || a.ks != 3 || a.C % 8) return false;
+    if (a.stride == 1) {
+        if (a.Win != 32 && a.Win != 16 && a.Win != 8) return false;
+        if (a.Hout != a.Hin || a.Wout != a.Win) return false;
+        if ((i64)a.Hin * a.Win * (a.dy.ld > a.y1.ld ? a.dy.ld : a.y1.ld) >= (1ll << 31)) return false;
+        return true;
+    }
+    if (a.stride == 2) {
+        if (a.Win != 64 && a.Win != 32 && a.Win != 16) return false;
+        if (a.Hout != (a.Hin - 1) / 2 + 1 || a.Wout != a.Win / 2) return false;
+        if ((i64)a.Hin * a.Win * (a.dy.ld > a.y1.ld ? a.dy.ld : a.y1.ld) >= (1ll << 31)) return false;
+        return true;
+    }
+    return false;
+}
+
+template <int LPW>
+static int launch_s1(const DwSpatialBwd& a, hipStream_t s) {
+    constexpr int NG = 16 / LPW, Wqp = LPW + 1;
+    const size_t rowb = (size_t)NG * Wqp * 256;
+    int R = a.rows_band;
+    if (R <= 0) {
+        R = 1;
+        while (R < a.Hin && (size_t)(R + 1 + 2) * rowb <= (size_t)WK_LDS_BUDGET) ++R;
+        const int nb = (a.Hin + R - 1) / R;
+        R = (a.Hin + nb - 1) / nb;                    // even split: no ragged last band
+    }
+    if (R > a.Hin) R = a.Hin;
+    const int rows_qmax = R + 2;
+    size_t lds = (size_t)rows_qmax * rowb;
+    if (lds < 9 * 64 * sizeof(float)) lds = 9 * 64 * sizeof(float);
+    if (lds > 150 * 1024) return dwn_set_error(-5, "dw_spatial_bwd: rows_band too large for the LDS tile");
+    auto kern = dw_spatial_bwd_s1_kernel<LPW>;
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        (void)hipGetLastError();
+    int bpc = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kern, 256, lds) != hipSuccess || bpc < 1) { (void)hipGetLastError(); bpc = 2; }
+    const int slices = (a.C + 63) / 64;
+    const int nbands = (a.Hin + R - 1) / R;
+    const i64 work = (i64)((a.planes + NG - 1) / NG) * nbands;
+    i64 gx = (256 * bpc) / slices;
+    if (gx < 1) gx = 1;
+    if (gx > work) gx = work;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, slices), dim3(256), lds, s, a, R, rows_qmax);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int LPW>
+static int launch_s2(const DwSpatialBwd& a, hipStream_t s) {
+    constexpr int NG = 16 / LPW, Wqp = LPW + 1;
+    const size_t rowb = (size_t)NG * Wqp * 256;
+    int R = a.rows_band;                              // input rows per band, even
+    if (R <= 0) {
+        R = 2;
+        while (R < a.Hin && (size_t)((R + 2) / 2 + 1) * rowb <= (size_t)WK_LDS_BUDGET) R += 2;
+        const int nb = (a.Hin + R - 1) / R;
+        R = (a.Hin + nb - 1) / nb;                    // even split
+    }
+    R = (R + 1) & ~1;
+    if (R > a.Hin) R = (a.Hin + 1) & ~1;
+    const int rows_qmax = R / 2 + 1;
+    size_t lds = (size_t)rows_qmax * rowb;
+    if (lds < 9 * 64 * sizeof(float)) lds = 9 * 64 * sizeof(float);
+    if (lds > 150 * 1024) return dwn_set_error(-5, "dw_spatial_bwd: rows_band too large for the LDS tile");
+    auto kern = dw_spatial_bwd_s2_kernel<LPW>;
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        (void)hipGetLastError();
+    int bpc = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kern, 256, lds) != hipSuccess || bpc < 1) { (void)hipGetLastError(); bpc = 2; }
+    const int slices = (a.C + 63) / 64;
+    const int nbands = (a.Hin + R - 1) / R;
+    const i64 work = (i64)((a.planes + NG - 1) / NG) * nbands;
+    i64 gx = (256 * bpc) / slices;
+    if (gx < 1) gx = 1;
+    if (gx > work) gx = work;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, slices), dim3(256), lds, s, a, R, rows_qmax);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_dw_spatial_bwd_walk(const DwSpatialBwd& a, hipStream_t s) {
+    if (a.stride == 1) {
+        if (a.Win == 32) return launch_s1<16>(a, s);
+        if (a.Win == 16) return launch_s1<8>(a, s);
+        return launch_s1<4>(a, s);
+    }
+    if (a.stride == 2) {
+        if (a.Win == 64) return launch_s2<16>(a, s);
+        if (a.Win == 32) return launch_s2<8>(a, s);
+        return launch_s2<4>(a, s);
+    }
+    return dwn_set_error(-3, "dw_spatial_bwd_walk: unsupported configuration");
+}

@@ -1266,7 +1266,10 @@ static int spatial_bwd_t(DwSpatialBwd a, hipStream_t s) {
     DWN_CHECK_LAUNCH();
     return 0;
 }
+bool dw_spatial_bwd_walk_supported(const DwSpatialBwd& a, int dtype);
+int launch_dw_spatial_bwd_walk(const DwSpatialBwd& a, hipStream_t s);
 int launch_dw_spatial_bwd(const DwSpatialBwd& a, int dtype, hipStream_t s) {
+    if (dw_spatial_bwd_walk_supported(a, dtype)) return launch_dw_spatial_bwd_walk(a, s);     // row-walk kernels (dwn_dwbwd.hip)
     return dtype == DWN_BF16 ? spatial_bwd_t<bf16_t>(a, s) : spatial_bwd_t<float>(a, s);
 }
 

@@ -1,0 +1,88 @@
+"""Row-walk spatial depth-wise backward kernels (sensorium_amd/csrc/dwn_dwbwd.hip; reference op: the backward of
+src/models/dwiseneuro.py:96-102) against the kernels they replace, through the C-ABI entry dwn_dw_spatial_bwd with
+DWN_DWS_WALK_OFF toggled per call.  The replaced kernels are pinned to the oracle by tests/test_gpu_block.py; here
+the two implementations must agree: dh1 BIT-identical (same dot2 order; stride 2 with bf16-representable stencil weights,
+which is what the dot2 kernels see anyway), dW and the BatchNorm-backward sums to summation order / bf16 rounding of z1."""
+import ctypes as C
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import sensorium_amd._lib as L  # noqa: E402
+from tests.gpu_helpers import dev  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def _desc(p, ld, **kw):
+    d = L.LoadDesc()
+    d.p = p.data_ptr(); d.ld = ld; d.rows_per_sample = 1
+    for k, v in kw.items():
+        setattr(d, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    return d
+
+
+def _both(planes, Hin, Win, Cc, stride, rows_band=0, seed=0):
+    d = dev()
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=d); g.manual_seed(seed)
+    Hout, Wout = (Hin - 1) // stride + 1, (Win - 1) // stride + 1
+    y1 = torch.randn(planes * Hin * Win, Cc, device=d, generator=g).to(BF)
+    dh2 = torch.randn(planes * Hout * Wout, Cc, device=d, generator=g).to(BF)
+    y2 = torch.randn(planes * Hout * Wout, Cc, device=d, generator=g).to(BF)
+    coef = torch.cat([torch.rand(Cc, device=d, generator=g) + 0.5, torch.randn(Cc, device=d, generator=g) * 0.3,
+                      torch.randn(Cc, device=d, generator=g) * 0.2, torch.rand(Cc, device=d, generator=g) + 0.5])
+    abc = torch.randn(3 * Cc, device=d, generator=g) * 0.5
+    w = (torch.randn(9, Cc, device=d, generator=g) / 3.0).to(BF).float()
+    out = {}
+    old_env = os.environ.get("DWN_DWS_WALK_OFF")
+    try:
+        for mode in ("old", "new"):
+            os.environ["DWN_DWS_WALK_OFF"] = "1" if mode == "old" else "0"
+            dh1 = torch.full_like(y1, float("nan"))
+            dw = torch.zeros(Cc, 9, device=d)
+            st = torch.zeros(32 * 2 * Cc, dtype=torch.float64, device=d)
+            a = L.DwSpatialBwdArgs()
+            a.dy = _desc(dh2, Cc, q=y2, v1=abc, v2=abc[Cc:], v3=abc[2 * Cc:])
+            a.y1 = _desc(y1, Cc, v1=coef, v2=coef[Cc:], v3=coef[2 * Cc:], v4=coef[3 * Cc:])
+            a.w = w.data_ptr(); a.dh1 = dh1.data_ptr(); a.dw = dw.data_ptr(); a.planes = planes; a.Hin = Hin; a.Win = Win
+            a.Hout = Hout; a.Wout = Wout; a.C = Cc; a.stride = stride; a.ks = 3; a.stats = st.data_ptr()
+            a.rows_band = rows_band if mode == "new" else 0
+            L.check(L.lib.dwn_dw_spatial_bwd(C.byref(a), L.DWN_BF16, d.index, s), "dwn_dw_spatial_bwd")
+            torch.cuda.synchronize()
+            out[mode] = (dh1, dw, st.view(32, 2, Cc).sum(0))
+    finally:
+        if old_env is None:
+            os.environ.pop("DWN_DWS_WALK_OFF", None)
+        else:
+            os.environ["DWN_DWS_WALK_OFF"] = old_env
+    return out["old"], out["new"]
+
+
+CASES = [
+    # planes, Hin, Win, C, stride   (Win in {32,16,8} stride 1 / {64,32,16} stride 2 take the row-walk kernels)
+    (3, 18, 32, 64, 1), (5, 9, 16, 128, 1), (7, 5, 8, 64, 1), (2, 3, 32, 72, 1), (9, 1, 8, 64, 1), (1, 20, 16, 64, 1),
+    (3, 36, 64, 64, 2), (5, 18, 32, 128, 2), (7, 9, 16, 64, 2), (2, 4, 64, 72, 2), (9, 1, 16, 64, 2), (3, 7, 32, 64, 2),
+    (130, 9, 16, 448, 1), (130, 9, 16, 448, 2),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_walk_kernels_match_replaced_kernels(case):
+    (d0, w0, s0), (d1, w1, s1) = _both(*case)
+    assert not torch.isnan(d1.float()).any()
+    assert torch.equal(d0.view(torch.int16), d1.view(torch.int16)), "dh1 differs"
+    assert float((w0 - w1).norm() / w0.norm()) < 2e-3            # z1 enters the weight gradient rounded to bf16
+    assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-4
+
+
+@pytest.mark.parametrize("stride,rows_band", [(1, 1), (1, 2), (1, 4), (1, 7), (2, 2), (2, 4), (2, 6)])
+def test_walk_kernels_band_heights(stride, rows_band):
+    H, W = (18, 32) if stride == 1 else (36, 64)
+    (d0, w0, s0), (d1, w1, s1) = _both(3, H, W, 64, stride, rows_band=rows_band)
+    assert torch.equal(d0.view(torch.int16), d1.view(torch.int16))
+    assert float((w0 - w1).norm() / w0.norm()) < 2e-3
+    assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-4
