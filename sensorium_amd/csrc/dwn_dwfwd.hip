@@ -1,0 +1,328 @@
+// spat_covn_dw forward (reference: src/models/dwiseneuro.py:96-102), bf16 storage, 3x3, stride 1 or 2 — "row walk" kernels.
+//
+//   y2 = dwS * SiLU(BN1(y1))   (+ Σy2, Σy2² for BatchNorm-2)
+//
+// Same arithmetic as dw_spatial_fwd_pair_kernel (activated input staged x-pair-packed in LDS, v_dot2c_f32_bf16 taps, bf16
+// stencil weights) with the loop organisation of the row-walk backward kernels (dwn_dwbwd.hip): a thread stages its own
+// pixel-pair column(s) row after row (constant halo mask, addresses advance by constants), then walks down the output rows
+// of its output pair column with the tile rows it needs in a sliding register window; planes narrower than 32 output pixels
+// sit side by side in one tile.  The stencils are VALU-issue-bound, and a quarter of the pair kernel's instructions were
+// flat-index decodes.  y2 is bit-identical to the pair kernel's.
+#include "dwn_internal.h"
+#include <stdlib.h>
+
+extern __shared__ __attribute__((aligned(16))) unsigned char wf_smem[];
+
+typedef float wf_f2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(2))) __bf16 wf_bf16x2_t;
+typedef unsigned wf_u32x2_t __attribute__((ext_vector_type(2)));
+
+#ifndef WF_MINW
+#define WF_MINW 3
+#endif
+
+__device__ __forceinline__ float wf_dot2(unsigned a, unsigned b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wf_bf16x2_t, a), __builtin_bit_cast(wf_bf16x2_t, b), c, false);
+}
+__device__ __forceinline__ void wf_unpack(const uint2& r, wf_f2_t& lo, wf_f2_t& hi) {
+    lo = wf_f2_t{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)};
+    hi = wf_f2_t{__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+}
+__device__ __forceinline__ uint2 wf_ld8(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+
+// LPW = output pixel pairs per plane row (Wout == 2*LPW in {32, 16, 8}); NG = 16/LPW planes side by side in one tile.
+// The staged tile has NPC = ST*LPW + 1 pair columns k = (wi = 2k-1, wi = 2k) and rows hi_first .. hi_first + rows_in - 1.
+template <int ST, int LPW>
+__global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_walk_kernel(const DwSpatialFwd a, const int R, const int rows_max) {
+    typedef bf16_t T;
+    constexpr int NT = 256, CS = 64, NG = 16 / LPW, NPC = ST * LPW + 1, NCW = ST;     // NCW: pair columns a thread stages
+    constexpr int NWC = ST == 1 ? 4 : 2;
+    __shared__ float lstat[2 * CS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int cv = tid & 15, pl = tid >> 4;
+    const int grp = pl / LPW, jj = pl % LPW;
+    const int c0 = blockIdx.y * CS;
+    const int chan = c0 + cv * 4;
+    const bool chan_ok = chan < a.C;
+    const int chs = chan_ok ? chan : 0;
+    if (tid < 2 * CS) lstat[tid] = 0.f;
+    __syncthreads();
+
+    // packed weights per stencil row dy and channel: A = (w0,w1), B = (w2,0) [, C = (0,w0), D = (w1,w2)]
+    unsigned wp[3][NWC][4];
+    {
+        float w[9][4];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            ldc4(a.w + (i64)k * a.C + chs, w[k]);
+            if (!chan_ok) { w[k][0] = w[k][1] = w[k][2] = w[k][3] = 0.f; }
+        }
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                wp[dy][0][q] = pk_bf16(w[dy * 3 + 0][q], w[dy * 3 + 1][q]);
+                wp[dy][1][q] = pk_bf16(w[dy * 3 + 2][q], 0.f);
+                if constexpr (ST == 1) {
+                    wp[dy][2][q] = pk_bf16(0.f, w[dy * 3 + 0][q]);
+                    wp[dy][3][q] = pk_bf16(w[dy * 3 + 1][q], w[dy * 3 + 2][q]);
+                }
+            }
+    }
+    float bs[4], bt[4];
+    ldc4(a.in.v1 + chs, bs); ldc4(a.in.v2 + chs, bt);
+    const wf_f2_t bs2[2] = {wf_f2_t{bs[0], bs[1]}, wf_f2_t{bs[2], bs[3]}}, bt2[2] = {wf_f2_t{bt[0], bt[1]}, wf_f2_t{bt[2], bt[3]}};
+    wf_f2_t st0[2] = {wf_f2_t{0.f, 0.f}, wf_f2_t{0.f, 0.f}}, st1[2] = {wf_f2_t{0.f, 0.f}, wf_f2_t{0.f, 0.f}};
+
+    const int Hin = a.Hin, Win = a.Win, Hout = a.Hout, Wout = a.Wout;
+    const int nbands = (Hout + R - 1) / R;
+    const int ngroups = (a.planes + NG - 1) / NG;
+    const int ntiles = ngroups * nbands;
+    const T* inp = reinterpret_cast<const T*>(a.in.p);
+    T* outp = reinterpret_cast<T*>(a.out);
+    unsigned* tile = reinterpret_cast<unsigned*>(wf_smem);        // [NG][rows_max][NPC][64] dwords
+    const int rowdw = NPC * CS;
+    unsigned* tplane = tile + grp * rows_max * rowdw + cv * 4;
+    const unsigned inrow = (unsigned)Win * (unsigned)a.in.ld, outrow = (unsigned)Wout * (unsigned)a.C;
+
+    auto act_pack = [&](const uint2& rlo, const uint2& rhi) {
+        wf_f2_t y0, y1v, z[2][2];
+        wf_unpack(rlo, y0, y1v);
+        {
+            const wf_f2_t h0 = y0 * bs2[0] + bt2[0], h1 = y1v * bs2[1] + bt2[1];
+            z[0][0] = h0 * wf_f2_t{sigmoidf_(h0.x), sigmoidf_(h0.y)};
+            z[0][1] = h1 * wf_f2_t{sigmoidf_(h1.x), sigmoidf_(h1.y)};
+        }
+        wf_unpack(rhi, y0, y1v);
+        {
+            const wf_f2_t h0 = y0 * bs2[0] + bt2[0], h1 = y1v * bs2[1] + bt2[1];
+            z[1][0] = h0 * wf_f2_t{sigmoidf_(h0.x), sigmoidf_(h0.y)};
+            z[1][1] = h1 * wf_f2_t{sigmoidf_(h1.x), sigmoidf_(h1.y)};
+        }
+        return make_uint4(pk_bf16(z[0][0].x, z[1][0].x), pk_bf16(z[0][0].y, z[1][0].y), pk_bf16(z[0][1].x, z[1][1].x), pk_bf16(z[0][1].y, z[1][1].y));
+    };
+
+    for (int tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+        const int pg = tile_id / nbands, band = tile_id - pg * nbands;
+        const int plane = pg * NG + grp;
+        const bool pvalid = plane < a.planes && chan_ok;
+        const int psafe = plane < a.planes ? plane : 0;
+        const int ho0 = band * R;
+        const int nro = (Hout - ho0 < R) ? Hout - ho0 : R;
+        const int hi_first = ho0 * ST - 1;
+        const int rows_in = (nro - 1) * ST + 3;
+        // ---------------- stage SiLU(BN1(y1)), x-pair-packed, zero halo: own pair column(s) for every row
+        {
+            const T* in0 = inp + (i64)psafe * Hin * Win * a.in.ld + chs;
+            constexpr int NB = ST == 1 ? 4 : 2;
+#pragma unroll
+            for (int cw = 0; cw < NCW; ++cw) {
+                const int kc = jj * NCW + cw;                                   // pair column: pixels wi = 2kc-1, 2kc
+                const unsigned cmask = (kc > 0 ? 0x0000ffffu : 0u) | 0xffff0000u;
+                const unsigned colhi = (unsigned)(2 * kc) * (unsigned)a.in.ld;
+                const unsigned lodelta = kc > 0 ? (unsigned)a.in.ld : 0u;
+                unsigned* tcol = tplane + kc * CS;
+                for (int r0 = 0; r0 < rows_in; r0 += NB) {
+                    uint2 rr[NB][2];
+                    bool ok[NB];
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        const int hi = hi_first + r0 + u;
+                        ok[u] = pvalid && r0 + u < rows_in && (unsigned)hi < (unsigned)Hin;
+                        const unsigned off = ok[u] ? (unsigned)hi * inrow + colhi : lodelta;
+                        rr[u][1] = wf_ld8(in0 + off);
+                        rr[u][0] = wf_ld8(in0 + off - lodelta);
+                    }
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        if (r0 + u < rows_in) {
+                            uint4 o = act_pack(rr[u][0], rr[u][1]);
+                            const unsigned m = ok[u] ? cmask : 0u;
+                            o.x &= m; o.y &= m; o.z &= m; o.w &= m;
+                            *reinterpret_cast<uint4*>(tcol + (r0 + u) * rowdw) = o;
+                        }
+                    }
+                }
+            }
+            // last pair column (wi = Win-1, halo): row r = jj, jj + LPW, ... of this plane
+            const unsigned collast = (unsigned)(Win - 1) * (unsigned)a.in.ld;
+            for (int r = jj; r < rows_in; r += LPW) {
+                const int hi = hi_first + r;
+                const bool okr = pvalid && (unsigned)hi < (unsigned)Hin;
+                const unsigned off = okr ? (unsigned)hi * inrow + collast : 0u;
+                const uint2 v = wf_ld8(in0 + off);
+                uint4 o = act_pack(v, v);
+                const unsigned m = okr ? 0x0000ffffu : 0u;
+                o.x &= m; o.y &= m; o.z &= m; o.w &= m;
+                *reinterpret_cast<uint4*>(tplane + r * rowdw + (NPC - 1) * CS) = o;
+            }
+        }
+        __syncthreads();
+        // ---------------- walk down the output rows of this thread's output pair column (outputs 2jj, 2jj+1)
+        if (pvalid) {
+            T* out0 = outp + ((i64)plane * Hout + ho0) * Wout * a.C + chan + (unsigned)(2 * jj) * (unsigned)a.C;
+            const unsigned* tc = tplane + (ST == 1 ? jj : 2 * jj) * CS;       // first tile pair of this output pair
+            auto finish = [&](const int oy, const float* acc0, const float* acc1) {
+                T* dst = out0 + (unsigned)oy * outrow;
+                const uint2 pk0 = make_uint2(pk_bf16(acc0[0], acc0[1]), pk_bf16(acc0[2], acc0[3]));
+                const uint2 pk1 = make_uint2(pk_bf16(acc1[0], acc1[1]), pk_bf16(acc1[2], acc1[3]));
+                *reinterpret_cast<uint2*>(dst) = pk0;
+                *reinterpret_cast<uint2*>(dst + a.C) = pk1;
+                wf_f2_t r0, r1;
+                wf_unpack(pk0, r0, r1);
+                st0[0] += r0; st0[1] += r1; st1[0] += r0 * r0; st1[1] += r1 * r1;
+                wf_unpack(pk1, r0, r1);
+                st0[0] += r0; st0[1] += r1; st1[0] += r0 * r0; st1[1] += r1 * r1;
+            };
+            if constexpr (ST == 1) {
+                uint4 tw[3][2];                              // tile rows oy, oy+1, oy+2: pairs jj, jj+1
+                tw[0][0] = *reinterpret_cast<const uint4*>(tc); tw[0][1] = *reinterpret_cast<const uint4*>(tc + CS);
+                tw[1][0] = *reinterpret_cast<const uint4*>(tc + rowdw); tw[1][1] = *reinterpret_cast<const uint4*>(tc + rowdw + CS);
+                auto row_step = [&](const int oy, const uint4 (&t0)[2], const uint4 (&t1)[2], uint4 (&t2)[2]) {
+                    t2[0] = *reinterpret_cast<const uint4*>(tc + (oy + 2) * rowdw);
+                    t2[1] = *reinterpret_cast<const uint4*>(tc + (oy + 2) * rowdw + CS);
+                    float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const uint4 p0 = dy == 0 ? t0[0] : dy == 1 ? t1[0] : t2[0];
+                        const uint4 p1 = dy == 0 ? t0[1] : dy == 1 ? t1[1] : t2[1];
+                        const unsigned x0[4] = {p0.x, p0.y, p0.z, p0.w}, x1[4] = {p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc0[q] = wf_dot2(x0[q], wp[dy][0][q], acc0[q]);
+                            acc0[q] = wf_dot2(x1[q], wp[dy][1][q], acc0[q]);
+                            acc1[q] = wf_dot2(x0[q], wp[dy][NWC - 2][q], acc1[q]);
+                            acc1[q] = wf_dot2(x1[q], wp[dy][NWC - 1][q], acc1[q]);
+                        }
+                    }
+                    finish(oy, acc0, acc1);
+                };
+                for (int oy = 0; oy < nro; oy += 3) {
+                    row_step(oy, tw[0], tw[1], tw[2]);
+                    if (oy + 1 < nro) row_step(oy + 1, tw[1], tw[2], tw[0]);
+                    if (oy + 2 < nro) row_step(oy + 2, tw[2], tw[0], tw[1]);
+                }
+            } else {
+                // stride 2: output ox reads staged columns 2ox .. 2ox+2 = P[ox] and the low half of P[ox+1]; rows 2oy .. 2oy+2
+                uint4 ta[3], tb[3], tcw[3];                  // tile rows 2oy (ta), 2oy+1 (tb), 2oy+2 (tcw): pairs 2jj, 2jj+1, 2jj+2
+#pragma unroll
+                for (int m = 0; m < 3; ++m) ta[m] = *reinterpret_cast<const uint4*>(tc + m * CS);
+                auto row_step = [&](const int oy, const uint4 (&r0)[3], uint4 (&r1)[3], uint4 (&r2)[3]) {
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        r1[m] = *reinterpret_cast<const uint4*>(tc + (2 * oy + 1) * rowdw + m * CS);
+                        r2[m] = *reinterpret_cast<const uint4*>(tc + (2 * oy + 2) * rowdw + m * CS);
+                    }
+                    float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const uint4 p0 = dy == 0 ? r0[0] : dy == 1 ? r1[0] : r2[0];
+                        const uint4 p1 = dy == 0 ? r0[1] : dy == 1 ? r1[1] : r2[1];
+                        const uint4 p2 = dy == 0 ? r0[2] : dy == 1 ? r1[2] : r2[2];
+                        const unsigned x0[4] = {p0.x, p0.y, p0.z, p0.w}, x1[4] = {p1.x, p1.y, p1.z, p1.w}, x2[4] = {p2.x, p2.y, p2.z, p2.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc0[q] = wf_dot2(x0[q], wp[dy][0][q], acc0[q]);
+                            acc0[q] = wf_dot2(x1[q], wp[dy][1][q], acc0[q]);
+                            acc1[q] = wf_dot2(x1[q], wp[dy][0][q], acc1[q]);
+                            acc1[q] = wf_dot2(x2[q], wp[dy][1][q], acc1[q]);
+                        }
+                    }
+                    finish(oy, acc0, acc1);
+                };
+                // the bottom tile row of one output row is the top row of the next: ta / tcw alternate
+                for (int oy = 0; oy < nro; oy += 2) {
+                    row_step(oy, ta, tb, tcw);
+                    if (oy + 1 < nro) row_step(oy + 1, tcw, tb, ta);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (a.stats) {
+        // fold the wave's four pixel lanes (8 sums -> 2 per lane) with two transposing lane swaps, then LDS atomics
+        const unsigned v[8] = {__float_as_uint(st0[0].x), __float_as_uint(st0[0].y), __float_as_uint(st0[1].x), __float_as_uint(st0[1].y),
+                               __float_as_uint(st1[0].x), __float_as_uint(st1[0].y), __float_as_uint(st1[1].x), __float_as_uint(st1[1].y)};
+        float c4[4], d2[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const wf_u32x2_t r = __builtin_amdgcn_permlane16_swap(v[k], v[k + 4], false, false);
+            c4[k] = __uint_as_float(r.x) + __uint_as_float(r.y);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const wf_u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c4[k]), __float_as_uint(c4[k + 2]), false, false);
+            d2[k] = __uint_as_float(r.x) + __uint_as_float(r.y);
+        }
+        const int r = lane >> 4;                          // lane row r holds value index (r&1)*4 + (r>>1)*2 + {0,1}
+#pragma unroll
+        for (int k = 0; k < 2; ++k) atomicAdd(&lstat[(r & 1) * CS + cv * 4 + (r >> 1) * 2 + k], d2[k]);
+        __syncthreads();
+        if (tid < 2 * CS) {
+            const int which = tid / CS, c = c0 + tid % CS;
+            if (c < a.C) stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.C, which, c, lstat[tid]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launcher
+// ------------------------------------------------------------------------------------------------
+#ifndef WF_LDS_BUDGET
+#define WF_LDS_BUDGET (52 * 1024)          // three workgroups per CU
+#endif
+
+bool dw_spatial_fwd_walk_supported(const DwSpatialFwd& a, int dtype) {
+    const char* off = getenv("DWN_DWS_WALK_OFF");          // read per call: lets one process A/B the two implementations
+    if ((off && off[0] == '1') || dtype != DWN_BF16 || a.ks != 3 || a.C % 8) return false;
+    // stride 2 is built and bit-exact too, but its staging (four input pixels per output, 8-byte loads) measured slower than the
+    // pair kernel's 16-byte / 512-thread staging (36x64: 770 vs 640-750 us): DWN_DWS_FWD_WALK_S2=1 enables it for experiments
+    static const bool s2 = getenv("DWN_DWS_FWD_WALK_S2") != nullptr;
+    if (a.stride != 1 && !(a.stride == 2 && s2)) return false;
+    if (a.Wout != 32 && a.Wout != 16 && a.Wout != 8) return false;
+    if (a.Win != a.Wout * a.stride || a.Hout != (a.Hin - 1) / a.stride + 1) return false;
+    if ((i64)a.Hin * a.Win * a.in.ld >= (1ll << 31)) return false;
+    return true;
+}
+
+template <int ST, int LPW>
+static int launch_fw(const DwSpatialFwd& a, hipStream_t s) {
+    constexpr int NG = 16 / LPW, NPC = ST * LPW + 1;
+    const size_t rowb = (size_t)NG * NPC * 256;
+    int R = a.rows_band;
+    if (R <= 0) {
+        R = 1;
+        while (R < a.Hout && (size_t)(R * ST + 3) * rowb <= (size_t)WF_LDS_BUDGET) ++R;
+        const int nb = (a.Hout + R - 1) / R;
+        R = (a.Hout + nb - 1) / nb;                   // even split: no ragged last band
+    }
+    if (R > a.Hout) R = a.Hout;
+    const int rows_max = (R - 1) * ST + 3;
+    const size_t lds = (size_t)rows_max * rowb;
+    if (lds > 150 * 1024) return dwn_set_error(-5, "dw_spatial_fwd: rows_band too large for the LDS tile");
+    auto kern = dw_spatial_fwd_walk_kernel<ST, LPW>;
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        (void)hipGetLastError();
+    int bpc = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kern, 256, lds) != hipSuccess || bpc < 1) { (void)hipGetLastError(); bpc = 2; }
+    const int slices = (a.C + 63) / 64;
+    const int nbands = (a.Hout + R - 1) / R;
+    const i64 work = (i64)((a.planes + NG - 1) / NG) * nbands;
+    i64 gx = (256 * bpc) / slices;
+    if (gx < 1) gx = 1;
+    if (gx > work) gx = work;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, slices), dim3(256), lds, s, a, R, rows_max);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_dw_spatial_fwd_walk(const DwSpatialFwd& a, hipStream_t s) {
+    if (a.stride == 1) {
+        if (a.Wout == 32) return launch_fw<1, 16>(a, s);
+        if (a.Wout == 16) return launch_fw<1, 8>(a, s);
+        return launch_fw<1, 4>(a, s);
+    }
+    if (a.Wout == 32) return launch_fw<2, 16>(a, s);
+    if (a.Wout == 16) return launch_fw<2, 8>(a, s);
+    return launch_fw<2, 4>(a, s);
+}

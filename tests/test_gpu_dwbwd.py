@@ -66,7 +66,7 @@ CASES = [
     # planes, Hin, Win, C, stride   (Win in {32,16,8} stride 1 / {64,32,16} stride 2 take the row-walk kernels)
     (3, 18, 32, 64, 1), (5, 9, 16, 128, 1), (7, 5, 8, 64, 1), (2, 3, 32, 72, 1), (9, 1, 8, 64, 1), (1, 20, 16, 64, 1),
     (3, 36, 64, 64, 2), (5, 18, 32, 128, 2), (7, 9, 16, 64, 2), (2, 4, 64, 72, 2), (9, 1, 16, 64, 2), (3, 7, 32, 64, 2),
-    (130, 9, 16, 448, 1), (130, 9, 16, 448, 2),
+    (130, 9, 16, 448, 1), (130, 9, 16, 448, 2), (131, 5, 8, 448, 1), (129, 18, 32, 448, 2),
 ]
 
 
@@ -74,7 +74,15 @@ CASES = [
 def test_walk_kernels_match_replaced_kernels(case):
     (d0, w0, s0), (d1, w1, s1) = _both(*case)
     assert not torch.isnan(d1.float()).any()
-    assert torch.equal(d0.view(torch.int16), d1.view(torch.int16)), "dh1 differs"
+    if case[4] == 1:
+        assert torch.equal(d0.view(torch.int16), d1.view(torch.int16)), "dh1 differs"
+    else:
+        # stride 2: the replaced generic kernel sums the (up to four) taps of a pixel as an fp32 FMA chain, the dot2 kernel two
+        # products at a time; the fp32 sums can differ in the last bit, which flips the bf16 rounding of a few results by one ulp
+        a, b = d0.float(), d1.float()
+        diff = (a - b).abs()
+        assert float((diff > 0).float().mean()) < 1e-3
+        assert bool((diff <= 2.0 ** -7 * a.abs() + 1e-30).all())
     assert float((w0 - w1).norm() / w0.norm()) < 2e-3            # z1 enters the weight gradient rounded to bf16
     assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-4
 
@@ -83,6 +91,6 @@ def test_walk_kernels_match_replaced_kernels(case):
 def test_walk_kernels_band_heights(stride, rows_band):
     H, W = (18, 32) if stride == 1 else (36, 64)
     (d0, w0, s0), (d1, w1, s1) = _both(3, H, W, 64, stride, rows_band=rows_band)
-    assert torch.equal(d0.view(torch.int16), d1.view(torch.int16))
+    assert float((d0.float() != d1.float()).float().mean()) < (1e-3 if stride == 2 else 1e-30)
     assert float((w0 - w1).norm() / w0.norm()) < 2e-3
     assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-4

@@ -1,0 +1,64 @@
+"""Row-walk spatial depth-wise forward kernel (sensorium_amd/csrc/dwn_dwfwd.hip; reference op src/models/dwiseneuro.py:96-102)
+against the pair kernel it replaces, through dwn_dw_spatial_fwd with DWN_DWS_WALK_OFF toggled per call: y2 BIT-identical,
+BatchNorm-2 sums to summation order.  (The pair kernel is pinned to the oracle by tests/test_gpu_block.py.)"""
+import ctypes as C
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import sensorium_amd._lib as L  # noqa: E402
+from tests.gpu_helpers import dev  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def _both(planes, Hin, Win, Cc, stride, rows_band=0, seed=0):
+    d = dev()
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=d); g.manual_seed(seed)
+    Hout, Wout = (Hin - 1) // stride + 1, (Win - 1) // stride + 1
+    x = torch.randn(planes * Hin * Win, Cc, device=d, generator=g).to(BF)
+    coef = torch.cat([torch.rand(Cc, device=d, generator=g) + 0.5, torch.randn(Cc, device=d, generator=g) * 0.3])
+    w = torch.randn(9, Cc, device=d, generator=g) / 3.0
+    out = {}
+    saved = os.environ.get("DWN_DWS_WALK_OFF")
+    try:
+        for mode in ("old", "new"):
+            os.environ["DWN_DWS_WALK_OFF"] = "1" if mode == "old" else "0"
+            y2 = torch.full((planes * Hout * Wout, Cc), float("nan"), dtype=BF, device=d)
+            st = torch.zeros(32 * 2 * Cc, dtype=torch.float64, device=d)
+            a = L.DwSpatialFwdArgs()
+            di = L.LoadDesc()
+            di.p = x.data_ptr(); di.ld = Cc; di.rows_per_sample = 1; di.v1 = coef.data_ptr(); di.v2 = coef[Cc:].data_ptr(); di.act = 1
+            a.inp = di
+            a.w = w.data_ptr(); a.out = y2.data_ptr(); a.planes = planes; a.Hin = Hin; a.Win = Win; a.Hout = Hout
+            a.Wout = Wout; a.C = Cc; a.stride = stride; a.ks = 3; a.stats = st.data_ptr()
+            a.rows_band = rows_band if mode == "new" else 0
+            L.check(L.lib.dwn_dw_spatial_fwd(C.byref(a), L.DWN_BF16, d.index, s), "dwn_dw_spatial_fwd")
+            torch.cuda.synchronize()
+            out[mode] = (y2, st.view(32, 2, Cc).sum(0))
+    finally:
+        if saved is None:
+            os.environ.pop("DWN_DWS_WALK_OFF", None)
+        else:
+            os.environ["DWN_DWS_WALK_OFF"] = saved
+    return out["old"], out["new"]
+
+
+@pytest.mark.parametrize("case", [(3, 18, 32, 64, 1), (5, 9, 16, 128, 1), (7, 5, 8, 64, 1), (2, 3, 32, 72, 1), (9, 1, 8, 64, 1),
+                                  (1, 20, 16, 64, 1), (130, 9, 16, 448, 1), (131, 5, 8, 448, 1)])
+def test_fwd_walk_matches_pair_kernel(case):
+    (y0, s0), (y1, s1) = _both(*case)
+    assert not torch.isnan(y1.float()).any()
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-5
+
+
+@pytest.mark.parametrize("rows_band", [1, 2, 4, 7])
+def test_fwd_walk_band_heights(rows_band):
+    (y0, s0), (y1, s1) = _both(3, 18, 32, 64, 1, rows_band=rows_band)
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-5
