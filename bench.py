@@ -70,34 +70,79 @@ def block_shapes(batch, frames, height, width, expansion):
     return out
 
 
-# algorithmic bytes per *step* of each timed kernel family (read input once + write output once;
-# backward = read x + read dy + write dx), in elements of the storage dtype
-def family_algorithmic_elems(shapes):
-    e = {}
-    e["dws_fwd"] = sum(mi * c + mo * c for mi, mo, c in shapes)
-    e["dwt_fwd"] = sum(2 * mo * c for mi, mo, c in shapes)
-    e["dws_bwd"] = sum(mi * c + mo * c + mi * c for mi, mo, c in shapes)
-    e["dwt_bwd"] = sum(3 * mo * c for mi, mo, c in shapes)
-    return e
+MFMA_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md: bf16 dense MFMA ~2.5 PFLOP/s
+MFMA_F32_PEAK_TFLOPS = 157.3       # ... fp32-input MFMA = the fp32 vector rate
+
+
+def family_work(batch, frames, height, width, expansion, readouts, fused_pw_blocks, esize):
+    """Algorithmic work per *step* of every timed kernel family: (bytes moved through HBM, FLOPs).
+    Depth-wise families follow SURVEY.md 8d (read input once + write output once; backward = read x + read dy + write dx);
+    GEMM families count every operand / result of the launches in the family once (2*M*K*N FLOPs per product).
+    `fused_pw_blocks`: blocks whose conv_pw data + weight gradient are one launch (counted under pw_dgrad)."""
+    e = {k: 0 for k in ("dws_fwd", "dwt_fwd", "dws_bwd", "dwt_bwd", "pw_fwd", "pwl_fwd", "pwl_dgrad", "pwl_wgrad",
+                        "pw_dgrad", "pw_wgrad", "se_pool")}
+    f = dict.fromkeys(e, 0)
+    h, w = height, width
+    for i, st in enumerate(STRIDES):
+        # block i: features[i] -> features[i] * expansion -> features[i + 1] (the last block keeps its width), dwiseneuro.py:319-335
+        cin, cout = CORE_FEATURES[i], CORE_FEATURES[min(i + 1, len(CORE_FEATURES) - 1)]
+        ho, wo = (h - 1) // st + 1, (w - 1) // st + 1
+        mi, mo, e_ = batch * frames * h * w, batch * frames * ho * wo, cin * expansion
+        e["dws_fwd"] += mi * e_ + mo * e_
+        e["dwt_fwd"] += 2 * mo * e_
+        e["dws_bwd"] += 2 * mi * e_ + mo * e_
+        e["dwt_bwd"] += 3 * mo * e_
+        e["se_pool"] += 2 * mo * e_
+        e["pw_fwd"] += mi * cin + mi * e_;                 f["pw_fwd"] += 2 * mi * cin * e_
+        e["pwl_fwd"] += mo * e_ + mo * cout;               f["pwl_fwd"] += 2 * mo * e_ * cout
+        e["pwl_dgrad"] += mo * cout + 2 * mo * e_;         f["pwl_dgrad"] += 2 * mo * e_ * cout     # dy4, y3 in; dh3 out
+        e["pwl_wgrad"] += mo * e_ + mo * cout;             f["pwl_wgrad"] += 2 * mo * e_ * cout
+        if i in fused_pw_blocks:
+            e["pw_dgrad"] += 2 * mi * e_ + 2 * mi * cin;   f["pw_dgrad"] += 4 * mi * cin * e_       # dh1, y1, a0 in; da0 out
+        else:
+            e["pw_dgrad"] += mi * e_ + 2 * mi * cin;       f["pw_dgrad"] += 2 * mi * (cin + e_) * cin   # K-concat fold
+            e["pw_wgrad"] += 2 * mi * e_ + mi * cin;       f["pw_wgrad"] += 2 * mi * cin * e_
+        h, w = ho, wo
+    m = batch * frames
+    cx = (CORE_FEATURES[-1],) + (1024, 2048, 4096)
+    e["cortex_fwd"] = sum(m * a + m * b for a, b in zip(cx[:-1], cx[1:]))
+    f["cortex_fwd"] = sum(2 * m * a * b // 2 for a, b in zip(cx[:-1], cx[1:]))                   # groups = 2
+    e["cortex_bwd"] = 2 * e["cortex_fwd"]
+    f["cortex_bwd"] = 2 * f["cortex_fwd"]
+    e = {k: v * esize for k, v in e.items()}
+    npad = [(n + 1) // 2 * 2 for n in readouts]
+    e["readout_fwd"] = sum(m * 4096 * esize + 4 * m * n for n in npad)                             # fp32 predictions
+    f["readout_fwd"] = sum(2 * m * 2048 * n for n in npad)
+    e["readout_bwd"] = sum(2 * m * 4096 * esize + 4 * m * n for n in npad)
+    f["readout_bwd"] = 2 * f["readout_fwd"]
+    return e, f
+
+
+def lib_sha16():
+    import hashlib
+    import sensorium_amd._lib as L
+    return hashlib.sha256(Path(L.LIB_PATH).read_bytes()).hexdigest()[:16]
 
 
 def cpu_baseline(frames, height, width, expansion):
-    """The CPU oracle (a port: oracle/dwiseneuro_oracle.py, pinned to the reference by tests/golden) timed on this
-    host on a BOUNDED sample of the benchmark workload: fwd + loss + bwd of B=1 clip at the benchmark's HxW and
-    width, first with T=8 frames; if that took < 6 s the full T-frame clip is timed instead, repeated until about
-    12 s of CPU work are sampled.  clips/s is scaled by the fraction of a clip processed (the path is linear in T)."""
+    """The CPU oracle (a port: oracle/dwiseneuro_oracle.py, pinned to the reference by tests/golden) timed on this host on a
+    BOUNDED sample of the benchmark workload, following BASELINE.md section 2: fwd + loss + bwd of B=2 clips at the
+    benchmark's T, HxW and width, fp32, all host cores (capped at 32: more only adds contention at these sizes), three
+    warm-up steps (one tiny, two full), then the MEDIAN of five timed steps (CPU step time drifts run to run).
+    B=2 instead of the largest batch that fits keeps the sample at ~20-25 s on the GPU box's host (B=4: ~50 s)."""
     from oracle import dwiseneuro_oracle as orc
     import numpy as np
     orc.DW_IMPL = "library"        # depth-wise convs through torch's conv3d, like the reference's CPU path
-    threads = min(os.cpu_count() or 1, 32)      # more threads than this only adds contention for these sizes
+    threads = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
+    bsz = 2
     sd = orc.make_state_dict(readout_outputs=(NUM_NEURONS_MOUSE0,), expansion_ratio=expansion, seed=0)
     sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and "inv_freq" not in k
               else v) for k, v in sd.items()}
-    rng = np.random.default_rng(0)
-    x = torch.from_numpy(rng.normal(size=(1, 5, frames, height, width)).astype(np.float32) * 40 + 80)
-    target = torch.from_numpy(np.maximum(rng.normal(size=(1, NUM_NEURONS_MOUSE0, frames)), 0).astype(np.float32))
-    w = torch.ones(1, 1)
+    rng = np.random.default_rng(20231122)
+    x = torch.from_numpy(rng.normal(size=(bsz, 5, frames, height, width)).astype(np.float32) * 40 + 80)
+    target = torch.from_numpy(np.maximum(rng.normal(size=(bsz, NUM_NEURONS_MOUSE0, frames)), 0).astype(np.float32))
+    w = torch.ones(bsz, 1)
 
     def step(t):
         for v in sd.values():
@@ -107,28 +152,28 @@ def cpu_baseline(frames, height, width, expansion):
         loss = orc.mice_poisson_loss(preds, [target[:, :, :t]], w)
         loss.backward()
 
-    step(2)                                    # tiny warm-up (thread pool, allocator)
-    t_s = min(8, frames)
+    step(2)                                    # warm-up 1: thread pool, allocator
+    t_q = max(4, frames // 4)
+    step(t_q)                                  # warm-up 2
     t0 = time.perf_counter()
-    step(t_s)
-    dt = time.perf_counter() - t0
-    if dt < 6.0 and t_s < frames:
-        t_s = frames
+    step(t_q)                                  # warm-up 3, timed to size the sample
+    quarter = time.perf_counter() - t0
+    # full clips when a step stays under ~5 s (five timed steps + warm-ups within the bounded sample), else a quarter of
+    # the frames (the path is linear in T)
+    t_s = frames if quarter * (frames / t_q) < 5.0 else t_q
+    if t_s != t_q:
+        step(t_s)                              # one more warm-up at the timed size
+    times = []
+    for _ in range(5):
         t0 = time.perf_counter()
         step(t_s)
-        dt = time.perf_counter() - t0
-    reps = 1
-    if t_s == frames and dt < 10.0:
-        # fast host: repeat the full clip until ~12 s of CPU work are sampled (at most 8 repetitions)
-        extra = min(int(12.0 / max(dt, 1e-3)), 7)
-        t0 = time.perf_counter()
-        for _ in range(extra):
-            step(t_s)
-        dt += time.perf_counter() - t0
-        reps += extra
-    return {"value": round(reps * (t_s / frames) / dt, 4), "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} fwd+loss+bwd step(s) of the CPU oracle on B=1 clip, {t_s} of {frames} frames, "
-                      f"{height}x{width}, expansion {expansion}, 1 readout, fp32, {dt:.1f} s in total; scaled to full clips"}
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(bsz * (t_s / frames) / med, 4), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"median of 5 fwd+loss+bwd steps (after 3 warm-ups) of the CPU oracle on B={bsz} clips, {t_s} of "
+                      f"{frames} frames, {height}x{width}, expansion {expansion}, 1 readout, fp32, torch "
+                      f"{torch.__version__}, mkldnn={torch.backends.mkldnn.is_available()}; step times "
+                      f"{min(times):.2f}-{max(times):.2f} s; scaled to full clips"}
 
 
 def main():
@@ -149,6 +194,7 @@ def main():
                     "forward + soft-label fill (ratio 0.36) + expansion-6 student step")
     ap.add_argument("--roofline-family", default="dws_bwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rooflines", action="store_true", help="skip the extra untimed steps that time every kernel family")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel family (adds event overhead)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU testing)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses cuda:0")
@@ -235,6 +281,21 @@ def main():
             L.check(L.lib.dwn_profile_collect(i, C.byref(ms), C.byref(n)), "profile_collect")
             fam_ms[name] = (ms.value, n.value)
     L.check(L.lib.dwn_profile_enable(0, local_rank), "profile_disable")
+    # every other kernel family: HIP events over a few extra, UNTIMED steps (events around every launch perturb the step)
+    fam_all, prof_steps = {}, 0
+    if rank == 0 and not args.no_rooflines:
+        prof_steps = 3
+        L.check(L.lib.dwn_profile_enable((1 << len(fam_names)) - 1, local_rank), "profile_enable")
+        for _ in range(prof_steps):
+            model.train_step(next_batch(), sync_loss=False)
+        torch.cuda.synchronize()
+        for i, name in enumerate(fam_names):
+            ms, n = C.c_double(0), C.c_longlong(0)
+            L.check(L.lib.dwn_profile_collect(i, C.byref(ms), C.byref(n)), "profile_collect")
+            fam_all[name] = (ms.value, n.value)
+        L.check(L.lib.dwn_profile_enable(0, local_rank), "profile_disable")
+    if world > 1:
+        dist.barrier()
     # SURVEY.md §8d asks for both figures: the same steps without optimizer / EMA (forward + loss + backward only)
     fwd_bwd_clips = None
     if world == 1 and not args.no_fwd_bwd and not args.distill:
@@ -260,39 +321,68 @@ def main():
         clips = args.batch * world * args.steps
         value = clips / elapsed
         esize = 2 if args.dtype == "bf16" else 4
-        shapes = block_shapes(args.batch, args.frames, args.height, args.width, expansion)
-        alg = family_algorithmic_elems(shapes)
+        fused = [i for i, c in enumerate(CORE_FEATURES)
+                 if L.lib.dwn_pw_bwd_fused_supported(L.DWN_BF16 if args.dtype == "bf16" else L.DWN_F32,
+                                                     128, c * expansion, c)]
+        alg, flops = family_work(args.batch, args.frames, args.height, args.width, expansion, num_neurons, fused, esize)
+        mfma_peak = MFMA_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected inside the timed run):
+        # profiles/<round>_pmc_traffic.json holds them for the default metric shape together with the hash of the
+        # library they were measured on; a different build makes them stale and they are not reported
+        default_shape = (args.batch, args.frames, args.height, args.width, expansion, args.dtype, args.mice,
+                         args.distill) == (32, 32, 36, 64, 7, "bf16", 1, False)
+        traffic = {}
+        traffic_src, traffic_stale = None, None
+        for tpath in sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"), reverse=True):
+            try:
+                tj = json.loads(tpath.read_text())
+            except ValueError:
+                continue
+            if "lib_sha16" not in tj:
+                continue
+            traffic_stale = tj["lib_sha16"] != lib_sha16()
+            if default_shape and not traffic_stale:
+                traffic = tj["families"]
+                traffic_src = f"profiles/{tpath.name} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; same library build)"
+            break
+
+        def roof_of(fam, ms, n, steps):
+            if n <= 0 or fam not in alg:
+                return None
+            lps = n / steps
+            avg_ms = ms / n
+            bpl = alg[fam] / lps
+            ach = bpl / (avg_ms * 1e-3) / 1e9
+            r = {"kernel": fam, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches_per_step": lps,
+                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(bpl)}
+            if flops.get(fam):
+                tf = flops[fam] / lps / (avg_ms * 1e-3) / 1e12
+                r["mfma"] = {"achieved": round(tf, 1), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(tf / mfma_peak, 4),
+                             "flops_per_launch": int(flops[fam] / lps)}
+                # compute-bound when the arithmetic intensity exceeds the ridge (peak FLOP/s / peak B/s)
+                if flops[fam] / alg[fam] > mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9):
+                    r["bound"] = "mfma"
+            tf_ = traffic.get(fam)
+            if tf_:
+                r["traffic"] = round(tf_["traffic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, 1)
+                r["traffic_bytes_per_launch"] = int(tf_["traffic_bytes_per_launch"])
+                r["traffic_source"] = traffic_src
+            elif traffic_stale:
+                r["traffic_stale"] = True
+            return r
+
         roof = None
         fam = args.roofline_family
-        if fam in fam_ms and fam in alg and fam_ms[fam][1] > 0:
-            ms, n = fam_ms[fam]
-            launches_per_step = n / args.steps
-            bytes_per_launch = alg[fam] * esize / launches_per_step
-            avg_ms = ms / n
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            roof = {"kernel": fam, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "launches_per_step": launches_per_step, "avg_launch_ms": round(avg_ms, 4),
-                    "algorithmic_bytes_per_launch": int(bytes_per_launch)}
-            # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected inside the timed
-            # run): read from the committed summary of the same command at the default metric shape, see
-            # tools/pmc_traffic.py; expressed like `achieved` (bytes per launch / this run's launch duration)
-            default_shape = (args.batch, args.frames, args.height, args.width, expansion, args.dtype, args.mice) == \
-                            (32, 32, 36, 64, 7, "bf16", 1)
-            tpath = ROOT / "profiles" / "r1f_pmc_traffic.json"
-            if default_shape and tpath.exists():
-                try:
-                    tf = json.loads(tpath.read_text())["families"].get(fam)
-                    if tf:
-                        roof["traffic"] = round(tf["traffic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, 1)
-                        roof["traffic_bytes_per_launch"] = int(tf["traffic_bytes_per_launch"])
-                        roof["traffic_source"] = "profiles/r1f_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
-                except (ValueError, KeyError):
-                    pass
+        if fam in fam_ms:
+            roof = roof_of(fam, fam_ms[fam][0], fam_ms[fam][1], args.steps)
+        rooflines = [r for r in (roof_of(k, v[0], v[1], prof_steps) for k, v in fam_all.items()) if r is not None]
         out = {
             "metric": "training clips/sec/GPU (DwiseNeuro fwd+bwd, B=32 T=32 36x64) at 1/2/4/8 GPUs",
             "value_is": "whole-job aggregate clips/s over all n_gpus (per-GPU figure: clips_per_s_per_gpu); a step "
-                        "includes loss, optimizer (fused AdamW), EMA and, for n_gpus > 1, the gradient all-reduce",
+                        "includes loss, optimizer (fused AdamW), EMA and, for n_gpus > 1, the gradient all-reduce; the loss scalar is "
+                        "read back once after the timed region (the reference calls loss.item() every step, "
+                        "argus_models.py:56): no arithmetic is skipped and the host stays ~4x ahead of the GPU",
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -302,9 +392,16 @@ def main():
             "clips_per_s_per_gpu": round(value / world, 2), "loss": round(loss_value, 3),
             "clips_per_s_fwd_bwd_only": None if fwd_bwd_clips is None else round(fwd_bwd_clips, 2),
             "roofline": roof,
+            "rooflines": rooflines,
+            "rooflines_note": "roofline = the dominant family, HIP events inside the timed region; rooflines = every family "
+                              "(HBM fraction of its algorithmic bytes; GEMM families also their MFMA fraction) from "
+                              f"{prof_steps} extra untimed steps with events around every launch",
+            "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
         }
         if args.profile_all:
             out["family_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in fam_ms.items()}
+        elif fam_all:
+            out["family_ms_per_step"] = {k: round(v[0] / prof_steps, 3) for k, v in fam_all.items()}
         if world == 1 and not args.no_cpu_baseline and args.mice == 1 and not args.distill:
             out["cpu_baseline"] = cpu_baseline(args.frames, args.height, args.width, args.expansion)
         print(json.dumps(out), flush=True)

@@ -271,7 +271,8 @@ typedef struct dwn_clip_desc {
 enum {
     DWN_FAM_PW_FWD = 0, DWN_FAM_DWS_FWD, DWN_FAM_DWT_FWD, DWN_FAM_SE_POOL, DWN_FAM_PWL_FWD, DWN_FAM_RESID_FWD,
     DWN_FAM_RESID_BWD, DWN_FAM_PWL_DGRAD, DWN_FAM_PWL_WGRAD, DWN_FAM_BN3_REDUCE, DWN_FAM_DWT_BWD, DWN_FAM_DWS_BWD,
-    DWN_FAM_PW_DGRAD, DWN_FAM_PW_WGRAD, DWN_FAM_COUNT
+    DWN_FAM_PW_DGRAD, DWN_FAM_PW_WGRAD, DWN_FAM_CORTEX_FWD, DWN_FAM_CORTEX_BWD, DWN_FAM_READOUT_FWD, DWN_FAM_READOUT_BWD,
+    DWN_FAM_COUNT
 };
 int dwn_profile_enable(unsigned long long family_mask, int device);
 int dwn_profile_collect(int family, double* total_ms, long long* launches);

@@ -31,7 +31,8 @@ DWN_NREP = 32
 LD_PLAIN, LD_PE, LD_BNACT, LD_AFFINE2, LD_DY3, LD_GATE = 0, 1, 2, 3, 4, 5
 EPI_STORE, EPI_READOUT, EPI_DG, EPI_STORE_CAT, EPI_DH3 = 0, 1, 2, 3, 4
 FAMILIES = ("pw_fwd", "dws_fwd", "dwt_fwd", "se_pool", "pwl_fwd", "resid_fwd", "resid_bwd", "pwl_dgrad", "pwl_wgrad",
-            "bn3_reduce", "dwt_bwd", "dws_bwd", "pw_dgrad", "pw_wgrad")
+            "bn3_reduce", "dwt_bwd", "dws_bwd", "pw_dgrad", "pw_wgrad", "cortex_fwd", "cortex_bwd", "readout_fwd",
+            "readout_bwd")
 
 
 class LoadDesc(C.Structure):

@@ -91,7 +91,7 @@ class MouseModel(Model):
         self.iter_size = int(params.get("iter_size", 1))
         self.amp = bool(params.get("amp", False))
         self.grad_scaler = torch.amp.GradScaler("cuda", enabled=False)   # bf16 needs no loss scaling
-        self.model_ema: Optional[ModelEma] = None
+        self._model_ema: Optional[ModelEma] = None
         self.distill_model: Optional[torch.nn.Module] = None
         self.distill_ratio: float = 0.0
         self._opt_spec = params.get("optimizer", ("AdamW", {"lr": 1e-3}))
@@ -100,10 +100,32 @@ class MouseModel(Model):
         self.prediction_transform = lambda x: x
 
     # -- setup ------------------------------------------------------------------------------------------
+    @property
+    def model_ema(self) -> Optional[ModelEma]:
+        return self._model_ema
+
+    @model_ema.setter
+    def model_ema(self, ema: Optional[ModelEma]):
+        """Plain attribute assignment as in the reference (scripts/train.py:53 ``model.model_ema = ModelEma(...)``), at
+        any time: an optimizer that already exists keeps its Adam moments and step counts and is re-bound to the new EMA
+        copies (or detached when ``ema`` is None)."""
+        self._model_ema = ema
+        if self.optimizer is not None:
+            self._bind_ema_to_optimizer()
+
+    def _bind_ema_to_optimizer(self):
+        ema = self._model_ema
+        if ema is None:
+            self.optimizer.bind_ema(None, self.optimizer.ema_decay)
+            return
+        by_name = dict(ema.ema.named_parameters())
+        ema_params = [by_name[n] for n, p in self.nn_module.named_parameters() if p.requires_grad]
+        self.optimizer.bind_ema(ema_params, ema.decay, owner=ema)
+
     def set_ema(self, decay: float):
-        """train.py:53 — must be called before the first step; the parameter EMA rides in the optimizer kernel."""
+        """train.py:53; the parameter EMA rides in the optimizer kernel (bound now if the optimizer exists, else when it
+        is built)."""
         self.model_ema = ModelEma(self.nn_module, decay=decay)
-        self.optimizer = None
 
     def get_optimizer(self):
         self._ensure_optimizer()
@@ -116,14 +138,18 @@ class MouseModel(Model):
             raise RuntimeError("model has no optimizer (loaded with optimizer=None)")
         oname, okwargs = self._opt_spec
         params = [p for p in self.nn_module.parameters() if p.requires_grad]
-        ema_params = None
-        decay = 0.999
-        if self.model_ema is not None:
-            ema_params = [p for p in self.model_ema.ema.parameters()]
-            decay = self.model_ema.decay
-        self.optimizer = MouseModel.optimizer[oname](params, ema_params=ema_params, ema_decay=decay, **okwargs)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            self.buckets = GradBuckets(self.nn_module)
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if distributed:
+            self.buckets = GradBuckets(self.nn_module)       # broadcasts rank 0's parameters and buffers
+            if self._model_ema is not None:                   # ... so the EMA copy taken earlier must follow (val_step uses it)
+                self._model_ema.set(self.nn_module)
+        self.optimizer = MouseModel.optimizer[oname](params, **okwargs)
+        if self._model_ema is not None:
+            self._bind_ema_to_optimizer()
+        pending = getattr(self, "_pending_optimizer_state", None)
+        if pending is not None:                               # load_model(..., optimizer_state) met a lazily built optimizer
+            self.optimizer.load_state_dict(pending)
+            self._pending_optimizer_state = None
 
     def train(self):
         self.nn_module.train()
@@ -160,7 +186,8 @@ class MouseModel(Model):
             self.buckets.finish()
         self.optimizer.step()
         if self.model_ema is not None:
-            self.model_ema.update(self.nn_module, skip_parameters=True)
+            # the fused AdamW kernel has already lerped the parameter copies iff it is bound to THIS ModelEma
+            self.model_ema.update(self.nn_module, skip_parameters=self.optimizer.folds_ema_of(self.model_ema))
         return {"prediction": self.prediction_transform(deep_detach(prediction)), "target": deep_detach(target),
                 "loss": loss_value}
 

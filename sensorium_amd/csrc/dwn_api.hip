@@ -635,7 +635,7 @@ int dwn_cortex_forward(const dwn_cortex_args* ap, int device, void* stream) {
     }
     GemmNN g = nn_base(ld_plain(a.x, a.Cin), LD_PLAIN, w.wp, Kg, a.y, a.C, M, Ng, Kg, a.groups);
     g.stats = tr ? w.st : nullptr; g.stat_nchan = a.C;
-    TRY(launch_gemm_nn(g, dt, s));
+    PROF(DWN_FAM_CORTEX_FWD, launch_gemm_nn(g, dt, s));
     if (tr) {
         TRY(k_colstats(ld_plain(a.x, a.Cin), LD_PLAIN, M, a.Cin, w.stsc, dt, s));
         TRY(k_bn_finalize_train2(fin_job(w.st, a.C, (double)M, a.bn, a.C), fin_job(w.stsc, a.Cin, (double)M, a.bnsc, a.C),
@@ -669,11 +669,11 @@ int dwn_cortex_backward(const dwn_cortex_args* ap, int device, void* stream) {
                         w.dy, dt, s));
     {
         GemmNN g = nn_base(ld_plain(w.dy, a.C), LD_PLAIN, w.wp, Ng, w.dxmain, a.Cin, M, Kg, Ng, a.groups);
-        TRY(launch_gemm_nn(g, dt, s));
+        PROF(DWN_FAM_CORTEX_BWD, launch_gemm_nn(g, dt, s));
     }
     {
         GemmTN g = tn_base(ld_plain(w.dy, a.C), LD_PLAIN, ld_plain(a.x, a.Cin), LD_PLAIN, M, Ng, Kg, a.dw, Kg, a.groups);
-        TRY(launch_gemm_tn(g, dt, s));
+        PROF(DWN_FAM_CORTEX_BWD, launch_gemm_tn(g, dt, s));
     }
     return k_cortex_bwd_dx(w.dxmain, a.x, a.dout, a.dout_mask, a.dout_mask_ld, w.abcsc, M, a.T, a.Cin, a.C, a.dx, dt, s);
 }
@@ -726,7 +726,8 @@ int dwn_readout_forward(const dwn_readout_args* ap, int device, void* stream) {
     }
     GemmNN g = nn_base(x, kind, w.wp, Kg, nullptr, 0, M, w.Rg, Kg, a.groups);
     g.epi = EPI_READOUT; g.bias = a.bias; g.sp_beta = a.softplus_beta; g.out_nct = a.out; g.Tn = a.T; g.n_valid = a.n_out;
-    return launch_gemm_nn(g, dt, s);
+    PROF(DWN_FAM_READOUT_FWD, launch_gemm_nn(g, dt, s));
+    return 0;
 }
 int dwn_readout_backward(const dwn_readout_args* ap, int device, void* stream) {
     ENTER(device);
@@ -740,7 +741,7 @@ int dwn_readout_backward(const dwn_readout_args* ap, int device, void* stream) {
     LoadDesc dz = ld_plain(w.dz, (i64)a.groups * w.Rp);
     {
         GemmNN g = nn_base(dz, LD_PLAIN, w.wp, w.Rp, a.dx, a.Cin, M, Kg, w.Rp, a.groups);
-        TRY(launch_gemm_nn(g, dt, s));
+        PROF(DWN_FAM_READOUT_BWD, launch_gemm_nn(g, dt, s));
     }
     LoadDesc x = ld_plain(a.x, a.Cin);
     const int kind = LD_PLAIN;
@@ -758,7 +759,8 @@ int dwn_readout_backward(const dwn_readout_args* ap, int device, void* stream) {
     }
     GemmTN g = tn_base(dz, LD_PLAIN, x, kind, M, w.Rg, Kg, a.dw, Kg, a.groups);
     g.R_load = w.Rp;
-    return launch_gemm_tn(g, dt, s);
+    PROF(DWN_FAM_READOUT_BWD, launch_gemm_tn(g, dt, s));
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ loss / optimizer

@@ -349,8 +349,12 @@ def load_model(file_path, nn_module=_KEEP, optimizer=_KEEP, loss=_KEEP, device=_
     model = _MODEL_REGISTRY[name](params)
     sd = change_state_dict_func(state["nn_state_dict"], params)
     model.get_nn_module().load_state_dict(sd, strict=True)
-    if "optimizer_state_dict" in state and getattr(model, "optimizer", None) is not None and optimizer is _KEEP:
-        model.optimizer.load_state_dict(state["optimizer_state_dict"])
+    if "optimizer_state_dict" in state and optimizer is _KEEP and params.get("optimizer") is not None:
+        if getattr(model, "optimizer", None) is not None:
+            model.optimizer.load_state_dict(state["optimizer_state_dict"])
+        else:
+            # models that build their optimizer lazily (MouseModel) restore the Adam moments / step counts when they do
+            model._pending_optimizer_state = state["optimizer_state_dict"]
     model.eval()
     return model
 

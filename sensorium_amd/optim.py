@@ -57,11 +57,27 @@ class FusedAdamWEma(torch.optim.Optimizer):
         self.ema_decay = float(ema_decay)
         self.max_blocks = int(max_blocks)
         self.grad_scale = 1.0
+        self._ema_of = {}
+        self._ema_owner = None          # the ModelEma whose parameter copies ride in this optimizer's kernel (or None)
+        self._tables = {}
+        if ema_params is not None:
+            self.bind_ema(ema_params, ema_decay)
+
+    def bind_ema(self, ema_params: Optional[List[torch.Tensor]], ema_decay: float, owner=None):
+        """(Re)attach the EMA copies of the optimised parameters without touching the Adam moments / step counts:
+        the reference assigns ``model.model_ema`` at any time (scripts/train.py:53), also after the optimizer exists.
+        ``ema_params=None`` detaches (ModelEma.update then lerps the parameters itself)."""
         flat = [p for g in self.param_groups for p in g["params"]]
         if ema_params is not None and len(ema_params) != len(flat):
             raise ValueError("ema_params must align one-to-one with the optimised parameters")
         self._ema_of = {id(p): e for p, e in zip(flat, ema_params)} if ema_params is not None else {}
+        self._ema_owner = owner if ema_params is not None else None
+        self.ema_decay = float(ema_decay)
         self._tables = {}
+
+    def folds_ema_of(self, owner) -> bool:
+        """True when this optimizer's step also updates the parameter EMA of ``owner`` (a ModelEma)."""
+        return owner is not None and self._ema_owner is owner and bool(self._ema_of)
 
     def state_for(self, p):
         return self.state[p]

@@ -179,3 +179,78 @@ def test_pointer_table_cache_uploads_only_on_change():
     assert c is not a
     torch.cuda.synchronize()
     assert bytes(c.cpu().numpy().tobytes()) == e.view(np.uint8).tobytes()
+
+
+def _tiny_batch(golden_dir):
+    z, sd = golden_sd(golden_dir, "tiny_model_train.npz")
+    x = torch.from_numpy(z["x"])
+    targets = [torch.from_numpy(z[f"target_{m}"]) for m in range(2)]
+    return sd, [x, [targets, torch.from_numpy(z["mice_weights"])]]
+
+
+def test_model_ema_assigned_after_optimizer_exists(golden_dir):
+    """scripts/train.py:53 assigns ``model.model_ema = ModelEma(...)`` as a plain attribute, possibly after
+    get_lr()/set_lr() have built the optimizer: the parameter EMA must still move (it rides in the AdamW kernel only when
+    the optimizer is bound to that ModelEma), and re-assigning it later must keep the Adam moments and step counts."""
+    from sensorium_amd.argus_models import MouseModel
+    from sensorium_amd.ema import ModelEma
+    sd, batch = _tiny_batch(golden_dir)
+    model = MouseModel(tiny_params())
+    model.nn_module.load_state_dict(sd, strict=True)
+    assert model.get_lr() == pytest.approx(2.4e-3)                 # builds the optimizer: no EMA exists yet
+    model.model_ema = ModelEma(model.nn_module, decay=0.9)
+    before = {k: v.clone() for k, v in model.model_ema.ema.state_dict().items()}
+    model.train_step(batch)
+    torch.cuda.synchronize()
+    name = "core.blocks.1.conv_pw.0.weight"
+    new_p = model.nn_module.state_dict()[name]
+    exp = orc.ema_update(before[name].cpu(), new_p.cpu(), 0.9)
+    assert rel(model.model_ema.ema.state_dict()[name], exp) < 1e-6
+    assert not torch.equal(model.model_ema.ema.state_dict()[name], before[name])
+    # replace the EMA mid-training: optimizer state survives, the new copy is the one that gets updated
+    p0 = next(iter(model.optimizer.state.values()))
+    step0, m0 = int(p0["step"]), p0["exp_avg"].clone()
+    model.model_ema = ModelEma(model.nn_module, decay=0.5)
+    st = next(iter(model.optimizer.state.values()))
+    assert int(st["step"]) == step0 and torch.equal(st["exp_avg"], m0)
+    before2 = model.model_ema.ema.state_dict()[name].clone()
+    model.train_step(batch)
+    torch.cuda.synchronize()
+    exp2 = orc.ema_update(before2.cpu(), model.nn_module.state_dict()[name].cpu(), 0.5)
+    assert rel(model.model_ema.ema.state_dict()[name], exp2) < 1e-6
+    assert int(next(iter(model.optimizer.state.values()))["step"]) == step0 + 1
+    # detaching: plain AdamW keeps training
+    model.model_ema = None
+    model.train_step(batch)
+
+
+def test_save_load_restores_optimizer_state(golden_dir, tmp_path):
+    """Model.save(optimizer_state=True) -> load_model: MouseModel builds its optimizer lazily, so the Adam moments and step
+    counts are restored when it does; the next step must equal the step an uninterrupted run takes."""
+    from sensorium_amd.argus_models import MouseModel
+    from sensorium_amd.engine import load_model
+    sd, batch = _tiny_batch(golden_dir)
+    model = MouseModel(tiny_params())
+    model.nn_module.load_state_dict(sd, strict=True)
+    model.train_step(batch)
+    model.train_step(batch)
+    path = tmp_path / "ckpt.pth"
+    model.save(path, optimizer_state=True)
+    loaded = load_model(str(path), device="cuda:0")
+    assert loaded.optimizer is None
+    # the moments and step counts come back bit for bit as soon as the optimizer is built
+    opt = loaded.get_optimizer()
+    saved = {n: model.optimizer.state[p] for n, p in model.nn_module.named_parameters()}
+    for n, p in loaded.nn_module.named_parameters():
+        st = opt.state[p]
+        assert int(st["step"]) == 2 and int(saved[n]["step"]) == 2, n
+        assert torch.equal(st["exp_avg"], saved[n]["exp_avg"]) and torch.equal(st["exp_avg_sq"], saved[n]["exp_avg_sq"]), n
+    model.train_step(batch)
+    loaded.train_step(batch)
+    torch.cuda.synchronize()
+    assert int(next(iter(loaded.optimizer.state.values()))["step"]) == 3
+    # same third step up to the run-to-run noise of the atomically accumulated gradients (Adam turns noise on tiny gradients
+    # into visible parameter differences, hence the loose bound; a fresh optimizer would take a first-step-sized jump instead)
+    for (k, a), b in zip(model.nn_module.state_dict().items(), loaded.nn_module.state_dict().values()):
+        if a.is_floating_point() and "running" not in k:
+            assert rel(b, a) < 3e-2, k

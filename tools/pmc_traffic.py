@@ -53,7 +53,11 @@ def main():
             fams[fam] = {"dispatches": n, "read_bytes_per_launch": rd / n, "write_bytes_per_launch": wr / n,
                          "traffic_bytes_per_launch": (rd + wr) / n}
     top = sorted(kernels.items(), key=lambda kv: -(kv[1]["read_bytes"] + kv[1]["write_bytes"]))[:40]
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1",
+    import hashlib
+    from pathlib import Path
+    libp = Path(__file__).resolve().parents[1] / "sensorium_amd" / "csrc" / "libdwiseneuro_hip.so"
+    sha = hashlib.sha256(libp.read_bytes()).hexdigest()[:16] if libp.exists() else None
+    json.dump({"lib_sha16": sha, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1",
                "corrections": "KiB units; reads = 2 x FETCH_SIZE on gfx950; Infinity-Cache hits included",
                "families": fams, "kernels": dict(top)}, open(out, "w"), indent=1)
     for fam, v in fams.items():
