@@ -145,8 +145,9 @@ def test_full_width_model_digest(golden_dir):
         assert abs(got - float(z[key])) <= 5e-3 * float(z[key]), (name, got, float(z[key]))
 
 
-def test_channel_shuffle_and_tile_bit_exact(golden_dir):
-    """Index ops must be bit-exact: a cortex layer with identity-like weights routes integers through shuffle/tile."""
+def test_cortex_layer_matches_oracle_on_integer_input(golden_dir):
+    """A cortex layer with routing-only weights against the oracle (the permutation / tile maps themselves are recovered from
+    the GPU output and compared with the golden maps in tests/test_gpu_index_ops.py)."""
     from sensorium_amd.dwiseneuro import ShuffleLayer
     cin, c, groups = 16, 32, 2
     layer = ShuffleLayer(cin, c, groups=groups).to(dev()).eval()
@@ -162,13 +163,7 @@ def test_channel_shuffle_and_tile_bit_exact(golden_dir):
         out = layer(x.to(dev()), torch.float32).cpu()
     sdict = {"l." + k: v.cpu() for k, v in layer.state_dict().items()}
     ref = orc.cortex_layer(x, "l", sdict, groups, False, None, None)
-    # SiLU of an integer is not an integer, but the *routing* is what is tested: compare exactly against the oracle's
-    # fp32 value computed with the same formula per element, then check the permutation with a pure index probe.
     assert rel(out, ref) < 1e-6
-    perm = orc.shuffle_source_index(c, groups)
-    z = np.load(golden_dir / "index_and_pe.npz")
-    assert np.array_equal(perm, orc.shuffle_source_index(c, groups))
-    assert np.array_equal(z["shuffle_64_2"], orc.shuffle_source_index(64, 2))
 
 
 def test_adamw_ema_multi_matches_reference(golden_dir):
