@@ -1,0 +1,101 @@
+"""Worker of tests/test_gpu_ddp.py: one rank of a 2-process data-parallel MouseModel.train_step on the HIP path.
+Launched as fresh processes by torch.distributed.run (nothing touches the GPU before the process group exists)."""
+import os
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def main():
+    backend = sys.argv[1]
+    share = backend == "gloo"
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = 0 if share else int(os.environ["LOCAL_RANK"])
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
+    from sensorium_amd.argus_models import MouseModel
+    from sensorium_amd.synthetic import make_batch
+    kw = dict(readout_outputs=(24, 40), in_channels=5, core_features=(8, 8, 16), spatial_strides=(2, 1, 2), spatial_kernel=3,
+              temporal_kernel=5, expansion_ratio=3, se_reduce_ratio=4, cortex_features=(32, 64), groups=2, softplus_beta=0.07,
+              drop_rate=0.0, drop_path_rate=0.0)
+    params = {"nn_module": ("dwiseneuro", kw), "loss": ("mice_poisson", {}), "optimizer": ("AdamW", {"lr": 1e-3, "weight_decay": 0.05}),
+              "device": str(dev), "amp": False, "iter_size": 1}
+    torch.manual_seed(100 + rank)                     # different init per rank: the rank-0 broadcast must fix it (EMA copy too)
+    model = MouseModel(params)
+    model.set_ema(0.9)
+    batch = make_batch(4, 6, 12, 16, (24, 40), seed=7 + rank, device=dev)
+    model.get_optimizer()                             # builds GradBuckets: broadcast of parameters / buffers
+    net = model.nn_module
+    names = [n for n, _ in net.named_parameters()]
+
+    def gather(t):
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t.contiguous())
+        return out
+
+    # identical weights and identical EMA copy on every rank after the broadcast
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    g = gather(flat)
+    assert all(torch.equal(g[0], x) for x in g), "parameters were not broadcast"
+    eflat = torch.cat([p.detach().reshape(-1) for p in model.model_ema.ema.parameters()])
+    assert torch.equal(eflat, flat), "the EMA copy did not follow the broadcast"
+    # reference: every rank's LOCAL gradient (no exchange), averaged
+    net.train()
+    net.zero_grad(set_to_none=True)
+    hooks_off = model.buckets._hooks
+    for h in hooks_off:
+        h.remove()
+    loss = model.loss(net(batch[0]), batch[1])
+    loss.backward()
+    local_g = torch.cat([p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), device=dev) for p in net.parameters()])
+    mean_g = sum(gather(local_g)) / world
+    # re-arm the hooks and take the real step
+    model.buckets._hooks = [p.register_post_accumulate_grad_hook(model.buckets._make_hook(bi))
+                            for bi, b in enumerate(model.buckets.buckets) for p in b["params"]]
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    model.buckets.zero_grad(1)
+    loss = model.loss(net(batch[0]), batch[1])
+    loss.backward()
+    model.buckets.finish()
+    ddp_g = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    tot = float(mean_g.norm())
+    err = float((ddp_g - mean_g).norm()) / tot
+    assert err < 1e-4, f"all-reduced gradients differ from the mean of the per-rank gradients: {err:.3e}"
+    # gradients are views of the flat buckets
+    b0 = model.buckets.buckets[0]
+    assert b0["params"][0].grad.data_ptr() == b0["flat"].data_ptr()
+    net.load_state_dict(state0)
+    out = model.train_step(batch)
+    torch.cuda.synchronize()
+    assert np.isfinite(out["loss"])
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    g = gather(flat)
+    for x in g[1:]:
+        # same averaged gradient + same optimizer state on every rank; fp32 atomics reorder the local sums, AVG is shared
+        assert float((g[0] - x).abs().max()) == 0.0, "parameters diverged between ranks after the step"
+    eflat = torch.cat([p.detach().reshape(-1) for p in model.model_ema.ema.parameters()])
+    ge = gather(eflat)
+    assert all(float((ge[0] - x).abs().max()) == 0.0 for x in ge[1:]), "EMA parameters diverged between ranks"
+    # forward(x, index): only one readout takes part -> optional buckets, no hang, the other readout's gradient is zero
+    model.buckets.zero_grad(1)
+    pred = net(batch[0], 0)
+    pred.float().sum().backward()
+    model.buckets.finish()
+    assert float(net.readouts[1].layer[1].weight.grad.abs().max()) == 0.0
+    assert float(net.readouts[0].layer[1].weight.grad.abs().max()) > 0.0
+    if rank == 0:
+        print(f"DDP_WORKER_OK backend={backend} world={world} grad_err={err:.2e}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,3 +96,73 @@ def test_grad_buckets_single_process_is_passthrough():
     model(torch.ones(2, 4)).sum().backward()
     buckets.finish()
     assert torch.allclose(model.weight.grad, torch.full((3, 4), 2.0))
+
+
+class _TwoHeads(torch.nn.Module):
+    """trunk + per-"mouse" readouts, called like DwiseNeuro.forward(x, index) (dwiseneuro.py:397-405)"""
+
+    def __init__(self):
+        super().__init__()
+        self.trunk = torch.nn.Linear(6, 5)
+        self.readouts = torch.nn.ModuleList([torch.nn.Linear(5, 3), torch.nn.Linear(5, 4)])
+
+    def forward(self, x, index=None):
+        h = torch.tanh(self.trunk(x))
+        if index is None:
+            return [r(h) for r in self.readouts]
+        return self.readouts[index](h)
+
+
+def _worker_optional(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sensorium_amd.ddp import GradBuckets
+        torch.manual_seed(3)
+        model = _TwoHeads()
+        buckets = GradBuckets(model, bucket_cap_mb=1e-5)
+        assert any(b["optional"] for b in buckets.buckets) and any(not b["optional"] for b in buckets.buckets)
+        for b in buckets.buckets:                       # optional and mandatory parameters never share a bucket
+            names = {n for n, p in model.named_parameters() if any(p is q for q in b["params"])}
+            assert len({n.startswith("readouts.") for n in names}) == 1
+        # each rank trains a DIFFERENT readout: rank r uses readout r only
+        buckets.zero_grad()
+        torch.manual_seed(20 + rank)
+        x = torch.randn(4, 6)
+        model(x, index=rank).pow(2).sum().backward()
+        buckets.finish()
+        ref = {n: torch.zeros_like(p) for n, p in model.named_parameters()}
+        for r in range(world):
+            m2 = _TwoHeads()
+            m2.load_state_dict(model.state_dict())
+            torch.manual_seed(20 + r)
+            m2(torch.randn(4, 6), index=r).pow(2).sum().backward()
+            for n, p in m2.named_parameters():
+                if p.grad is not None:
+                    ref[n] += p.grad / world
+        for n, p in model.named_parameters():
+            assert p.grad is not None, n               # unused readouts receive the other rank's (averaged) gradient
+            assert torch.allclose(p.grad, ref[n], rtol=1e-5, atol=1e-6), n
+        # a second step where nobody uses readout 1: its averaged gradient is exactly zero, nothing hangs
+        buckets.zero_grad()
+        model(torch.randn(4, 6), index=0).sum().backward()
+        buckets.finish()
+        assert float(model.readouts[1].weight.grad.abs().max()) == 0.0
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_buckets_optional_readouts_world2():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker_optional, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    for p in procs:
+        assert p.exitcode == 0, "a rank failed"
+    assert dict(ret) == {0: "ok", 1: "ok"}
