@@ -1,10 +1,12 @@
 """Sliding-window trial prediction (reference: src/predictors.py:20-55, scripts/predict.py:24-50, src/indexes.py).
 
-``Predictor.predict_trial`` keeps the reference's contract — inputs ``(5, L, H, W)``, one model evaluation per end
-frame ``index`` over the window ``index-behind : index+1 : step``, accumulate + divide by the overlap count
-("ones" blend weights) — but evaluates ``windows_per_batch`` windows per forward (the windows are independent in
-eval mode: BatchNorm uses running statistics), removes the per-window device->host sync (one copy per trial), and
-accumulates on the device.  ``windows_per_batch=1`` reproduces the reference's launch pattern exactly.
+``Predictor`` keeps the reference's surface — ``Predictor(model_path, device, blend_weights)``,
+``predict_trial(video, behavior, pupil_center, mouse_index)``, one model evaluation per end frame ``index`` over the window
+``index-behind : index+1 : step``, accumulate + divide by the accumulated blend weights — but evaluates
+``windows_per_batch`` windows per forward (the windows are independent in eval mode: BatchNorm uses running statistics),
+removes the per-window device->host sync (one copy per trial) and accumulates on the device in a fixed order.
+``windows_per_batch=1`` reproduces the reference's launch pattern.  ``EnsemblePredictor`` runs all fold models of
+scripts/predict.py:44-50 inside one forward / one captured hipGraph per window batch.
 """
 from __future__ import annotations
 
@@ -36,23 +38,82 @@ class IndexesGenerator:
         return list(range(index - self.behind, index + self.ahead + 1, self.step))
 
 
+def get_blend_weights(name: str, size: int) -> np.ndarray:
+    """src/predictors.py:13-19"""
+    if name == "ones":
+        return np.ones(size, dtype=np.float32)
+    if name == "linear":
+        return np.linspace(0, 1, num=size).astype(np.float32)
+    raise ValueError(f"Blend weights '{name}' is not supported")
+
+
 class Predictor:
-    def __init__(self, model, frame_stack_size: int = 16, frame_stack_step: int = 2, position: str = "last",
-                 windows_per_batch: int = 16, use_graph: bool = False):
-        """``model``: a ``sensorium_amd.argus_models.MouseModel`` (``predict(input, mouse_index)``).
+    def __init__(self, model, device: str = "cuda:0", blend_weights: str = "ones", *, frame_stack_size: Optional[int] = None,
+                 frame_stack_step: Optional[int] = None, position: str = "last", windows_per_batch: int = 16,
+                 use_graph: bool = False):
+        """``model``: a checkpoint path — the reference's constructor ``Predictor(model_path, device, blend_weights)``
+        (src/predictors.py:22-34: ``load_model(path, device=device, optimizer=None, loss=None)``, frame stack and inputs
+        processor read from the stored params) — or an already built ``MouseModel`` together with ``frame_stack_size`` /
+        ``frame_stack_step``.
+        ``windows_per_batch``: windows evaluated per forward (1 = the reference's launch pattern).
         ``use_graph``: capture the eval forward of one full window batch into a hipGraph (torch.cuda.CUDAGraph) per
         (mouse, shape) and replay it — the C-ABI neither allocates nor synchronises, so the ~500 launches of one
-        forward collapse into one graph launch (SURVEY.md §3.3: ~270 tiny forwards per trial per model)."""
+        forward collapse into one graph launch (SURVEY.md 3.3: ~270 tiny forwards per trial per model)."""
+        self.inputs_processor = None
+        if isinstance(model, (str, bytes)) or hasattr(model, "__fspath__"):
+            from .engine import load_model
+            from .inputs import get_inputs_processor
+            model = load_model(model, device=device, optimizer=None, loss=None)
+            params = model.params
+            if "inputs_processor" in params:
+                self.inputs_processor = get_inputs_processor(*params["inputs_processor"])
+            fs = params.get("frame_stack", {})
+            frame_stack_size = fs.get("size", frame_stack_size)
+            frame_stack_step = fs.get("step", frame_stack_step)
+            position = fs.get("position", position)
+            if position != "last":
+                raise ValueError("Predictor: only frame_stack position 'last' is supported (src/predictors.py:29)")
+            rp = params.get("responses_processor", ("identity", {}))
+            if rp[0] != "identity":
+                raise ValueError("Predictor: only the identity responses processor is supported (src/predictors.py:30)")
+        if frame_stack_size is None or frame_stack_step is None:
+            frame_stack_size, frame_stack_step = frame_stack_size or 16, frame_stack_step or 2
         self.model = model
+        self.model.eval()
         self.use_graph = bool(use_graph)
         self._graphs: dict = {}
-        self.indexes_generator = IndexesGenerator(frame_stack_size, frame_stack_step, position)
-        self.blend_weights = np.ones(frame_stack_size, dtype=np.float32)        # get_blend_weights("ones")
+        self.frame_stack_size, self.frame_stack_step = int(frame_stack_size), int(frame_stack_step)
+        self.indexes_generator = IndexesGenerator(self.frame_stack_size, self.frame_stack_step, position)
+        self.blend_weights = get_blend_weights(blend_weights, self.frame_stack_size)
         self.windows_per_batch = max(1, int(windows_per_batch))
 
+    # ---- one window batch: (nw, 5, size, H, W) -> (nw, N, size)
+    def _forward(self, windows: torch.Tensor, mouse_index: int) -> torch.Tensor:
+        return self.model.predict(windows, mouse_index)
+
+    def _make_inputs(self, video, behavior, pupil_center, mouse_index):
+        """Accepts the reference's call ``predict_trial(video, behavior, pupil_center, mouse_index)`` (numpy arrays in the
+        on-disk layout, src/predictors.py:36-41) and the pre-processed form ``predict_trial(inputs, mouse_index)`` with
+        ``inputs`` = (5, L, H, W) as produced by an inputs processor."""
+        if pupil_center is None and mouse_index is None:
+            if behavior is None:
+                raise TypeError("predict_trial: mouse_index is required")
+            return (video if torch.is_tensor(video) else torch.from_numpy(np.asarray(video))), int(behavior)
+        if mouse_index is None:
+            raise TypeError("predict_trial: mouse_index is required")
+        if self.inputs_processor is None:
+            raise RuntimeError("predict_trial(video, behavior, pupil_center, ...) needs an inputs processor: build the "
+                               "Predictor from a checkpoint path or set predictor.inputs_processor")
+        return self.inputs_processor(video, behavior, pupil_center), int(mouse_index)
+
     @torch.no_grad()
-    def predict_trial(self, inputs: torch.Tensor, mouse_index: int, num_neurons: Optional[int] = None) -> np.ndarray:
-        """``inputs``: (5, L, H, W) already produced by the inputs processor (src/inputs.py). Returns (N, L) fp32."""
+    def predict_trial(self, video, behavior=None, pupil_center=None, mouse_index: Optional[int] = None,
+                      num_neurons: Optional[int] = None) -> np.ndarray:
+        """Returns (N, L) fp32: every window ending at frame ``index`` adds its prediction to the frames it covers, and the
+        sum is divided by the accumulated blend weights (src/predictors.py:43-55; like the reference, the predictions themselves
+        are not multiplied by the blend weights).  Accumulation happens on the device, one deterministic pass per window
+        position (frames are distinct within a pass), one device-to-host copy per trial."""
+        inputs, mouse_index = self._make_inputs(video, behavior, pupil_center, mouse_index)
         gen = self.indexes_generator
         device = self.model.device
         inputs = inputs.to(device)
@@ -60,6 +121,7 @@ class Predictor:
         ends = list(range(gen.behind, length - gen.ahead))
         responses = None
         counts = torch.zeros(length, dtype=torch.float32, device=device)
+        bw = torch.from_numpy(self.blend_weights).to(device)
         for i in range(0, len(ends), self.windows_per_batch):
             chunk = ends[i:i + self.windows_per_batch]
             idx = torch.tensor([gen.make_indexes(e) for e in chunk], device=device)          # [nw, size]
@@ -67,18 +129,18 @@ class Predictor:
             if self.use_graph and len(chunk) == self.windows_per_batch:
                 pred = self._graph_forward(windows, mouse_index)
             else:
-                pred = self.model.predict(windows, mouse_index)                              # (nw, N, size)
+                pred = self._forward(windows, mouse_index)                                   # (nw, N, size)
             if responses is None:
                 responses = torch.zeros(pred.shape[1], length, dtype=torch.float32, device=device)
-            flat_idx = idx.reshape(-1)
-            responses.index_add_(1, flat_idx, pred.permute(1, 0, 2).reshape(pred.shape[1], -1).float())
-            counts.index_add_(0, flat_idx, torch.ones_like(flat_idx, dtype=torch.float32))
+            pred = pred.float()
+            for j in range(idx.shape[1]):                 # window position j: the nw frames idx[:, j] are distinct
+                responses.index_add_(1, idx[:, j], pred[:, :, j].t())
+                counts.index_add_(0, idx[:, j], bw[j].expand(idx.shape[0]))
         if responses is None:
             n = num_neurons if num_neurons is not None else 0
             return np.zeros((n, length), dtype=np.float32)
         responses /= counts.clamp(min=1.0)
         return responses.cpu().numpy()
-
 
     def _graph_forward(self, windows: torch.Tensor, mouse_index: int) -> torch.Tensor:
         key = (mouse_index, tuple(windows.shape), windows.dtype)
@@ -88,11 +150,11 @@ class Predictor:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                      # warm-up outside the capture (allocator, lazy loads)
-                self.model.predict(static_in, mouse_index)
+                self._forward(static_in, mouse_index)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                static_out = self.model.predict(static_in, mouse_index)
+                static_out = self._forward(static_in, mouse_index)
             entry = (graph, static_in, static_out)
             self._graphs[key] = entry
         graph, static_in, static_out = entry
@@ -101,7 +163,36 @@ class Predictor:
         return static_out
 
 
-def ensemble_predict_trial(predictors: Sequence[Predictor], inputs: torch.Tensor, mouse_index: int) -> np.ndarray:
-    """Mean over fold models (reference: scripts/predict.py:44-50)."""
+class EnsemblePredictor(Predictor):
+    """The fold ensemble of scripts/predict.py:44-50 (mean of the fold models' trial predictions) with every fold model
+    evaluated on the same window batch inside ONE forward / ONE captured hipGraph: the window gather, the host loop and the
+    blend are paid once instead of once per fold, and the mean over models is taken on the device (the blend is linear, so
+    mean-then-blend equals the reference's blend-then-mean up to summation order)."""
+
+    def __init__(self, models: Sequence, device: str = "cuda:0", blend_weights: str = "ones", **kw):
+        models = list(models)
+        if not models:
+            raise ValueError("EnsemblePredictor: at least one model")
+        first = Predictor(models[0], device, blend_weights, **kw)
+        self.__dict__.update(first.__dict__)
+        self._graphs = {}
+        members = [first]
+        for m in models[1:]:
+            p = Predictor(m, device, blend_weights, **kw)
+            if (p.frame_stack_size, p.frame_stack_step) != (first.frame_stack_size, first.frame_stack_step):
+                raise ValueError("EnsemblePredictor: fold models disagree on the frame stack")
+            members.append(p)
+        self.models = [p.model for p in members]
+
+    def _forward(self, windows: torch.Tensor, mouse_index: int) -> torch.Tensor:
+        acc = None
+        for m in self.models:
+            pr = m.predict(windows, mouse_index).float()
+            acc = pr if acc is None else acc + pr
+        return acc / float(len(self.models))
+
+
+def ensemble_predict_trial(predictors: Sequence[Predictor], inputs, mouse_index: int) -> np.ndarray:
+    """Mean over fold models, one predictor after the other (reference: scripts/predict.py:44-50)."""
     preds = [p.predict_trial(inputs, mouse_index) for p in predictors]
     return np.mean(preds, axis=0)
