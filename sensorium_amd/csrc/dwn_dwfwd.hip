@@ -35,7 +35,7 @@ __device__ __forceinline__ uint2 wf_ld8(const bf16_t* p) { return *reinterpret_c
 template <int ST, int LPW>
 __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_walk_kernel(const DwSpatialFwd a, const int R, const int rows_max) {
     typedef bf16_t T;
-    constexpr int NT = 256, CS = 64, NG = 16 / LPW, NPC = ST * LPW + 1, NCW = ST;     // NCW: pair columns a thread stages
+    constexpr int NT = 256, CS = 64, NG = 16 / LPW, NPC = ST * LPW + 1;
     constexpr int NWC = ST == 1 ? 4 : 2;
     __shared__ float lstat[2 * CS];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -111,13 +111,12 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_walk_kernel(const
         const int nro = (Hout - ho0 < R) ? Hout - ho0 : R;
         const int hi_first = ho0 * ST - 1;
         const int rows_in = (nro - 1) * ST + 3;
-        // ---------------- stage SiLU(BN1(y1)), x-pair-packed, zero halo: own pair column(s) for every row
-        {
+        // ---------------- stage SiLU(BN1(y1)), x-pair-packed, zero halo: own pair column for every row
+        if constexpr (ST == 1) {
             const T* in0 = inp + (i64)psafe * Hin * Win * a.in.ld + chs;
-            constexpr int NB = ST == 1 ? 4 : 2;
-#pragma unroll
-            for (int cw = 0; cw < NCW; ++cw) {
-                const int kc = jj * NCW + cw;                                   // pair column: pixels wi = 2kc-1, 2kc
+            constexpr int NB = 4;
+            {
+                const int kc = jj;                                              // pair column: pixels wi = 2kc-1, 2kc
                 const unsigned cmask = (kc > 0 ? 0x0000ffffu : 0u) | 0xffff0000u;
                 const unsigned colhi = (unsigned)(2 * kc) * (unsigned)a.in.ld;
                 const unsigned lodelta = kc > 0 ? (unsigned)a.in.ld : 0u;
@@ -155,6 +154,72 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_walk_kernel(const
                 const unsigned m = okr ? 0x0000ffffu : 0u;
                 o.x &= m; o.y &= m; o.z &= m; o.w &= m;
                 *reinterpret_cast<uint4*>(tplane + r * rowdw + (NPC - 1) * CS) = o;
+            }
+        } else {
+            // stride 2 stages four input pixels per output: 16-byte loads (8 channels per staging lane, 32 lanes = one lane
+            // per pair column), twice the bytes per load instruction and half the per-item overhead of the 4-channel role
+            constexpr int SLW = 2 * LPW;                                       // staging lanes per plane row
+            const int scv = tid & 7, spl = tid >> 3;
+            const int sgrp = spl / SLW, kc = spl % SLW;
+            const int splane = pg * NG + sgrp;
+            const int sch = c0 + scv * 8;
+            const bool svalid = splane < a.planes && sch < a.C;
+            const int schs = sch < a.C ? sch : 0;
+            const T* in0 = inp + (i64)(splane < a.planes ? splane : 0) * Hin * Win * a.in.ld + schs;
+            wf_f2_t s8[4], t8[4];
+            {
+                float sf[8], tf[8];
+                ldc4(a.in.v1 + schs, sf); ldc4(a.in.v1 + schs + 4, sf + 4);
+                ldc4(a.in.v2 + schs, tf); ldc4(a.in.v2 + schs + 4, tf + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { s8[i] = wf_f2_t{sf[2 * i], sf[2 * i + 1]}; t8[i] = wf_f2_t{tf[2 * i], tf[2 * i + 1]}; }
+            }
+            auto act_pack8 = [&](const uint4& rlo, const uint4& rhi, const unsigned m, unsigned* dst) {
+                const unsigned wa[4] = {rlo.x, rlo.y, rlo.z, rlo.w}, wb[4] = {rhi.x, rhi.y, rhi.z, rhi.w};
+                unsigned o[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const wf_f2_t ya = wf_f2_t{__uint_as_float(wa[i] << 16), __uint_as_float(wa[i] & 0xffff0000u)};
+                    const wf_f2_t yb = wf_f2_t{__uint_as_float(wb[i] << 16), __uint_as_float(wb[i] & 0xffff0000u)};
+                    const wf_f2_t ha = ya * s8[i] + t8[i], hb = yb * s8[i] + t8[i];
+                    const wf_f2_t za = ha * wf_f2_t{sigmoidf_(ha.x), sigmoidf_(ha.y)};
+                    const wf_f2_t zb = hb * wf_f2_t{sigmoidf_(hb.x), sigmoidf_(hb.y)};
+                    o[2 * i] = pk_bf16(za.x, zb.x) & m;
+                    o[2 * i + 1] = pk_bf16(za.y, zb.y) & m;
+                }
+                reinterpret_cast<uint4*>(dst)[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                reinterpret_cast<uint4*>(dst)[1] = make_uint4(o[4], o[5], o[6], o[7]);
+            };
+            unsigned* splane_t = tile + sgrp * rows_max * rowdw + scv * 8;
+            constexpr int NB = 4;
+            {
+                const unsigned cmask = (kc > 0 ? 0x0000ffffu : 0u) | 0xffff0000u;
+                const unsigned colhi = (unsigned)(2 * kc) * (unsigned)a.in.ld;
+                const unsigned lodelta = kc > 0 ? (unsigned)a.in.ld : 0u;
+                unsigned* tcol = splane_t + kc * CS;
+                for (int r0 = 0; r0 < rows_in; r0 += NB) {
+                    uint4 rr[NB][2];
+                    bool ok[NB];
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        const int hi = hi_first + r0 + u;
+                        ok[u] = svalid && r0 + u < rows_in && (unsigned)hi < (unsigned)Hin;
+                        const unsigned off = ok[u] ? (unsigned)hi * inrow + colhi : lodelta;
+                        rr[u][1] = *reinterpret_cast<const uint4*>(in0 + off);
+                        rr[u][0] = *reinterpret_cast<const uint4*>(in0 + off - lodelta);
+                    }
+#pragma unroll
+                    for (int u = 0; u < NB; ++u)
+                        if (r0 + u < rows_in) act_pack8(rr[u][0], rr[u][1], ok[u] ? cmask : 0u, tcol + (r0 + u) * rowdw);
+                }
+            }
+            const unsigned collast = (unsigned)(Win - 1) * (unsigned)a.in.ld;
+            for (int r = kc; r < rows_in; r += SLW) {
+                const int hi = hi_first + r;
+                const bool okr = svalid && (unsigned)hi < (unsigned)Hin;
+                const unsigned off = okr ? (unsigned)hi * inrow + collast : 0u;
+                const uint4 v = *reinterpret_cast<const uint4*>(in0 + off);
+                act_pack8(v, v, okr ? 0x0000ffffu : 0u, splane_t + r * rowdw + (NPC - 1) * CS);
             }
         }
         __syncthreads();
@@ -275,10 +340,8 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_walk_kernel(const
 bool dw_spatial_fwd_walk_supported(const DwSpatialFwd& a, int dtype) {
     const char* off = getenv("DWN_DWS_WALK_OFF");          // read per call: lets one process A/B the two implementations
     if ((off && off[0] == '1') || dtype != DWN_BF16 || a.ks != 3 || a.C % 8) return false;
-    // stride 2 is built and bit-exact too, but its staging (four input pixels per output, 8-byte loads) measured slower than the
-    // pair kernel's 16-byte / 512-thread staging (36x64: 770 vs 640-750 us): DWN_DWS_FWD_WALK_S2=1 enables it for experiments
-    static const bool s2 = getenv("DWN_DWS_FWD_WALK_S2") != nullptr;
-    if (a.stride != 1 && !(a.stride == 2 && s2)) return false;
+    const char* s2 = getenv("DWN_DWS_FWD_WALK_S2");       // "0": stride 2 through the pair kernel (A/B)
+    if (a.stride != 1 && !(a.stride == 2 && !(s2 && s2[0] == '0'))) return false;
     if (a.Wout != 32 && a.Wout != 16 && a.Wout != 8) return false;
     if (a.Win != a.Wout * a.stride || a.Hout != (a.Hin - 1) / a.stride + 1) return false;
     if ((i64)a.Hin * a.Win * a.in.ld >= (1ll << 31)) return false;

@@ -89,6 +89,13 @@ if __name__ == "__main__":
         for cfg in ((1024, 36, 64, 448, 2), (1024, 18, 32, 448, 1), (1024, 18, 32, 896, 2), (1024, 9, 16, 896, 1), (1024, 9, 16, 1792, 2),
                     (1024, 5, 8, 1792, 1)):
             ok &= run(*cfg)
+    if "s2bands" in which:
+        for rb in (2, 3, 4, 6):
+            run(1024, 36, 64, 448, 2, rows_band=rb)
+        for rb in (3, 5, 9):
+            run(1024, 18, 32, 896, 2, rows_band=rb)
+        for rb in (3, 5):
+            run(1024, 9, 16, 1792, 2, rows_band=rb)
     if "bands" in which:
         for rb in (2, 3, 4, 6):
             run(1024, 36, 64, 448, 2, rows_band=rb)
