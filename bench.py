@@ -74,42 +74,53 @@ MFMA_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md: bf16 dense MFMA ~2.5 P
 MFMA_F32_PEAK_TFLOPS = 157.3       # ... fp32-input MFMA = the fp32 vector rate
 
 
-def family_work(batch, frames, height, width, expansion, readouts, fused_pw_blocks, esize):
-    """Algorithmic work per *step* of every timed kernel family: (bytes moved through HBM, FLOPs).
-    Depth-wise families follow SURVEY.md 8d (read input once + write output once; backward = read x + read dy + write dx);
-    GEMM families count every operand / result of the launches in the family once (2*M*K*N FLOPs per product).
-    `fused_pw_blocks`: blocks whose conv_pw data + weight gradient are one launch (counted under pw_dgrad)."""
-    e = {k: 0 for k in ("dws_fwd", "dwt_fwd", "dws_bwd", "dwt_bwd", "pw_fwd", "pwl_fwd", "pwl_dgrad", "pwl_wgrad",
-                        "pw_dgrad", "pw_wgrad", "se_pool")}
-    f = dict.fromkeys(e, 0)
+def block_work(batch, frames, height, width, expansion, fused_pw_blocks, esize):
+    """Per block: {family: (algorithmic HBM bytes, FLOPs)} of one launch set of that family in that block, plus the block's
+    geometry.  Depth-wise families follow SURVEY.md 8d (read input once + write output once; backward = read x + read dy +
+    write dx); GEMM families count every operand / result once (2*M*K*N FLOPs per product)."""
+    out = []
     h, w = height, width
     for i, st in enumerate(STRIDES):
         # block i: features[i] -> features[i] * expansion -> features[i + 1] (the last block keeps its width), dwiseneuro.py:319-335
         cin, cout = CORE_FEATURES[i], CORE_FEATURES[min(i + 1, len(CORE_FEATURES) - 1)]
         ho, wo = (h - 1) // st + 1, (w - 1) // st + 1
         mi, mo, e_ = batch * frames * h * w, batch * frames * ho * wo, cin * expansion
-        e["dws_fwd"] += mi * e_ + mo * e_
-        e["dwt_fwd"] += 2 * mo * e_
-        e["dws_bwd"] += 2 * mi * e_ + mo * e_
-        e["dwt_bwd"] += 3 * mo * e_
-        e["se_pool"] += 2 * mo * e_
-        e["pw_fwd"] += mi * cin + mi * e_;                 f["pw_fwd"] += 2 * mi * cin * e_
-        e["pwl_fwd"] += mo * e_ + mo * cout;               f["pwl_fwd"] += 2 * mo * e_ * cout
-        e["pwl_dgrad"] += mo * cout + 2 * mo * e_;         f["pwl_dgrad"] += 2 * mo * e_ * cout     # dy4, y3 in; dh3 out
-        e["pwl_wgrad"] += mo * e_ + mo * cout;             f["pwl_wgrad"] += 2 * mo * e_ * cout
+        d = {
+            "dws_fwd": (mi * e_ + mo * e_, 0), "dwt_fwd": (2 * mo * e_, 0), "dws_bwd": (2 * mi * e_ + mo * e_, 0),
+            "dwt_bwd": (3 * mo * e_, 0), "se_pool": (2 * mo * e_, 0),
+            "pw_fwd": (mi * cin + mi * e_, 2 * mi * cin * e_),
+            "pwl_fwd": (mo * e_ + mo * cout, 2 * mo * e_ * cout),
+            "pwl_dgrad": (mo * cout + 2 * mo * e_, 2 * mo * e_ * cout),                           # dy4, y3 in; dh3 out
+            "pwl_wgrad": (mo * e_ + mo * cout, 2 * mo * e_ * cout),
+        }
         if i in fused_pw_blocks:
-            e["pw_dgrad"] += 2 * mi * e_ + 2 * mi * cin;   f["pw_dgrad"] += 4 * mi * cin * e_       # dh1, y1, a0 in; da0 out
+            d["pw_dgrad"] = (2 * mi * e_ + 2 * mi * cin, 4 * mi * cin * e_)                       # dh1, y1, a0 in; da0 out
         else:
-            e["pw_dgrad"] += mi * e_ + 2 * mi * cin;       f["pw_dgrad"] += 2 * mi * (cin + e_) * cin   # K-concat fold
-            e["pw_wgrad"] += 2 * mi * e_ + mi * cin;       f["pw_wgrad"] += 2 * mi * cin * e_
+            d["pw_dgrad"] = (mi * e_ + 2 * mi * cin, 2 * mi * (cin + e_) * cin)                   # K-concat fold
+            d["pw_wgrad"] = (2 * mi * e_ + mi * cin, 2 * mi * cin * e_)
+        out.append({"block": i, "stride": st, "cin": cin, "cmid": e_, "cout": cout, "in_hw": (h, w), "out_hw": (ho, wo),
+                    "m_in": mi, "m_out": mo, "work": {k: (v[0] * esize, v[1]) for k, v in d.items()}})
         h, w = ho, wo
+    return out
+
+
+def family_work(batch, frames, height, width, expansion, readouts, fused_pw_blocks, esize):
+    """Algorithmic work per *step* of every timed kernel family: (bytes moved through HBM, FLOPs) -- block_work summed over
+    the nine blocks, plus the cortex and the readouts.
+    `fused_pw_blocks`: blocks whose conv_pw data + weight gradient are one launch (counted under pw_dgrad)."""
+    e = {k: 0 for k in ("dws_fwd", "dwt_fwd", "dws_bwd", "dwt_bwd", "pw_fwd", "pwl_fwd", "pwl_dgrad", "pwl_wgrad",
+                        "pw_dgrad", "pw_wgrad", "se_pool")}
+    f = dict.fromkeys(e, 0)
+    for blk in block_work(batch, frames, height, width, expansion, fused_pw_blocks, esize):
+        for k, (by, fl) in blk["work"].items():
+            e[k] += by
+            f[k] += fl
     m = batch * frames
     cx = (CORE_FEATURES[-1],) + (1024, 2048, 4096)
-    e["cortex_fwd"] = sum(m * a + m * b for a, b in zip(cx[:-1], cx[1:]))
+    e["cortex_fwd"] = esize * sum(m * a + m * b for a, b in zip(cx[:-1], cx[1:]))
     f["cortex_fwd"] = sum(2 * m * a * b // 2 for a, b in zip(cx[:-1], cx[1:]))                   # groups = 2
     e["cortex_bwd"] = 2 * e["cortex_fwd"]
     f["cortex_bwd"] = 2 * f["cortex_fwd"]
-    e = {k: v * esize for k, v in e.items()}
     npad = [(n + 1) // 2 * 2 for n in readouts]
     e["readout_fwd"] = sum(m * 4096 * esize + 4 * m * n for n in npad)                             # fp32 predictions
     f["readout_fwd"] = sum(2 * m * 2048 * n for n in npad)

@@ -52,6 +52,20 @@ __device__ __forceinline__ uint4 load_op_packed(const LoadDesc& d, i64 row, int 
     }
 }
 
+// LDS-DMA: 64 lanes x 16 bytes land at lds_dst + 16 * lane (lds_dst wave-uniform); the source address is per lane.
+// Invisible to the compiler's s_waitcnt bookkeeping: the consumer waits with an explicit s_waitcnt vmcnt.
+static __device__ __forceinline__ void nn_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// workgroup barrier for LDS hand-offs only (no vector-memory drain: DMA loads and stores stay in flight across it)
+static __device__ __forceinline__ void nn_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------------------
 // NN — persistent: a workgroup owns one N-tile and a contiguous range of M-tiles.
 //   * K <= one k-tile (the point-wise expand convs, K = 64 bf16): the weight tile is loaded once and stays
@@ -81,13 +95,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     // epilogue staging then aliases the A tiles (two workgroups per CU need <= 80 KB each) — the next tile's A rows
     // wait in registers until the epilogue is over, so nothing else touches that memory meanwhile
     constexpr int NKT = SINGLE == 2 ? 2 : 1;
+    // SINGLE == 3: k-loop whose operand tiles arrive by LDS-DMA (global_load_lds_dwordx4, plain loaders, bf16, K % 64 == 0)
+    // into a ring of NST stages: the loads of k-tile s+2 are issued before the MFMAs of k-tile s, across tile boundaries
+    // and under the epilogue, with no staging registers.  One workgroup per CU (131 KB).  For the shapes whose k-loop is a
+    // serial chain of HBM round trips: few M-tiles per workgroup and a long K (blocks 7-8, cortex, readouts).
+    constexpr bool DMA = SINGLE == 3;
+    constexpr int NST = 3;
     constexpr int SA_BYTES = NKT * BM * ROWB, SB_BYTES = NKT * BN * ROWB, SC_BYTES = CROWS * CROW;
+    constexpr int STG_BYTES = SA_BYTES + SB_BYTES;
     constexpr bool ALIAS_C = (NKT == 2 && BN == 128);
     constexpr int R0_BYTES = ALIAS_C ? (SA_BYTES > SC_BYTES ? SA_BYTES : SC_BYTES) : SA_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem_nn[R0_BYTES + SB_BYTES + (ALIAS_C ? 0 : SC_BYTES)];
+    constexpr int SMEM_BYTES = DMA ? NST * STG_BYTES + SC_BYTES : R0_BYTES + SB_BYTES + (ALIAS_C ? 0 : SC_BYTES);
+    __shared__ __attribute__((aligned(16))) unsigned char smem_nn[SMEM_BYTES];
     unsigned char* const sA = smem_nn;
-    unsigned char* const sB = smem_nn + R0_BYTES;
-    unsigned char* const sC = ALIAS_C ? smem_nn : smem_nn + R0_BYTES + SB_BYTES;
+    unsigned char* const sB = smem_nn + (DMA ? SA_BYTES : R0_BYTES);
+    unsigned char* const sC = DMA ? smem_nn + NST * STG_BYTES : (ALIAS_C ? smem_nn : smem_nn + R0_BYTES + SB_BYTES);
     __shared__ float lred[2 * BN];
 
     const int tid = threadIdx.x;
@@ -96,10 +118,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     // XCD-aware order (gridDim.x is a multiple of 8; blocks b and b+8 share an XCD's L2): the N-tiles of one
     // M-range re-read the same A rows, so they get consecutive slots of one XCD.  M-ranges interleave over the XCDs
     // when their count allows it, and the M-tiles are split evenly (range sizes differ by at most one tile).
+    // Per-sample weight matrices (the gated project conv): an XCD takes a CONTIGUOUS run of M-ranges instead, so that its
+    // L2 only ever holds the weights of the few samples it is working on (32 samples x N x K do not fit one L2;
+    // measured -5 % on blocks 4-8).
     const int bid = blockIdx.x;
     const int nranges = (int)(gridDim.x / ntn);
     int nt, mr;
-    if ((nranges & 7) == 0) {
+    if (ntm < ntn) {
+        // few M-tiles, many N-tiles (cortex, readouts: M = batch x frames): the weights are the big operand, so an XCD
+        // takes a contiguous run of N-tiles with ALL their M-ranges -- each weight tile crosses the fabric once
+        const int lid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+        mr = lid % nranges;
+        nt = lid / nranges;
+    } else if ((nranges & 7) == 0 && !g.b_sample_stride) {
         const int jj = bid >> 3;
         nt = jj % ntn;
         mr = (jj / ntn) * 8 + (bid & 7);
@@ -118,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     const int ccol0 = grp * g.N;
     // SINGLE (K <= one k-tile) is a separate instantiation: sharing one loop nest between the resident-B and the
     // k-loop variants made the compiler merge their s_waitcnt scoreboards and drain every prefetch early
-    constexpr bool single = SINGLE != 0;
+    constexpr bool single = SINGLE == 1 || SINGLE == 2;
 
     // Staging is split in two (cdna_hip_programming.md "Async-STAGE split"): load_* only ISSUES the global loads into
     // raw registers; the prologue math, the bounds select and the ds_write happen in store_*, after the MFMAs of the
@@ -224,13 +255,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     const int lr = lane & 15, lg = lane >> 4;
     f32x4_t acc[4][NJ];
 
-    auto mma_tile = [&]() {
+    auto mma_tile = [&](const int stage_off = 0) {
 #pragma unroll
         for (int kb = 0; kb < 2 * NKT; ++kb) {
             uint4 af[4], bfr[NJ];
             const int chunk = (kb & 1) * 4 + lg;
-            const unsigned char* tA = sA + (kb >> 1) * (BM * ROWB);
-            const unsigned char* tB = sB + (kb >> 1) * (BN * ROWB);
+            const unsigned char* tA = sA + stage_off + (kb >> 1) * (BM * ROWB);
+            const unsigned char* tB = sB + stage_off + (kb >> 1) * (BN * ROWB);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int row = wm * 64 + i * 16 + lr;
@@ -273,20 +304,64 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     [[maybe_unused]] int gb3 = -1;
     constexpr bool NEEDY = (EPI == EPI_DG || EPI == EPI_DH3);     // the epilogue reads a second [M][N] tensor (g.y3)
 
+    // epilogue barriers hand over LDS only; the DMA variant must not drain the k-tiles in flight for the next tile
+    auto bar = [&]() {
+        if constexpr (DMA) nn_lds_barrier();
+        else __syncthreads();
+    };
     // flush dgp (sample dg_b) through LDS: one global atomic per column per workgroup
     auto flush_dg = [&]() {
         if (tid < BN) lred[tid] = 0.f;
-        __syncthreads();
+        bar();
         if (ncol < g.N) {
 #pragma unroll
             for (int i = 0; i < KC; ++i) atomicAdd(&lred[ch * KC + i], dgp[i]);
         }
-        __syncthreads();
+        bar();
         if (tid < BN && n0 + tid < g.N && dg_b >= 0) atomicAdd(g.dg + (i64)dg_b * g.dg_ld + n0 + tid, lred[tid]);
-        __syncthreads();
+        bar();
 #pragma unroll
         for (int i = 0; i < KC; ++i) dgp[i] = 0.f;
     };
+
+    // ---- LDS-DMA ring (SINGLE == 3).  A wave's load instruction fills 8 tile rows (64 lanes x 16 B, contiguous in LDS from
+    // a wave-uniform base); the XOR swizzle of the tile layout is applied on the SOURCE side (lane -> column chunk).
+    // Rows past M / N are clamped to the last valid row: their products land in accumulator rows / columns the epilogue
+    // never stores.
+    [[maybe_unused]] int is_mt = mt_beg, is_k = 0, is_st = 0, n_issued = 0, n_done = 0;
+    [[maybe_unused]] const int nk = g.K / BK;
+    [[maybe_unused]] auto dma_issue = [&]() {
+        if constexpr (DMA) {
+            if (is_mt >= mt_end) return;
+            const unsigned lds0 = (unsigned)(size_t)smem_nn + (unsigned)(is_st * STG_BYTES);
+            const int r8 = lane >> 3, kc = (lane & 7) ^ r8;
+            const int m0i = is_mt * BM, k0 = is_k * BK;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int grp8 = wave * 4 + j;
+                int m = m0i + grp8 * 8 + r8;
+                m = m < g.M ? m : g.M - 1;
+                const T* src;
+                if (EPI == EPI_STORE_CAT && k0 >= g.K1) src = reinterpret_cast<const T*>(g.a2) + (i64)m * g.a2_ld + (k0 - g.K1) + kc * KC;
+                else src = Ap + (i64)m * g.a.ld + acol0 + k0 + kc * KC;
+                nn_glds16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)grp8 * 1024u)));
+            }
+            const T* Bt = Bp;
+            if (g.b_sample_stride) Bt += (i64)(m0i / g.b_rows_per_sample) * g.b_sample_stride;
+#pragma unroll
+            for (int j = 0; j < BN / 32; ++j) {
+                const int grp8 = wave * (BN / 32) + j;
+                int n = n0 + grp8 * 8 + r8;
+                n = n < g.N ? n : g.N - 1;
+                nn_glds16(Bt + (i64)n * g.ldb + k0 + kc * KC,
+                          (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)SA_BYTES + (unsigned)grp8 * 1024u)));
+            }
+            ++n_issued;
+            is_st = is_st == NST - 1 ? 0 : is_st + 1;
+            if (++is_k == nk) { is_k = 0; ++is_mt; }
+        }
+    };
+    [[maybe_unused]] int cs_st = 0;                    // ring stage of the k-tile consumed next
 
     if constexpr (single) {
         load_b(0);
@@ -315,7 +390,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                 gb3 = b;
             }
         }
-        if constexpr (single) {
+        if constexpr (DMA) {
+            for (int kt = 0; kt < nk; ++kt) {
+                // this wave's loads of the consumed k-tile have landed once at most the next k-tile's are outstanding
+                // (loads retire in order; the epilogue's younger stores only make the wait stricter)
+                if (n_issued - n_done > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + BN / 32) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                nn_lds_barrier();                               // every wave's part landed; everyone is past the previous MFMAs
+                dma_issue();                                    // k-tile +2 into the stage the previous MFMAs just released
+                mma_tile(cs_st * STG_BYTES);
+                ++n_done;
+                cs_st = cs_st == NST - 1 ? 0 : cs_st + 1;
+            }
+        } else if constexpr (single) {
             if constexpr (HN) load_a((mt + 1) * BM, 0);         // in flight under the MFMAs and the epilogue
             mma_tile();
         } else {
@@ -419,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                         }
                     }
                 }
-                __syncthreads();
+                bar();
                 if constexpr (fast) {
 #pragma unroll
                     for (int it = 0; it < CROWS * CPR / 256; ++it) {
@@ -517,9 +604,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                     const bool last = (pass == NPASS - 1) && (mt + 1 == mt_end);
                     const int b_next = (m_next < g.M ? m_next : g.M - 1) / g.rows_per_sample;
                     if (last || b_next != b_pass || m_next >= g.M) flush_dg();
-                    else __syncthreads();
+                    else bar();
                 } else {
-                    __syncthreads();
+                    bar();
                 }
             }
         }
@@ -529,7 +616,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
             __syncthreads();
         }
     };
-    if constexpr (!single) { load_a(mt_beg * BM, 0); load_b(0, mt_beg * BM); }
+    if constexpr (DMA) { dma_issue(); dma_issue(); }
+    else if constexpr (!single) { load_a(mt_beg * BM, 0); load_b(0, mt_beg * BM); }
     for (int mt = mt_beg; mt < mt_end; ++mt) {
         const int m0_ = mt * BM;
         bool fast = m0_ + BM <= g.M;
@@ -540,6 +628,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
         if constexpr (single) {
             if (mt + 1 < mt_end) { if (fast) tile(mt, T_{}, T_{}); else tile(mt, T_{}, F_{}); }
             else { if (fast) tile(mt, F_{}, T_{}); else tile(mt, F_{}, F_{}); }
+        } else if constexpr (DMA) {
+            if (fast) tile(mt, F_{}, T_{}); else tile(mt, F_{}, F_{});
         } else {
             tile(mt, F_{}, F_{});       // k-loop variant: its prefetches live inside the k loop; one generic copy
         }
@@ -606,6 +696,21 @@ template <int ALD, int EPI> struct HasSingle2 {
     static constexpr bool value = ALD == LD_PLAIN && (EPI == EPI_STORE || EPI == EPI_DG || EPI == EPI_DH3);
 };
 
+// LDS-DMA ring variant (SINGLE == 3): one workgroup per CU with a two-k-tile lead instead of two per CU with a one-k-tile lead.
+// DWN_NN_DMA=0 never, =1 whenever eligible; default: when a workgroup has few M-tiles to amortise its k chains over.
+static bool nn_use_dma(const GemmNN& g, int bn) {
+    static const char* e = getenv("DWN_NN_DMA");
+    if (g.K % 64 != 0 || g.K < 128 || (g.epi == EPI_STORE_CAT && g.K1 % 64 != 0)) return false;
+    if (g.epi == EPI_READOUT) return false;        // softplus + transposed fp32 stores: that epilogue wants a second workgroup on the CU
+    if (e) return e[0] == '1';
+    // measured (profiles/r2_gemm_dma.txt): wins 5-16 % on the gated project conv (per-sample weights, K = 448..1792) and on
+    // K >= 512 products with at most ~5 tiles per CU; loses where K is four k-tiles (the epilogue dominates) and on the
+    // big-M K-concat products
+    if (g.b_sample_stride) return true;
+    const long long tiles = (long long)((g.M + 127) / 128) * ((g.N + bn - 1) / bn) * g.groups;
+    return tiles <= 5 * 256 && g.K >= 512;
+}
+
 template <typename T, int ALD, int EPI>
 static int launch_nn_t(const GemmNN& g, hipStream_t s) {
     constexpr int BK = 128 / (int)sizeof(T);
@@ -620,6 +725,10 @@ static int launch_nn_t(const GemmNN& g, hipStream_t s) {
         static const bool no_s2 = getenv("DWN_NN_NO_S2") != nullptr;
         if (g.K <= 2 * BK && !g.b_sample_stride && !no_s2)
             return n64 ? launch_nn_k<T, ALD, EPI, 64, 2>(g, s) : launch_nn_k<T, ALD, EPI, 128, 2>(g, s);
+    }
+    if constexpr (ALD == LD_PLAIN && TT<T>::IS_BF16) {
+        if (nn_use_dma(g, n64 ? 64 : 128))
+            return n64 ? launch_nn_k<T, ALD, EPI, 64, 3>(g, s) : launch_nn_k<T, ALD, EPI, 128, 3>(g, s);
     }
     return n64 ? launch_nn_k<T, ALD, EPI, 64, 0>(g, s) : launch_nn_k<T, ALD, EPI, 128, 0>(g, s);
 }
