@@ -373,11 +373,16 @@ def main():
                              "flops_per_launch": int(flops[fam] / lps)}
                 # compute-bound when the arithmetic intensity exceeds the ridge (peak FLOP/s / peak B/s)
                 if flops[fam] / alg[fam] > mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9):
-                    r["bound"] = "mfma"
+                    # the headline numbers of a compute-bound family are its MFMA ones; the HBM view moves to "hbm"
+                    r["hbm"] = {k: r[k] for k in ("achieved", "peak", "unit", "frac")}
+                    r.update({"bound": "mfma", **{k: r["mfma"][k] for k in ("achieved", "peak", "unit", "frac")}})
             tf_ = traffic.get(fam)
             if tf_:
-                r["traffic"] = round(tf_["traffic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, 1)
-                r["traffic_bytes_per_launch"] = int(tf_["traffic_bytes_per_launch"])
+                # measured HBM bytes of the family per step (PMC) over this run's launches; `traffic` = the rate they moved at
+                tbl = tf_["traffic_bytes_per_step"] / lps if "traffic_bytes_per_step" in tf_ else tf_["traffic_bytes_per_launch"]
+                r["traffic"] = round(tbl / (avg_ms * 1e-3) / 1e9, 1)
+                r["traffic_bytes_per_launch"] = int(tbl)
+                r["traffic_frac_of_peak"] = round(tbl / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 r["traffic_source"] = traffic_src
             elif traffic_stale:
                 r["traffic_stale"] = True

@@ -14,6 +14,9 @@ import csv
 import json
 import re
 import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
 
 FAMILIES = {
     "dws_bwd": ("dw_spatial_bwd",), "dws_fwd": ("dw_spatial_fwd",), "dwt_bwd": ("dw_temporal_bwd",),
@@ -52,17 +55,39 @@ def main():
             wr = sum(kernels[k]["write_bytes"] for k in ks)
             fams[fam] = {"dispatches": n, "read_bytes_per_launch": rd / n, "write_bytes_per_launch": wr / n,
                          "traffic_bytes_per_launch": (rd + wr) / n}
+    # the bench's own family names (pw_fwd ... pw_wgrad, resid_*): the launches of the last profiled step assigned to
+    # (block, family) from the launch order, as tools/per_block.py does
+    import per_block as pb
+    fstep, wstep = pb.pmc_step(dir_f, "FETCH_SIZE"), pb.pmc_step(dir_w, "WRITE_SIZE")
+    d = Path(dir_f)
+    seq = pb.last_step(list(csv.DictReader(open(d / "p_kernel_trace.csv"))), which=-1)
+    wal = pb.align([n for n, _ in fstep], wstep)
+    if wal is not None:
+        per_step = collections.defaultdict(lambda: [0, 0.0])
+        for (fam, _blk), (_, fb), (_, wb) in zip(pb.classify(seq), fstep, wal):
+            if fam is not None:
+                per_step[fam][0] += 1
+                per_step[fam][1] += 2.0 * fb + wb
+        for fam, (n, by) in per_step.items():
+            fams.setdefault(fam, {})
+            fams[fam].update({"launches_per_step": n, "traffic_bytes_per_step": by})
+            fams[fam].setdefault("traffic_bytes_per_launch", by / n)
+        fams["_step_total"] = {"traffic_bytes_per_step": sum(2.0 * f[1] + w[1] for f, w in zip(fstep, wal)),
+                               "launches_per_step": len(seq)}
     top = sorted(kernels.items(), key=lambda kv: -(kv[1]["read_bytes"] + kv[1]["write_bytes"]))[:40]
     import hashlib
-    from pathlib import Path
     libp = Path(__file__).resolve().parents[1] / "sensorium_amd" / "csrc" / "libdwiseneuro_hip.so"
     sha = hashlib.sha256(libp.read_bytes()).hexdigest()[:16] if libp.exists() else None
     json.dump({"lib_sha16": sha, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1",
                "corrections": "KiB units; reads = 2 x FETCH_SIZE on gfx950; Infinity-Cache hits included",
                "families": fams, "kernels": dict(top)}, open(out, "w"), indent=1)
     for fam, v in fams.items():
-        print(f"{fam:12s} launches {v['dispatches']:4d}  read {v['read_bytes_per_launch'] / 1e6:9.1f} MB  "
-              f"write {v['write_bytes_per_launch'] / 1e6:9.1f} MB per launch")
+        if "dispatches" in v:
+            print(f"{fam:12s} launches {v['dispatches']:4d}  read {v['read_bytes_per_launch'] / 1e6:9.1f} MB  "
+                  f"write {v['write_bytes_per_launch'] / 1e6:9.1f} MB per launch")
+    for fam, v in fams.items():
+        if "traffic_bytes_per_step" in v:
+            print(f"{fam:12s} {v['launches_per_step']:4d} launches/step  {v['traffic_bytes_per_step'] / 1e9:8.3f} GB/step")
 
 
 if __name__ == "__main__":
