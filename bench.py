@@ -294,17 +294,21 @@ def main():
     L.check(L.lib.dwn_profile_enable(0, local_rank), "profile_disable")
     # every other kernel family: HIP events over a few extra, UNTIMED steps (events around every launch perturb the step)
     fam_all, prof_steps = {}, 0
-    if rank == 0 and not args.no_rooflines:
+    if not args.no_rooflines:
+        # every rank takes these steps (a training step contains the gradient all-reduce: rank 0 alone would leave its
+        # collectives unmatched); only rank 0 times its launches
         prof_steps = 3
-        L.check(L.lib.dwn_profile_enable((1 << len(fam_names)) - 1, local_rank), "profile_enable")
+        if rank == 0:
+            L.check(L.lib.dwn_profile_enable((1 << len(fam_names)) - 1, local_rank), "profile_enable")
         for _ in range(prof_steps):
             model.train_step(next_batch(), sync_loss=False)
         torch.cuda.synchronize()
-        for i, name in enumerate(fam_names):
-            ms, n = C.c_double(0), C.c_longlong(0)
-            L.check(L.lib.dwn_profile_collect(i, C.byref(ms), C.byref(n)), "profile_collect")
-            fam_all[name] = (ms.value, n.value)
-        L.check(L.lib.dwn_profile_enable(0, local_rank), "profile_disable")
+        if rank == 0:
+            for i, name in enumerate(fam_names):
+                ms, n = C.c_double(0), C.c_longlong(0)
+                L.check(L.lib.dwn_profile_collect(i, C.byref(ms), C.byref(n)), "profile_collect")
+                fam_all[name] = (ms.value, n.value)
+            L.check(L.lib.dwn_profile_enable(0, local_rank), "profile_disable")
     if world > 1:
         dist.barrier()
     # SURVEY.md §8d asks for both figures: the same steps without optimizer / EMA (forward + loss + backward only)
