@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(LoadDesc dy, const float*
     const unsigned rows = (unsigned)((i64)B * S);          // < 2^31 (checked by the launcher)
     const UDiv32 dS((unsigned)S);
     if (chan_ok) {
-        constexpr int RU = 2;                              // rows in flight per thread
+        constexpr int RU = 4;                              // rows in flight per thread (2: 256 us at the metric shape, latency-bound)
         const unsigned stride = gridDim.x * 32u;
         for (unsigned row0 = blockIdx.x * 32u + pl; row0 < rows; row0 += RU * stride) {
             float g[RU][KC], xv[RU][MAXCIN];
