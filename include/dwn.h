@@ -254,16 +254,20 @@ typedef struct dwn_clip_src {
     int frame_start, frame_step;
     int valid;                       /* 0 = slot unused */
 } dwn_clip_src;
-/* One sample of the batch: `src`, optionally cut-mixed with `mix` (same mouse): rows [bbx1,bbx2) x columns [bby1,bby2)
- * of all five input channels come from `mix` — the reference pastes its "x" range onto the row axis, mixers.py:63 —
- * and the target is one_minus_lam*relu(src) + lam*relu(mix) with lam = box area / (H*W) (mixers.py:64-65), both
- * factors rounded to float by the caller. */
+/* One sample of the batch: `src`, optionally mixed with `mix` (same mouse).
+ * mix_mode DWN_MIX_BOX (CutMix, mixers.py:52-67): rows [bbx1,bbx2) x columns [bby1,bby2) of all five input channels come
+ * from `mix` — the reference pastes its "x" range onto the row axis, mixers.py:63 — and the target is
+ * one_minus_lam*relu(src) + lam*relu(mix) with lam = box area / (H*W) (mixers.py:64-65).
+ * mix_mode DWN_MIX_BLEND (Mixup, mixers.py:22-33): inputs AND target are one_minus_lam*src + lam*mix with the drawn lam.
+ * Both factors are rounded to float by the caller (torch multiplies a float tensor by the scalar cast to float). */
+#define DWN_MIX_BOX 0
+#define DWN_MIX_BLEND 1
 typedef struct dwn_clip_desc {
     dwn_clip_src src, mix;
     int bbx1, bby1, bbx2, bby2;
     float one_minus_lam, lam;
     int mouse;                       /* owner: index into the per-mouse target table */
-    int pad_;
+    int mix_mode;
 } dwn_clip_desc;
 
 /* opt-in kernel-family timer: HIP events recorded on the launch stream around the block-level kernels.

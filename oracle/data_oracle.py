@@ -57,10 +57,11 @@ def responses_to_target(responses: np.ndarray) -> np.ndarray:
     return np.maximum(responses.astype(np.float32), 0.0)
 
 
-def cutmix_draw(rng: np.random.RandomState, height: int, width: int, alpha: float, prob: float
+def cutmix_draw(rng: np.random.RandomState, height: int, width: int, alpha: float, prob: Optional[float]
                 ) -> Optional[Tuple[int, int, int, int]]:
-    """Returns None when the mixer is not used, else (bbx1, bby1, bbx2, bby2) exactly as ``rand_bbox`` clips them."""
-    if not (rng.random_sample() < prob):
+    """Returns None when the mixer is not used, else (bbx1, bby1, bbx2, bby2) exactly as ``rand_bbox`` clips them.
+    ``prob=None``: only ``CutMix.__call__``'s own draws (the mixer was chosen by ``RandomChoiceMixer``, src/mixers.py:77-79)."""
+    if prob is not None and not (rng.random_sample() < prob):
         return None
     lam = rng.beta(alpha, alpha)
     cut_rat = np.sqrt(lam)
@@ -83,6 +84,22 @@ def cutmix_apply(inputs1: np.ndarray, target1: np.ndarray, inputs2: np.ndarray, 
     return inputs, target
 
 
+def mixup_draw(rng: np.random.RandomState, alpha: float, prob: float) -> Optional[float]:
+    """``Mixer.use`` + ``Mixup.__call__``'s draw (src/mixers.py:15-16,30): None when unused, else lam."""
+    if not (rng.random_sample() < prob):
+        return None
+    return float(rng.beta(alpha, alpha))
+
+
+def mixup_apply(inputs1: np.ndarray, target1: np.ndarray, inputs2: np.ndarray, target2: np.ndarray, lam: float
+                ) -> Tuple[np.ndarray, np.ndarray]:
+    """src/mixers.py:31-32 on float32 tensors: torch multiplies by the scalar cast to float32; mul, mul, add rounded
+    separately."""
+    a, b = np.float32(1 - lam), np.float32(lam)
+    return (a * inputs1.astype(np.float32) + b * inputs2.astype(np.float32)).astype(np.float32), \
+        (a * target1.astype(np.float32) + b * target2.astype(np.float32)).astype(np.float32)
+
+
 def mice_sample(mouse_index: int, target: np.ndarray, num_neurons: Sequence[int]) -> Tuple[List[np.ndarray], np.ndarray]:
     temporal = [target.shape[-1]] if target.ndim == 2 else []
     targets = [target if m == mouse_index else np.zeros((n, *temporal), dtype=np.float32)
@@ -101,15 +118,16 @@ def collate(samples):
     return x, (targets, weights)
 
 
-def assemble_batch(trials, picks, num_neurons, size, pad_fill_value, window, boxes):
+def assemble_batch(trials, picks, num_neurons, size, pad_fill_value, window, boxes, lams=None):
     """End-to-end restatement of ``ConcatMiceVideoDataset.__getitem__`` + collate for explicit picks.
 
     trials[mouse][trial] = dict(video (H0,W0,L), behavior (2,L), pupil_center (2,L), responses (N,L));
     picks = [(mouse, trial, end_frame, partner or None)] with partner = (trial, end_frame) of the same mouse;
-    window = (size, step); boxes[i] = cut-mix box or None.
+    window = (size, step); boxes[i] = cut-mix box or None; lams[i] = Mixup factor or None.
     """
     samples = []
-    for (mouse, trial, end, partner), box in zip(picks, boxes):
+    lams = lams if lams is not None else [None] * len(picks)
+    for (mouse, trial, end, partner), box, lam in zip(picks, boxes, lams):
         def one(tr, e):
             d = trials[mouse][tr]
             idx = window_indexes(e, *window)
@@ -119,5 +137,8 @@ def assemble_batch(trials, picks, num_neurons, size, pad_fill_value, window, box
         if box is not None:
             x2, t2 = one(*partner)
             x, t = cutmix_apply(x, t, x2, t2, box)
+        elif lam is not None:
+            x2, t2 = one(*partner)
+            x, t = mixup_apply(x, t, x2, t2, lam)
         samples.append((x, mice_sample(mouse, t, num_neurons)))
     return collate(samples)

@@ -29,6 +29,70 @@ def load_by_path(name, rel):
     return mod
 
 
+def mixup_fixture(ref_inputs, ref_mixers):
+    """tests/golden/data_mixup.npz: ``Mixup`` and ``RandomChoiceMixer([CutMix, Mixup])`` (src/mixers.py:22-33,70-79) driven on
+    seeded synthetic trials; the oracle's restatement is checked against them here."""
+    rng = np.random.default_rng(20231123)
+    out, case = {}, 0
+    for (h0, w0, size, fill, vid_dtype) in [(36, 64, (64, 64), 0.0, np.uint8), (9, 13, (16, 12), 3.5, np.float32)]:
+        length, n = 40, 11
+        trial = []
+        for _ in range(2):
+            video = rng.integers(0, 256, size=(h0, w0, length)).astype(vid_dtype)
+            beh = (rng.normal(size=(2, length)) * 10 + 20).astype(np.float32)
+            pup = (rng.normal(size=(2, length)) * 20 + 90).astype(np.float32)
+            resp = (rng.normal(size=(n, length)) * 5).astype(np.float32)
+            trial.append((video, beh, pup, resp))
+        proc = ref_inputs.StackInputsProcessor(size=size, pad_fill_value=fill)
+        idx = (dorc.window_indexes(35, 8, 2), dorc.window_indexes(29, 8, 2))
+        s = []
+        for (video, beh, pup, resp), ix in zip(trial, idx):
+            s.append((proc(video[..., ix], beh[..., ix], pup[..., ix]), torch.relu(torch.from_numpy(resp[..., ix].astype(np.float32)))))
+        mixup = ref_mixers.Mixup(alpha=0.4, prob=0.7)
+        choice = ref_mixers.RandomChoiceMixer([ref_mixers.CutMix(alpha=1.0), ref_mixers.Mixup(alpha=0.4)], [0.5, 0.5], prob=1.0)
+        for seed in range(5):
+            key = f"c{case}_s{seed}"
+            np.random.seed(2000 + seed + 31 * case)
+            used = mixup.use()
+            rs = np.random.RandomState(2000 + seed + 31 * case)
+            lam = dorc.mixup_draw(rs, 0.4, 0.7)
+            assert (lam is not None) == bool(used)
+            out[key + "_mixup_used"] = np.array(used)
+            if used:
+                xm, tm = mixup(s[0], s[1])
+                mx, mt = dorc.mixup_apply(s[0][0].numpy(), s[0][1].numpy(), s[1][0].numpy(), s[1][1].numpy(), lam)
+                assert np.array_equal(mx, xm.numpy()) and np.array_equal(mt, tm.numpy()), key
+                out[key + "_mixup_lam"], out[key + "_mixup_x"], out[key + "_mixup_t"] = np.array(lam), xm.numpy(), tm.numpy()
+            # RandomChoiceMixer: use, choice, then the chosen mixer's draws
+            np.random.seed(3000 + seed + 31 * case)
+            assert choice.use()
+            xm, tm = choice(s[0], s[1])
+            rs = np.random.RandomState(3000 + seed + 31 * case)
+            assert rs.random_sample() < 1.0
+            which = int(rs.choice(2, p=[0.5, 0.5]))
+            out[key + "_choice"] = np.array(which)
+            if which == 0:
+                box = dorc.cutmix_draw(rs, s[0][0].shape[-2], s[0][0].shape[-1], 1.0, None)
+                mx, mt = dorc.cutmix_apply(s[0][0].numpy(), s[0][1].numpy(), s[1][0].numpy(), s[1][1].numpy(), box)
+                out[key + "_choice_box"] = np.array(box)
+            else:
+                lam2 = float(rs.beta(0.4, 0.4))
+                mx, mt = dorc.mixup_apply(s[0][0].numpy(), s[0][1].numpy(), s[1][0].numpy(), s[1][1].numpy(), lam2)
+                out[key + "_choice_lam"] = np.array(lam2)
+            assert np.array_equal(mx, xm.numpy()) and np.array_equal(mt, tm.numpy()), key
+            out[key + "_choice_x"], out[key + "_choice_t"] = xm.numpy(), tm.numpy()
+        for i, (video, beh, pup, resp) in enumerate(trial):
+            out[f"c{case}_video{i}"], out[f"c{case}_beh{i}"] = video, beh
+            out[f"c{case}_pup{i}"], out[f"c{case}_resp{i}"] = pup, resp
+        out[f"c{case}_meta"] = np.array([h0, w0, size[0], size[1], 35, 29, 8, 2], dtype=np.int64)
+        out[f"c{case}_fill"] = np.array(fill, dtype=np.float32)
+        case += 1
+    out["num_cases"] = np.array(case)
+    path = ROOT / "tests" / "golden" / "data_mixup.npz"
+    np.savez_compressed(path, **out)
+    print("wrote", path, path.stat().st_size, "bytes")
+
+
 def main():
     ref_inputs = load_by_path("ref_inputs", "src/inputs.py")
     ref_mixers = load_by_path("ref_mixers", "src/mixers.py")
@@ -80,6 +144,7 @@ def main():
         out[f"c{case}_meta"] = np.array([h0, w0, size[0], size[1], 35, 29, 8, 2], dtype=np.int64)
         out[f"c{case}_fill"] = np.array(fill, dtype=np.float32)
         case += 1
+    mixup_fixture(ref_inputs, ref_mixers)
     out["num_cases"] = np.array(case)
     path = ROOT / "tests" / "golden" / "data_pipeline.npz"
     np.savez_compressed(path, **out)

@@ -144,7 +144,7 @@ class ClipSrc(C.Structure):
 
 class ClipDesc(C.Structure):
     _fields_ = [("src", ClipSrc), ("mix", ClipSrc), ("bbx1", c_i), ("bby1", c_i), ("bbx2", c_i), ("bby2", c_i),
-                ("one_minus_lam", c_f), ("lam", c_f), ("mouse", c_i), ("pad_", c_i)]
+                ("one_minus_lam", c_f), ("lam", c_f), ("mouse", c_i), ("mix_mode", c_i)]
 
 
 class PwBwdArgs(C.Structure):
@@ -158,6 +158,7 @@ class DwSpatialRcFwdArgs(C.Structure):
                 ("stats", c_p), ("rows_band", c_i), ("round_y1", c_i)]
 
 
+MIX_BOX, MIX_BLEND = 0, 1
 VID_U8, VID_F32 = 0, 1
 
 _STRUCTS = {

@@ -11,6 +11,15 @@
 #include "dwn_internal.h"
 #include "dwn_kernels.h"
 
+// hipcc contracts a*b + c into an FMA by default and HIP's __fmul_rn / __fadd_rn are plain operators (a
+// `#pragma clang fp contract(off)` did not stop it either): the blends below must round the two products and the sum
+// separately, as torch's three element-wise kernels do, so every product passes through an opaque register barrier.
+__device__ __forceinline__ float rounded(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ float blend3(float a, float x, float b, float y) { return rounded(a * x) + rounded(b * y); }
+
 namespace {
 
 __device__ __forceinline__ float video_at(const dwn_clip_src& s, long long off) {
@@ -19,7 +28,9 @@ __device__ __forceinline__ float video_at(const dwn_clip_src& s, long long off) 
 
 // One workgroup per (sample b, output row y).  Channel 0: the needed [W0][T] slab of the video row is read with the
 // frame axis fastest (it is the contiguous axis on disk), transposed through LDS and written as T contiguous rows.
-// Channels 1-4: per-frame scalars broadcast over the row.  Inside the cut-mix box every channel comes from `mix`.
+// Channels 1-4: per-frame scalars broadcast over the row.  Inside the cut-mix box every channel comes from `mix`;
+// mix_mode == DWN_MIX_BLEND (Mixup, src/mixers.py:22-33): every element of all five channels is
+// one_minus_lam*src + lam*mix (three separately rounded fp32 operations, pad pixels included, like torch).
 __global__ __launch_bounds__(256) void assemble_inputs_kernel(const dwn_clip_desc* __restrict__ descs, int T, int H0,
                                                               int W0, int H, int W, float pad, float* __restrict__ x) {
     extern __shared__ float sm[];
@@ -28,9 +39,11 @@ __global__ __launch_bounds__(256) void assemble_inputs_kernel(const dwn_clip_des
     const int hs = (H - H0) / 2, ws = (W - W0) / 2;
     const int yy = y - hs;
     const bool row_in_video = yy >= 0 && yy < H0;
-    const bool row_in_box = d.mix.valid && y >= d.bbx1 && y < d.bbx2;
+    const bool blend = d.mix.valid && d.mix_mode == DWN_MIX_BLEND;
+    const bool row_in_box = d.mix.valid && !blend && y >= d.bbx1 && y < d.bbx2;
     float* tile = sm;                          // [T][W0 + 1]
     float* scal = sm + (size_t)T * (W0 + 1);   // [2 sources][4 channels][T]
+    float* tile2 = scal + 8 * (size_t)T;       // [T][W0 + 1] of `mix` (blend mode only)
     const int tw = W0 + 1;
     if (row_in_video) {
         for (int i = threadIdx.x; i < W0 * T; i += 256) {
@@ -40,6 +53,10 @@ __global__ __launch_bounds__(256) void assemble_inputs_kernel(const dwn_clip_des
             const dwn_clip_src& s = from_mix ? d.mix : d.src;
             long long f = s.frame_start + (long long)t * s.frame_step;
             tile[t * tw + xx] = video_at(s, ((long long)yy * W0 + xx) * s.length + f);
+            if (blend) {
+                long long f2 = d.mix.frame_start + (long long)t * d.mix.frame_step;
+                tile2[t * tw + xx] = video_at(d.mix, ((long long)yy * W0 + xx) * d.mix.length + f2);
+            }
         }
     }
     for (int i = threadIdx.x; i < 8 * T; i += 256) {
@@ -59,13 +76,17 @@ __global__ __launch_bounds__(256) void assemble_inputs_kernel(const dwn_clip_des
     for (int i = threadIdx.x; i < T * W; i += 256) {
         int xo = i % W, t = i / W;
         int xx = xo - ws;
-        float v = (row_in_video && xx >= 0 && xx < W0) ? tile[t * tw + xx] : pad;
+        const bool in_video = row_in_video && xx >= 0 && xx < W0;
+        float v = in_video ? tile[t * tw + xx] : pad;
+        if (blend) v = blend3(d.one_minus_lam, v, d.lam, in_video ? tile2[t * tw + xx] : pad);
         xb[(long long)t * plane + xo] = v;
     }
     for (int i = threadIdx.x; i < 4 * T * W; i += 256) {
         int xo = i % W, t = (i / W) % T, c = i / (W * T);
         const bool from_mix = row_in_box && xo >= d.bby1 && xo < d.bby2;
-        xb[((long long)(c + 1) * T + t) * plane + xo] = scal[((from_mix ? 4 : 0) + c) * T + t];
+        float v = scal[((from_mix ? 4 : 0) + c) * T + t];
+        if (blend) v = blend3(d.one_minus_lam, v, d.lam, scal[(4 + c) * T + t]);
+        xb[((long long)(c + 1) * T + t) * plane + xo] = v;
     }
 }
 
@@ -98,7 +119,7 @@ __global__ __launch_bounds__(256) void assemble_targets_kernel(const dwn_clip_de
         float v = fmaxf(d.src.responses[n * d.src.length + d.src.frame_start + (long long)t * d.src.frame_step], 0.f);
         if (mixed) {
             float v2 = fmaxf(d.mix.responses[n * d.mix.length + d.mix.frame_start + (long long)t * d.mix.frame_step], 0.f);
-            v = __fadd_rn(__fmul_rn(d.one_minus_lam, v), __fmul_rn(d.lam, v2));
+            v = blend3(d.one_minus_lam, v, d.lam, v2);
         }
         out[i] = v;
     }
@@ -108,7 +129,7 @@ __global__ __launch_bounds__(256) void assemble_targets_kernel(const dwn_clip_de
 
 int k_assemble_inputs(const dwn_clip_desc* descs, int B, int T, int H0, int W0, int H, int W, float pad, float* x,
                       hipStream_t s) {
-    size_t lds = ((size_t)T * (W0 + 1) + 8 * (size_t)T) * sizeof(float);
+    size_t lds = (2 * (size_t)T * (W0 + 1) + 8 * (size_t)T) * sizeof(float);
     if (lds > 64 * 1024) return dwn_set_error(-3, "assemble_inputs: T*(W0+1) tile exceeds 64 KB of LDS");
     hipLaunchKernelGGL(assemble_inputs_kernel, dim3((unsigned)(B * H)), dim3(256), lds, s, descs, T, H0, W0, H, W, pad, x);
     DWN_CHECK_LAUNCH();

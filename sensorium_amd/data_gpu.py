@@ -99,14 +99,16 @@ class ClipPick(NamedTuple):
     mouse: int
     trial: int
     end_frame: int                                        # the window's reference index (position "last": its last frame)
-    mix: Optional[Tuple[int, int]] = None                 # (trial, end_frame) of the cut-mix partner, same mouse
-    box: Optional[Tuple[int, int, int, int]] = None       # (bbx1, bby1, bbx2, bby2) as rand_bbox returns them
+    mix: Optional[Tuple[int, int]] = None                 # (trial, end_frame) of the mixing partner, same mouse
+    box: Optional[Tuple[int, int, int, int]] = None       # CutMix: (bbx1, bby1, bbx2, bby2) as rand_bbox returns them
+    lam: Optional[float] = None                           # Mixup: the drawn blend factor
 
 
-def cutmix_box(rng: np.random.RandomState, height: int, width: int, alpha: float, prob: float
+def cutmix_box(rng: np.random.RandomState, height: int, width: int, alpha: float, prob: Optional[float] = None
                ) -> Optional[Tuple[int, int, int, int]]:
-    """``Mixer.use`` + the draws of ``CutMix.__call__`` / ``rand_bbox`` (src/mixers.py:15-16,36-49,58-62), in order."""
-    if not (rng.random_sample() < prob):
+    """The draws of ``CutMix.__call__`` / ``rand_bbox`` (src/mixers.py:36-49,58-62), in order; with ``prob`` also the
+    preceding ``Mixer.use`` (src/mixers.py:15-16)."""
+    if prob is not None and not (rng.random_sample() < prob):
         return None
     lam = rng.beta(alpha, alpha)
     cut_rat = np.sqrt(lam)
@@ -117,6 +119,42 @@ def cutmix_box(rng: np.random.RandomState, height: int, width: int, alpha: float
     clip = lambda v, hi: int(min(max(v, 0), hi))          # noqa: E731
     return clip(cx - cut_w // 2, width), clip(cy - cut_h // 2, height), clip(cx + cut_w // 2, width), \
         clip(cy + cut_h // 2, height)
+
+
+def parse_mixer(spec) -> Optional[dict]:
+    """Normalise a mixer description: ``{"alpha", "prob"}`` (the ``cutmix`` entry of configs/true_batch_001.py:64-67),
+    ``("cutmix" | "mixup", {...})`` or ``("random_choice", {"mixers": [...], "choice_probs": [...], "prob": p})``
+    — the three classes of src/mixers.py."""
+    if spec is None:
+        return None
+    if isinstance(spec, dict) and "kind" not in spec:
+        spec = ("cutmix", spec)
+    if isinstance(spec, dict):
+        return spec
+    kind, params = spec
+    params = dict(params)
+    if kind == "cutmix":
+        return dict(kind="cutmix", alpha=float(params.get("alpha", 1.0)), prob=float(params.get("prob", 1.0)))
+    if kind == "mixup":
+        return dict(kind="mixup", alpha=float(params.get("alpha", 0.4)), prob=float(params.get("prob", 1.0)))
+    if kind == "random_choice":
+        subs = [parse_mixer(m) for m in params["mixers"]]
+        probs = [float(p) for p in params["choice_probs"]]
+        if len(subs) != len(probs) or not subs:
+            raise ValueError("random_choice: one probability per mixer")
+        return dict(kind="random_choice", mixers=subs, choice_probs=probs, prob=float(params.get("prob", 1.0)))
+    raise ValueError(f"unknown mixer {kind!r}")
+
+
+def mixer_call(rng: np.random.RandomState, mixer: dict, height: int, width: int):
+    """The random draws of ``mixer.__call__`` (after ``use`` and after the partner sample was drawn, src/datasets.py:126-128):
+    returns (box, lam) — a CutMix box or a Mixup factor."""
+    if mixer["kind"] == "cutmix":
+        return cutmix_box(rng, height, width, mixer["alpha"]), None
+    if mixer["kind"] == "mixup":
+        return None, float(rng.beta(mixer["alpha"], mixer["alpha"]))                 # src/mixers.py:30
+    index = int(rng.choice(len(mixer["mixers"]), p=mixer["choice_probs"]))            # src/mixers.py:77
+    return mixer_call(rng, mixer["mixers"][index], height, width)
 
 
 class _PinnedRing:
@@ -150,18 +188,21 @@ class BatchAssembler:
     """Builds ``(input, (targets, mice_weights))`` batches on the device from a ``DeviceTrialStore``.
 
     ``num_neurons[m]`` sizes the m-th target tensor (``constants.num_neurons``); ``frame_stack`` / ``size`` /
-    ``pad_fill_value`` / ``cutmix`` are the config entries of configs/true_batch_001.py:49-68.
+    ``pad_fill_value`` / ``cutmix`` are the config entries of configs/true_batch_001.py:49-68; ``mixer`` (instead of
+    ``cutmix``) takes any of the reference's three mixers, see ``parse_mixer``.
     """
 
     def __init__(self, store: DeviceTrialStore, num_neurons: Sequence[int], frame_stack: dict,
-                 size: Tuple[int, int], pad_fill_value: float = 0.0, cutmix: Optional[dict] = None):
+                 size: Tuple[int, int], pad_fill_value: float = 0.0, cutmix: Optional[dict] = None, mixer=None):
         self.store = store
         self.num_neurons = [int(n) for n in num_neurons]
         self.gen = IndexesGenerator(**frame_stack)
         self.window = int(frame_stack["size"])
         self.size = (int(size[0]), int(size[1]))                       # (W, H) like the reference
         self.pad_fill_value = float(pad_fill_value)
-        self.cutmix = dict(cutmix) if cutmix else None
+        if cutmix and mixer is not None:
+            raise ValueError("give either cutmix or mixer")
+        self.mixer = parse_mixer(mixer if mixer is not None else (cutmix or None))
         self._ring = _PinnedRing()
         self._n_dev = torch.tensor(self.num_neurons, dtype=torch.int32, device=store.device)
 
@@ -179,9 +220,12 @@ class BatchAssembler:
         picks = []
         for mouse in mice:
             trial, frame = self._draw_clip(rng, mouse)
-            box = cutmix_box(rng, h, w, **self.cutmix) if self.cutmix else None
-            mix = self._draw_clip(rng, mouse) if box is not None else None
-            picks.append(ClipPick(int(mouse), trial, frame, mix, box))
+            mix = box = lam = None
+            # Mixer.use, then the partner sample, then the mixer's own draws (src/datasets.py:126-128)
+            if self.mixer is not None and rng.random_sample() < self.mixer["prob"]:
+                mix = self._draw_clip(rng, mouse)
+                box, lam = mixer_call(rng, self.mixer, h, w)
+            picks.append(ClipPick(int(mouse), trial, frame, mix, box, lam))
         return picks
 
     def val_picks(self, mouse: int) -> List[ClipPick]:
@@ -228,12 +272,16 @@ class BatchAssembler:
                 raise ValueError(f"mouse {p.mouse}: trial has {t.responses.shape[0]} neurons, expected "
                                  f"{self.num_neurons[p.mouse]}")
             d.mouse = p.mouse
-            d.one_minus_lam, d.lam = 1.0, 0.0
+            d.one_minus_lam, d.lam, d.mix_mode = 1.0, 0.0, L.MIX_BOX
             if p.box is not None:
                 self._fill_src(d.mix, p.mouse, p.mix[0], p.mix[1], with_targets, h0w0)
                 d.bbx1, d.bby1, d.bbx2, d.bby2 = (int(v) for v in p.box)
                 lam = (d.bbx2 - d.bbx1) * (d.bby2 - d.bby1) / (H * W)          # python float, like mixers.py:64
                 d.one_minus_lam, d.lam = float(np.float32(1 - lam)), float(np.float32(lam))
+            elif p.lam is not None:                                                # Mixup (src/mixers.py:30-32)
+                self._fill_src(d.mix, p.mouse, p.mix[0], p.mix[1], with_targets, h0w0)
+                d.mix_mode = L.MIX_BLEND
+                d.one_minus_lam, d.lam = float(np.float32(1 - p.lam)), float(np.float32(p.lam))
         x = torch.empty(B, 5, T, H, W, dtype=torch.float32, device=dev)
         targets = weights = None
         raw = bytes(descs)

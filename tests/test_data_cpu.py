@@ -66,6 +66,72 @@ def test_host_cutmix_box_matches_oracle_draws():
     assert 60 < n_used < 140
 
 
+def _samples(k):
+    s = []
+    for d, e in zip(k["trials"], k["ends"]):
+        idx = dorc.window_indexes(e, *k["window"])
+        s.append((dorc.stack_inputs(d["video"][..., idx], d["behavior"][..., idx], d["pupil_center"][..., idx],
+                                    k["size"], k["fill"]), dorc.responses_to_target(d["responses"][..., idx])))
+    return s
+
+
+def test_oracle_matches_reference_mixup_and_random_choice(golden_dir):
+    """Mixup / RandomChoiceMixer([CutMix, Mixup]) of src/mixers.py:22-33,70-79 (tests/golden/data_mixup.npz)."""
+    gold = np.load(golden_dir / "data_mixup.npz")
+    n_mix = n_box = n_lam = 0
+    for c in range(int(gold["num_cases"])):
+        k = _case(gold, c)
+        s = _samples(k)
+        for seed in range(5):
+            key = f"c{c}_s{seed}"
+            lam = dorc.mixup_draw(np.random.RandomState(2000 + seed + 31 * c), 0.4, 0.7)
+            assert (lam is not None) == bool(gold[key + "_mixup_used"])
+            if lam is not None:
+                assert lam == float(gold[key + "_mixup_lam"])
+                x, t = dorc.mixup_apply(s[0][0], s[0][1], s[1][0], s[1][1], lam)
+                assert np.array_equal(x, gold[key + "_mixup_x"]) and np.array_equal(t, gold[key + "_mixup_t"])
+                n_mix += 1
+            rs = np.random.RandomState(3000 + seed + 31 * c)
+            assert rs.random_sample() < 1.0                                   # Mixer.use
+            which = int(rs.choice(2, p=[0.5, 0.5]))
+            assert which == int(gold[key + "_choice"])
+            if which == 0:
+                box = dorc.cutmix_draw(rs, k["size"][1], k["size"][0], 1.0, None)
+                assert box == tuple(int(v) for v in gold[key + "_choice_box"])
+                x, t = dorc.cutmix_apply(s[0][0], s[0][1], s[1][0], s[1][1], box)
+                n_box += 1
+            else:
+                lam2 = float(rs.beta(0.4, 0.4))
+                assert lam2 == float(gold[key + "_choice_lam"])
+                x, t = dorc.mixup_apply(s[0][0], s[0][1], s[1][0], s[1][1], lam2)
+                n_lam += 1
+            assert np.array_equal(x, gold[key + "_choice_x"]) and np.array_equal(t, gold[key + "_choice_t"])
+    assert n_mix >= 5 and n_box >= 2 and n_lam >= 2
+
+
+def test_host_mixer_draws_follow_the_reference_order():
+    """BatchAssembler.draw_train_picks: sample, Mixer.use, partner sample, then the mixer's own draws (datasets.py:121-129)."""
+    from sensorium_amd.data_gpu import mixer_call, parse_mixer
+    spec = parse_mixer(("random_choice", {"mixers": [("cutmix", {"alpha": 1.0}), ("mixup", {"alpha": 0.4})],
+                                          "choice_probs": [0.5, 0.5], "prob": 1.0}))
+    n_box = n_lam = 0
+    for seed in range(100):
+        rs, ro = np.random.RandomState(seed), np.random.RandomState(seed)
+        box, lam = mixer_call(rs, spec, 36, 64)
+        which = int(ro.choice(2, p=[0.5, 0.5]))
+        if which == 0:
+            assert lam is None and box == dorc.cutmix_draw(ro, 36, 64, 1.0, None)
+            n_box += 1
+        else:
+            assert box is None and lam == float(ro.beta(0.4, 0.4))
+            n_lam += 1
+    assert n_box > 25 and n_lam > 25
+    assert parse_mixer({"alpha": 1.0, "prob": 0.5}) == dict(kind="cutmix", alpha=1.0, prob=0.5)
+    assert parse_mixer(None) is None
+    with pytest.raises(ValueError):
+        parse_mixer(("blur", {}))
+
+
 def test_mice_sample_and_collate_structure():
     t = np.arange(12, dtype=np.float32).reshape(3, 4)
     targets, w = dorc.mice_sample(1, t, (2, 3, 5))

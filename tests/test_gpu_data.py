@@ -54,6 +54,65 @@ def test_assembly_matches_reference_golden(golden_dir, compact):
     assert checked >= 12
 
 
+@pytest.mark.parametrize("compact", [True, False])
+def test_mixup_and_random_choice_match_reference_golden(golden_dir, compact):
+    """Mixup (whole-tensor blend of inputs and targets) and RandomChoiceMixer([CutMix, Mixup]) — src/mixers.py:22-33,70-79 —
+    bit-exact against tests/golden/data_mixup.npz (reference outputs)."""
+    from sensorium_amd.data_gpu import BatchAssembler, ClipPick, DeviceTrialStore
+    gold = np.load(golden_dir / "data_mixup.npz")
+    checked = 0
+    for c in range(int(gold["num_cases"])):
+        h0, w0, sw, sh, e0, e1, size, step = (int(v) for v in gold[f"c{c}_meta"])
+        store = DeviceTrialStore(dev())
+        for i in range(2):
+            store.add_trial(0, gold[f"c{c}_video{i}"], gold[f"c{c}_beh{i}"], gold[f"c{c}_pup{i}"],
+                            gold[f"c{c}_resp{i}"], compact=compact)
+        asm = BatchAssembler(store, (gold[f"c{c}_resp0"].shape[0],), dict(size=size, step=step, position="last"),
+                             (sw, sh), float(gold[f"c{c}_fill"]))
+        picks, want = [], []
+        for seed in range(5):
+            key = f"c{c}_s{seed}"
+            if bool(gold[key + "_mixup_used"]):
+                picks.append(ClipPick(0, 0, e0, (1, e1), None, float(gold[key + "_mixup_lam"])))
+                want.append((gold[key + "_mixup_x"], gold[key + "_mixup_t"]))
+            if int(gold[key + "_choice"]) == 0:
+                picks.append(ClipPick(0, 0, e0, (1, e1), tuple(int(v) for v in gold[key + "_choice_box"])))
+            else:
+                picks.append(ClipPick(0, 0, e0, (1, e1), None, float(gold[key + "_choice_lam"])))
+            want.append((gold[key + "_choice_x"], gold[key + "_choice_t"]))
+        _poison_allocator()
+        x, (targets, weights) = asm.assemble(picks)
+        torch.cuda.synchronize()
+        x, t = x.cpu().numpy(), targets[0].cpu().numpy()
+        for b, (wx, wt) in enumerate(want):
+            assert np.array_equal(x[b], wx), (c, b)
+            assert np.array_equal(t[b], wt), (c, b)
+            checked += 1
+    assert checked >= 14
+
+
+def test_mixup_batch_drawn_on_the_host_matches_oracle():
+    from sensorium_amd.data_gpu import BatchAssembler
+    rng = np.random.default_rng(9)
+    n_neurons = (11, 29)
+    store, host = _synthetic_store(rng, n_neurons, 9, 13, u8=False)
+    mixer = ("random_choice", {"mixers": [("cutmix", {"alpha": 1.0}), ("mixup", {"alpha": 0.4})],
+                               "choice_probs": [0.4, 0.6], "prob": 0.8})
+    asm = BatchAssembler(store, n_neurons, dict(size=8, step=2, position="last"), (16, 12), 2.5, mixer=mixer)
+    picks = asm.draw_train_picks(np.random.RandomState(11), [0, 1, 1, 0, 1, 0, 0, 1, 1, 0, 1, 0])
+    assert sum(p.box is not None for p in picks) >= 1 and sum(p.lam is not None for p in picks) >= 2
+    assert any(p.mix is None for p in picks)
+    _poison_allocator()
+    x, (targets, weights) = asm.assemble(picks)
+    torch.cuda.synchronize()
+    wx, (wt, ww) = dorc.assemble_batch(host, [(p.mouse, p.trial, p.end_frame, p.mix) for p in picks], n_neurons, (16, 12),
+                                       2.5, (8, 2), [p.box for p in picks], [p.lam for p in picks])
+    assert np.array_equal(x.cpu().numpy(), wx)
+    for m in range(2):
+        assert np.array_equal(targets[m].cpu().numpy(), wt[m]), m
+    assert np.array_equal(weights.cpu().numpy(), ww)
+
+
 def _synthetic_store(rng, n_neurons, h0, w0, trials_per_mouse=3, length=70, u8=True):
     from sensorium_amd.data_gpu import DeviceTrialStore
     store = DeviceTrialStore(dev())
