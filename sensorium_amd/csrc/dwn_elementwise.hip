@@ -1179,35 +1179,73 @@ int k_bn3_bwd_reduce(const LoadDesc& d, const float* coef3, i64 rows, int C, dou
 __global__ __launch_bounds__(256) void pwl_bwd_reduce_kernel(const float* __restrict__ P, const float* __restrict__ gate,
                                                              const float* __restrict__ W, int B, int K, int N,
                                                              float* __restrict__ dW, float* __restrict__ dg) {
-    __shared__ float red[4][4][64];
-    const int nl = threadIdx.x & 63, kl = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + nl, b0 = blockIdx.y * 4;
-    float dgp[4] = {0.f, 0.f, 0.f, 0.f}, gt[4] = {0.f, 0.f, 0.f, 0.f};
+    // thread = (4 consecutive columns, one of 16 k-lanes): 16-byte loads, K/16 iterations with 4 samples in flight each
+    // (the first version walked K/4 rows with scalar loads: 34 us for the 29 MB of block 6)
+    __shared__ float red[4][16][64 + 4];
+    const int nq = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const int n = blockIdx.x * 64 + nq * 4, b0 = blockIdx.y * 4;
+    float dgp[4][4], gt[4][4];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dgp[bb][j] = 0.f; gt[bb][j] = 0.f; }
+    const bool vec = (N & 3) == 0 && n + 3 < N;         // whole 16-byte group inside the row (N % 4 == 0 keeps it aligned)
     const bool nok = n < N;
     if (nok) {
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb)
-            if (b0 + bb < B) gt[bb] = gate[(i64)(b0 + bb) * N + n];
-#pragma unroll 4
-        for (int k = kl; k < K; k += 4) {
-            const float w = W[(i64)k * N + n];
-            float dwa = 0.f;
+            if (b0 + bb < B)
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                const int b = b0 + bb < B ? b0 + bb : B - 1;
-                const float p = P[((i64)b * K + k) * N + n];
-                dgp[bb] = fmaf(w, p, dgp[bb]);
-                dwa = fmaf(gt[bb], p, dwa);          // gt = 0 for the clamped duplicates
+                for (int j = 0; j < 4; ++j)
+                    if (n + j < N) gt[bb][j] = gate[(i64)(b0 + bb) * N + n + j];
+        for (int k = kl; k < K; k += 16) {
+            float w[4], dwa[4] = {0.f, 0.f, 0.f, 0.f}, p[4][4];
+            if (vec) {
+                const float4 w4 = *reinterpret_cast<const float4*>(W + (i64)k * N + n);
+                w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int b = b0 + bb < B ? b0 + bb : B - 1;
+                    const float4 p4 = *reinterpret_cast<const float4*>(P + ((i64)b * K + k) * N + n);
+                    p[bb][0] = p4.x; p[bb][1] = p4.y; p[bb][2] = p4.z; p[bb][3] = p4.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = n + j < N ? W[(i64)k * N + n + j] : 0.f;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int b = b0 + bb < B ? b0 + bb : B - 1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) p[bb][j] = n + j < N ? P[((i64)b * K + k) * N + n + j] : 0.f;
+                }
             }
-            atomicAdd(dW + (i64)k * N + n, dwa);
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dgp[bb][j] = fmaf(w[j], p[bb][j], dgp[bb][j]);
+                    dwa[j] = fmaf(gt[bb][j], p[bb][j], dwa[j]);          // gt = 0 for the clamped duplicates
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (n + j < N) atomicAdd(dW + (i64)k * N + n + j, dwa[j]);
         }
     }
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb) red[bb][kl][nl] = dgp[bb];
+    for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[bb][kl][nq * 4 + j] = dgp[bb][j];
     __syncthreads();
-    const int bb = kl;                                // wave kl finishes sample b0 + kl
-    if (nok && b0 + bb < B)
-        dg[(i64)(b0 + bb) * N + n] = (red[bb][0][nl] + red[bb][1][nl]) + (red[bb][2][nl] + red[bb][3][nl]);
+    {   // 256 threads finish 4 samples x 64 columns: sum over the 16 k-lanes in a fixed order
+        const int bb = threadIdx.x >> 6, nl = threadIdx.x & 63;
+        const int nn = blockIdx.x * 64 + nl;
+        if (nn < N && b0 + bb < B) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += red[bb][q][nl];
+            dg[(i64)(b0 + bb) * N + nn] = t;
+        }
+    }
 }
 int k_pwl_bwd_reduce(const float* P, const float* gate, const float* W, int B, int K, int N, float* dW, float* dg,
                      hipStream_t s) {
@@ -1762,33 +1800,81 @@ __global__ __launch_bounds__(256) void pw_bwd_prep_kernel(const float* w1, const
                                                           float* r3, int nscale, int gx, int gy) {
     const i64 ld = (i64)E + C;
     int bid = blockIdx.x;
+    __shared__ float sA[64][64 + 4], sB[64][64 + 4];
     if (bid < nscale) {
-        const i64 idx = (i64)bid * 256 + threadIdx.x;
-        if (idx < (i64)E * C) {
-            const int k = (int)(idx / C), n = (int)(idx % C);
-            bp[n * ld + k] = from_f<T>(abc[k] * round_t<T>(w1[idx]));
+        // Bp[n][k] = A1[k] * W1[k][n]: a 64 x 64 tile transposed through LDS (reads contiguous along n, writes contiguous along
+        // k; the first version wrote 2-byte elements at a stride of (E + C) elements)
+        const int nkt = (E + 63) / 64;
+        const int k0 = (bid % nkt) * 64, n0 = (bid / nkt) * 64;
+        for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+            const int kl = i >> 6, nl = i & 63;
+            const int k = k0 + kl, n = n0 + nl;
+            sA[kl][nl] = (k < E && n < C) ? abc[k] * round_t<T>(w1[(i64)k * C + n]) : 0.f;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+            const int nl = i >> 6, kl = i & 63;
+            const int k = k0 + kl, n = n0 + nl;
+            if (k < E && n < C) bp[n * ld + k] = from_f<T>(sA[kl][nl]);
         }
         return;
     }
     bid -= nscale;
+    // Gram part: a 64 x 64 tile of G over a 64-row chunk of E, operands staged through LDS (the first version read both W1
+    // columns straight from global memory: 0.9 GB of L1 traffic for 117 MFLOP at C = 256, 63 us)
+    // sA[e][c'] = A2[e]*W1[e][c'], sB[e][c] = W1[e][c]
     const int bx = bid % gx, by = (bid / gx) % gy, bz = bid / (gx * gy);
-    const int cp = bx * 16 + (threadIdx.x >> 4);
-    const int c = by * 16 + (threadIdx.x & 15);
     const int e0 = bz * 64;
-    if (cp < C && c < C) {
-        const float* A2 = abc + E;
-        const float* A3 = abc + 2 * E;
-        float acc = 0.f, acc3 = 0.f;
-#pragma unroll 16
-        for (int i = 0; i < 64; ++i) {            // fixed trip count + clamped index: 16 x 4 independent loads in flight
-            const int e = e0 + i < E ? e0 + i : E - 1;
-            const float on = e0 + i < E ? 1.f : 0.f;
-            const float wc = round_t<T>(w1[(i64)e * C + c]) * on;
-            acc = fmaf(A2[e] * round_t<T>(w1[(i64)e * C + cp]), wc, acc);
-            acc3 = fmaf(A3[e], wc, acc3);
+    const float* A2 = abc + E;
+    const float* A3 = abc + 2 * E;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int el = i >> 6, cl = i & 63;
+        const int e = e0 + el;
+        const int cpg = bx * 64 + cl, cg = by * 64 + cl;
+        const bool eok = e < E;
+        sA[el][cl] = (eok && cpg < C) ? A2[e] * round_t<T>(w1[(i64)e * C + cpg]) : 0.f;
+        sB[el][cl] = (eok && cg < C) ? round_t<T>(w1[(i64)e * C + cg]) : 0.f;
+    }
+    __syncthreads();
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    float acc[4][4], acc3[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc3[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    }
+    const bool do_r3 = bx == 0 && ty == 0;
+#pragma unroll 8
+    for (int el = 0; el < 64; ++el) {             // ascending e with fmaf: the partial sums of the first version, bit for bit
+        const float4 a4 = *reinterpret_cast<const float4*>(&sA[el][ty * 4]);
+        const float4 b4 = *reinterpret_cast<const float4*>(&sB[el][tx * 4]);
+        const float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        if (do_r3) {
+            const float a3 = e0 + el < E ? A3[e0 + el] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc3[j] = fmaf(a3, b[j], acc3[j]);
         }
-        atomicAdd(gacc + (i64)cp * C + c, acc);
-        if (bx == 0 && (threadIdx.x >> 4) == 0) atomicAdd(r3 + c, acc3);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cp = bx * 64 + ty * 4 + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = by * 64 + tx * 4 + j;
+            if (cp < C && c < C) atomicAdd(gacc + (i64)cp * C + c, acc[i][j]);
+        }
+    }
+    if (do_r3) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = by * 64 + tx * 4 + j;
+            if (c < C) atomicAdd(r3 + c, acc3[j]);
+        }
     }
 }
 // (a "last block converts G" tail instead of this second launch was measured 4x slower than the whole chain it replaced:
@@ -1803,8 +1889,8 @@ __global__ __launch_bounds__(256) void pw_bwd_gram_store_kernel(const float* gac
 // gacc [C*C] fp32 and r3 [C] fp32 must be zero on entry (the block backward's prep launch clears them)
 int k_pw_bwd_prep(const float* w1, const float* abc, int E, int C, void* bp, float* gacc, float* r3, int dtype,
                   hipStream_t s) {
-    const int nscale = (int)(((i64)E * C + 255) / 256);
-    const int gx = (C + 15) / 16, gy = (C + 15) / 16, gz = (E + 63) / 64;
+    const int nscale = ((E + 63) / 64) * ((C + 63) / 64);
+    const int gx = (C + 63) / 64, gy = (C + 63) / 64, gz = (E + 63) / 64;
     const int ngram = gx * gy * gz;
     DISPATCH_T(dtype,
         hipLaunchKernelGGL((pw_bwd_prep_kernel<bf16_t>), dim3(nscale + ngram), dim3(256), 0, s, w1, abc, E, C, (bf16_t*)bp, gacc, r3, nscale, gx, gy),
