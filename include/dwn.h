@@ -142,6 +142,11 @@ typedef struct dwn_dw_temporal_fwd_args {
     void* out;
     int B, T, HW, C, kt;
     double* stats;
+    /* eval-mode epilogue (BatchNorm-3 coefficients are known before the pass): with z_scale != NULL the kernel stores
+     * z3 = SiLU(z_scale * y3 + z_shift) instead of y3 (y3 rounded to the storage type first, as a stored y3 would read back)
+     * and, with pooled != NULL, adds the per-(sample, channel) sums of the stored z3 into pooled [B][C] (zeroed by the
+     * caller) — the SqueezeExcite pooling pass (dwiseneuro.py:38-39) without a separate read of y3. */
+    const float* z_scale; const float* z_shift; float* pooled;
 } dwn_dw_temporal_fwd_args;
 
 typedef struct dwn_dw_temporal_bwd_args {

@@ -73,7 +73,7 @@ class DwSpatialBwdArgs(C.Structure):
 
 class DwTemporalFwdArgs(C.Structure):
     _fields_ = [("inp", LoadDesc), ("w", c_p), ("out", c_p), ("B", c_i), ("T", c_i), ("HW", c_i), ("C", c_i),
-                ("kt", c_i), ("stats", c_p)]
+                ("kt", c_i), ("stats", c_p), ("z_scale", c_p), ("z_shift", c_p), ("pooled", c_p)]
 
 
 class DwTemporalBwdArgs(C.Structure):

@@ -408,17 +408,24 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     }
     if (tr) TRY(bn_finalize(w.st2, a.Cmid, (double)Mout, a.bn2, a.Cmid, tr, a.momentum, a.eps, s));
     // temp_covn_dw (:105-111)
+    static const bool z3_off = getenv("DWN_EVAL_Z3_OFF") != nullptr;
+    const bool eval_z3 = !tr && !z3_off;
     {
         DwTemporalFwd d; memset(&d, 0, sizeof(d));
         d.in = ld_bnact(a.y2, a.Cmid, a.bn2.coef, a.Cmid, 1, nullptr, 0, 1);
         d.w = w.wdwt; d.out = a.y3; d.B = a.B; d.T = a.T; d.HW = a.Hout * a.Wout; d.C = a.Cmid; d.kt = a.kt;
         d.stats = tr ? w.st3 : nullptr;
+        if (eval_z3) {       // eval: BatchNorm-3 is known -> z3 and the SE pooling sums straight from this pass, y3 never stored
+            d.out = a.z3; d.z_scale = a.bn3.coef; d.z_shift = a.bn3.coef + a.Cmid; d.pooled = w.pooled;
+        }
         PROF(DWN_FAM_DWT_FWD, launch_dw_temporal_fwd(d, dt, s));
     }
     if (tr) TRY(bn_finalize(w.st3, a.Cmid, (double)Mout, a.bn3, a.Cmid, tr, a.momentum, a.eps, s));
     // se (:38-43)
-    LoadDesc z3 = ld_bnact(a.y3, a.Cmid, a.bn3.coef, a.Cmid, 1, nullptr, 0, S_out);
-    PROF(DWN_FAM_SE_POOL, k_se_pool(z3, a.B, a.Cmid, S_out, w.pooled, a.z3, dt, s));
+    if (!eval_z3) {
+        LoadDesc z3 = ld_bnact(a.y3, a.Cmid, a.bn3.coef, a.Cmid, 1, nullptr, 0, S_out);
+        PROF(DWN_FAM_SE_POOL, k_se_pool(z3, a.B, a.Cmid, S_out, w.pooled, a.z3, dt, s));
+    }
     TRY(k_se_mlp_fwd(w.pooled, 1.0f / (float)S_out, a.se_wr, a.se_br, a.se_we, a.se_be, a.B, a.Cmid, a.se_r,
                      a.se_pmean, a.se_hidpre, a.se_gate, s));
     // conv_pwl (:117-120): y4 = (silu(bn3(y3)) * gate) @ W2^T

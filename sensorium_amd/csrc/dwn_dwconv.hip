@@ -741,7 +741,8 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, (ST == 1 ? DWS_BWD_MINB1 : 3)) voi
 // ------------------------------------------------------------------------------------------------
 // temporal forward: y3[t] = sum_k w[k] z2[t + k - P]
 // ------------------------------------------------------------------------------------------------
-template <typename T, int KT>
+// ZOUT (eval mode): the output is z3 = SiLU(BN3(y3)) and the SqueezeExcite pooling sums ride along (see dwn.h)
+template <typename T, int KT, bool ZOUT = false>
 __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFwd a) {
     constexpr int NCV = SL<T>::NCV, CS = SL<T>::CS, LP = SL<T>::LP, P = KT / 2;
     typedef typename SL<T>::raw_t raw_t;
@@ -760,6 +761,8 @@ __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFw
     ldc4(a.in.v1 + chs, bs);
     ldc4(a.in.v2 + chs, bt);
     float st0[4] = {0.f, 0.f, 0.f, 0.f}, st1[4] = {0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] float zs[4], zt[4];
+    if constexpr (ZOUT) { ldc4(a.z_scale + chs, zs); ldc4(a.z_shift + chs, zt); }
 
     const i64 npos = (i64)a.B * a.HW;
     const T* inp = reinterpret_cast<const T*>(a.in.p);
@@ -771,6 +774,7 @@ __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFw
             const T* ip = inp + (b * a.T * a.HW + hw) * a.C + chan;      // element (t = 0)
             T* op = outp + (b * a.T * a.HW + hw) * a.C + chan;
             float win[KT][4];                                           // win[k] = z2(t + k - P)
+            [[maybe_unused]] float ps[4] = {0.f, 0.f, 0.f, 0.f};         // ZOUT: this position's sums over t of the stored z3
 #pragma unroll
             for (int k = 0; k < KT - 1; ++k) {
                 int t = k - P;
@@ -795,17 +799,49 @@ __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFw
                     for (int k = 0; k < KT; ++k)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[k][i], win[k][i], acc[i]);
-                    st4<T>(op + t * tstride, acc);
+                    if constexpr (ZOUT) {
+                        float z[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float r = round_t<T>(acc[i]);
-                        st0[i] += r;
-                        st1[i] += r * r;
+                        for (int i = 0; i < 4; ++i) {
+                            z[i] = siluf_(fmaf(round_t<T>(acc[i]), zs[i], zt[i]));     // BN3 + SiLU of the value a stored y3 holds
+                            ps[i] += round_t<T>(z[i]);
+                        }
+                        st4<T>(op + t * tstride, z);
+                    } else {
+                        st4<T>(op + t * tstride, acc);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float r = round_t<T>(acc[i]);
+                            st0[i] += r;
+                            st1[i] += r * r;
+                        }
                     }
 #pragma unroll
                     for (int k = 0; k < KT - 1; ++k)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) win[k][i] = win[k + 1][i];
+                }
+            }
+            if constexpr (ZOUT) {
+                if (a.pooled) {
+                    // the wave's pixel lanes that share a channel vector: one sample almost always (positions are consecutive);
+                    // then fold them with xor-shuffles and let the first NCV lanes add 4 channels each
+                    const int b0 = __builtin_amdgcn_readfirstlane((int)b);
+                    const bool uniform = __popcll(__ballot(1)) == 64 && __all((int)b == b0);
+                    float* dst = a.pooled + b * a.C + chan;
+                    if (uniform) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int o = NCV; o < 64; o <<= 1) ps[i] += __shfl_xor(ps[i], o);
+                        if ((tid & 63) < NCV) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) atomicAdd(dst + i, ps[i]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) atomicAdd(dst + i, ps[i]);
+                    }
                 }
             }
         }
@@ -1283,6 +1319,14 @@ static int temporal_fwd_t(const DwTemporalFwd& a, hipStream_t s) {
     const int slices = (a.C + CS - 1) / CS;
     const i64 npos = (i64)a.B * a.HW;
     const i64 work = (npos + LP - 1) / LP;
+    if (a.z_scale) {
+        if (!a.z_shift || a.stats) return dwn_set_error(-2, "dw_temporal: the z3 epilogue needs z_shift and no statistics (eval mode)");
+        if (a.kt == 5) { dim3 grid(resident_grid_x(dw_temporal_fwd_kernel<T, 5, true>, 0, slices, work), slices); hipLaunchKernelGGL((dw_temporal_fwd_kernel<T, 5, true>), grid, dim3(256), 0, s, a); }
+        else if (a.kt == 3) { dim3 grid(resident_grid_x(dw_temporal_fwd_kernel<T, 3, true>, 0, slices, work), slices); hipLaunchKernelGGL((dw_temporal_fwd_kernel<T, 3, true>), grid, dim3(256), 0, s, a); }
+        else return dwn_set_error(-4, "dw_temporal: only temporal_kernel 3 or 5 is built");
+        DWN_CHECK_LAUNCH();
+        return 0;
+    }
     if (a.kt == 5) { dim3 grid(resident_grid_x(dw_temporal_fwd_kernel<T, 5>, 0, slices, work), slices); hipLaunchKernelGGL((dw_temporal_fwd_kernel<T, 5>), grid, dim3(256), 0, s, a); }
     else if (a.kt == 3) { dim3 grid(resident_grid_x(dw_temporal_fwd_kernel<T, 3>, 0, slices, work), slices); hipLaunchKernelGGL((dw_temporal_fwd_kernel<T, 3>), grid, dim3(256), 0, s, a); }
     else return dwn_set_error(-4, "dw_temporal: only temporal_kernel 3 or 5 is built");

@@ -49,7 +49,7 @@ def get_blend_weights(name: str, size: int) -> np.ndarray:
 
 class Predictor:
     def __init__(self, model, device: str = "cuda:0", blend_weights: str = "ones", *, frame_stack_size: Optional[int] = None,
-                 frame_stack_step: Optional[int] = None, position: str = "last", windows_per_batch: int = 16,
+                 frame_stack_step: Optional[int] = None, position: str = "last", windows_per_batch: int = 32,
                  use_graph: bool = False):
         """``model``: a checkpoint path — the reference's constructor ``Predictor(model_path, device, blend_weights)``
         (src/predictors.py:22-34: ``load_model(path, device=device, optimizer=None, loss=None)``, frame stack and inputs

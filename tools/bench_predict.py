@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32")
     ap.add_argument("--repeats", type=int, default=3)
     ap.add_argument("--folds", type=int, default=7, help="fold models of the ensemble leg (scripts/predict.py:44-50: 7)")
+    ap.add_argument("--windows", type=int, default=32, help="windows per forward of the ensemble leg")
     args = ap.parse_args()
     from bench import HBM_PEAK_GBS, NUM_NEURONS_MOUSE0, family_work, model_params
     from sensorium_amd.argus_models import MouseModel
@@ -47,8 +48,9 @@ def main():
     out = {"length": args.length, "hw": [args.height, args.width], "dtype": args.dtype, "expansion": args.expansion,
            "window": [16, 2], "neurons": NUM_NEURONS_MOUSE0, "trials_per_s": {}}
     ref = None
-    for name, wpb, graph in (("one_window_per_forward", 1, False), ("16_windows_per_forward", 16, False),
-                             ("16_windows_per_forward_hipgraph", 16, True)):
+    W = args.windows
+    for name, wpb, graph in (("one_window_per_forward", 1, False), (f"{W}_windows_per_forward", W, False),
+                             (f"{W}_windows_per_forward_hipgraph", W, True)):
         pred = Predictor(model, frame_stack_size=16, frame_stack_step=2, windows_per_batch=wpb, use_graph=graph)
         r = pred.predict_trial(inputs, 0)                       # warm-up (graph capture included)
         torch.cuda.synchronize()
@@ -76,10 +78,10 @@ def main():
         legs = {}
         for name, cls_args in (("sequential_predictors_hipgraph", None), ("one_graph_all_folds", True)):
             if cls_args is None:
-                preds = [Predictor(m, frame_stack_size=16, frame_stack_step=2, windows_per_batch=16, use_graph=True) for m in models]
+                preds = [Predictor(m, frame_stack_size=16, frame_stack_step=2, windows_per_batch=args.windows, use_graph=True) for m in models]
                 run = lambda: np.mean([p.predict_trial(inputs, 0) for p in preds], axis=0)
             else:
-                ens = EnsemblePredictor(models, frame_stack_size=16, frame_stack_step=2, windows_per_batch=16, use_graph=True)
+                ens = EnsemblePredictor(models, frame_stack_size=16, frame_stack_step=2, windows_per_batch=args.windows, use_graph=True)
                 run = lambda: ens.predict_trial(inputs, 0)
             r = run()
             torch.cuda.synchronize()
@@ -89,12 +91,12 @@ def main():
             torch.cuda.synchronize()
             legs[name] = ((time.perf_counter() - t0) / args.repeats, r)
         es = 2 if args.dtype == "bf16" else 4
-        alg, _ = family_work(16, 16, args.height, args.width, args.expansion, (NUM_NEURONS_MOUSE0,), [], es)
+        alg, _ = family_work(args.windows, 16, args.height, args.width, args.expansion, (NUM_NEURONS_MOUSE0,), [], es)
         fwd_bytes = sum(alg[k] for k in ("pw_fwd", "dws_fwd", "dwt_fwd", "se_pool", "pwl_fwd"))       # one window batch, one fold
-        nbatch = -(-(args.length - 30) // 16)
+        nbatch = -(-(args.length - 30) // args.windows)
         dt = legs["one_graph_all_folds"][0]
         out["ensemble"] = {
-            "folds": args.folds,
+            "folds": args.folds, "windows_per_forward": args.windows,
             "trials_per_s": {k: round(1.0 / v[0], 3) for k, v in legs.items()},
             "max_rel_diff_between_legs": float(np.abs(legs["one_graph_all_folds"][1] - legs["sequential_predictors_hipgraph"][1]).max()
                                                / (np.abs(legs["sequential_predictors_hipgraph"][1]).max() + 1e-12)),
