@@ -1,33 +1,45 @@
-"""Inputs processors (reference: src/inputs.py:9-48).  ``stack_inputs`` builds the model input of one trial: channel 0 the
-video centre-padded to ``size`` (width, height), channels 1-2 behavior, 3-4 pupil_center broadcast over the frame.
-Host-side (numpy) like the reference; the training path assembles batches on the device instead (data_gpu.py)."""
+"""Host-side inputs processor used by ``Predictor`` when it is built from a checkpoint path (the stored params name it:
+``"inputs_processor": ("stack_inputs", {"size": (64, 64), "pad_fill_value": 0.})``, reference src/inputs.py:15-48).
+
+Model input of one trial = 5 planes per frame: the grey-level video centre-padded to ``size`` = (width, height), then the two
+behaviour traces and the two pupil-centre traces, each constant over the frame.  Built with torch ops (pad + expand + cat);
+the training path never comes here — it assembles whole batches on the device (data_gpu.py / csrc/dwn_data.hip)."""
 from __future__ import annotations
+
+from typing import Callable, Dict, Sequence
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 
 class StackInputsProcessor:
-    def __init__(self, size, pad_fill_value: int = 0):
-        self.size = tuple(size)
+    def __init__(self, size: Sequence[int], pad_fill_value: float = 0):
+        self.width, self.height = int(size[0]), int(size[1])
+        self.size = (self.width, self.height)
         self.pad_fill_value = pad_fill_value
 
     def __call__(self, frames: np.ndarray, behavior: np.ndarray, pupil_center: np.ndarray) -> torch.Tensor:
-        length = frames.shape[-1]
-        out = np.full((5, length, self.size[1], self.size[0]), self.pad_fill_value, dtype=np.float32)
-        video = np.transpose(frames.astype(np.float32), (2, 0, 1))             # (H, W, L) on disk -> (L, H, W)
-        h, w = video.shape[-2:]
-        h0, w0 = (self.size[1] - h) // 2, (self.size[0] - w) // 2
-        out[0, :, h0:h0 + h, w0:w0 + w] = video
-        out[1:3] = behavior[:, :, None, None]
-        out[3:] = pupil_center[:, :, None, None]
-        return torch.from_numpy(out)
+        # trials are stored (H, W, L); the model wants (L, H, W)
+        video = torch.from_numpy(np.ascontiguousarray(frames)).to(torch.float32).permute(2, 0, 1)
+        n_frames, h, w = video.shape
+        top, left = (self.height - h) // 2, (self.width - w) // 2
+        if top < 0 or left < 0:
+            raise ValueError(f"video {h}x{w} does not fit the {self.height}x{self.width} input")
+        video = F.pad(video, (left, self.width - w - left, top, self.height - h - top), value=float(self.pad_fill_value))
+        traces = torch.cat([torch.as_tensor(np.asarray(behavior)), torch.as_tensor(np.asarray(pupil_center))]).to(torch.float32)
+        if traces.shape != (4, n_frames):
+            raise ValueError("behavior and pupil_center must be (2, frames) each")
+        planes = traces[:, :, None, None].expand(4, n_frames, self.height, self.width)
+        return torch.cat([video[None], planes]).contiguous()
 
 
-_REGISTRY = {"stack_inputs": StackInputsProcessor}
+_PROCESSORS: Dict[str, Callable] = {"stack_inputs": StackInputsProcessor}
 
 
 def get_inputs_processor(name: str, processor_params: dict):
-    if name not in _REGISTRY:
-        raise ValueError(f"inputs processor '{name}' is not supported (known: {sorted(_REGISTRY)})")
-    return _REGISTRY[name](**processor_params)
+    try:
+        factory = _PROCESSORS[name]
+    except KeyError:
+        raise ValueError(f"inputs processor '{name}' is not supported (known: {sorted(_PROCESSORS)})") from None
+    return factory(**processor_params)

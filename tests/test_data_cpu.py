@@ -31,6 +31,23 @@ def test_oracle_matches_reference_stack_inputs_and_targets(gold):
         assert np.array_equal(dorc.responses_to_target(d["responses"][..., idx]), gold[f"c{c}_t0"])
 
 
+def test_host_inputs_processor_matches_reference(gold):
+    """sensorium_amd.inputs.StackInputsProcessor (what Predictor builds from a checkpoint's params) against the reference's
+    StackInputsProcessor outputs stored in the fixture."""
+    from sensorium_amd.inputs import get_inputs_processor
+    for c in range(int(gold["num_cases"])):
+        k = _case(gold, c)
+        d = k["trials"][0]
+        idx = dorc.window_indexes(k["ends"][0], *k["window"])
+        proc = get_inputs_processor("stack_inputs", dict(size=k["size"], pad_fill_value=k["fill"]))
+        x = proc(d["video"][..., idx], d["behavior"][..., idx], d["pupil_center"][..., idx])
+        assert x.dtype.is_floating_point and np.array_equal(x.numpy(), gold[f"c{c}_x0"])
+    with pytest.raises(ValueError):
+        get_inputs_processor("resize", {})
+    with pytest.raises(ValueError):
+        get_inputs_processor("stack_inputs", dict(size=(4, 4)))(np.zeros((8, 8, 3)), np.zeros((2, 3)), np.zeros((2, 3)))
+
+
 def test_oracle_matches_reference_cutmix_draws_and_blend(gold):
     used = 0
     for c in range(int(gold["num_cases"])):
