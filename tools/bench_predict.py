@@ -104,8 +104,10 @@ def main():
             "achieved_GBs": round(fwd_bytes * nbatch * args.folds / dt / 1e9, 1),
             "hbm_frac": round(fwd_bytes * nbatch * args.folds / dt / 1e9 / HBM_PEAK_GBS, 4),
             "note": "algorithmic bytes = the E-wide forward passes of the materialised pass structure (conv_pw write, stencils, "
-                    "SE pooling, conv_pwl read) per window batch x batches per trial x folds; the bf16 eval path skips the "
-                    "conv_pw pass on blocks 0-6 (y1 rebuilt inside the stencil kernel), so its traffic is below this figure",
+                    "SE pooling, conv_pwl read) per window batch x batches per trial x folds; the eval path moves fewer bytes than "
+                    "this (bf16: no conv_pw pass on blocks 0-6, y1 rebuilt inside the stencil kernel; both dtypes: z3 and the SE "
+                    "pooling sums come from the temporal pass, y3 is never stored), so hbm_frac is a rate of useful work, not of "
+                    "traffic",
         }
     print(json.dumps(out))
 
