@@ -2,7 +2,9 @@
 """Benchmark of the DwiseNeuro training hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N>1 either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...:
+  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or plainly, in which case bench.py starts that launcher
+  itself as a child process before touching the GPU.
 
 A "step" is one full ``MouseModel.train_step`` (src/argus_models.py:43-71 semantics) over one batch of
 synthetic clips already resident in HBM: forward, Poisson loss, backward, (N>1: gradient all-reduce over
@@ -187,6 +189,46 @@ def cpu_baseline(frames, height, width, expansion):
                       f"{min(times):.2f}-{max(times):.2f} s; scaled to full clips"}
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    bench.py <same args>` as a child (never an exec: this may only happen before any GPU call, and the child is a fresh
+    process anyway), pass its output through (rank 0 prints the one JSON line) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, rank, world):
+    """Launcher / rendezvous plumbing without a GPU (tests/test_bench_launch.py): the same barrier + max-over-ranks
+    timing and rank-0 JSON line as the real run, with the timed loop replaced by a sleep.  Never a measurement."""
+    if world > 1:
+        dist.init_process_group(args.backend if args.backend != "nccl" else "gloo")
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * args.steps)
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ranks": dist.get_world_size() if world > 1 else 1,
+                          "ms_per_step": round(float(t.item()) / args.steps * 1e3, 3)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,13 +251,20 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="time every kernel family (adds event overhead)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU testing)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--dry-run", action="store_true", help="testing only: launcher + rendezvous + timing plumbing, no GPU work")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process and before anything in this
+        # process touches the GPU (an exec from a GPU-initialised process is forbidden on the pool), relay rank 0's line
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
