@@ -318,6 +318,300 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1_kernel(const D
 }
 
 // ------------------------------------------------------------------------------------------------
+// stride 1, CHAINED bands (round 3).  Same arithmetic and dot2 order as dw_spatial_bwd_s1_kernel (dh1 bit-identical), other
+// schedule.  What the round-2 kernel's profile said: per 9-row tile a workgroup made ~14 DEPENDENT memory round trips (three
+// 4-row staging batches, the halo column, then one y1 row per row step prefetched a single step ahead) and both VALU
+// (~40 %) and HBM (3.3-4.6 TB/s) idled on latency; bands re-read two halo rows of (dh2, y2) each.  Here:
+//   * a workgroup walks a WHOLE plane group top to bottom in chunks of RB rows and keeps the gradient tile as a RING of
+//     RB + 2 row slots: the two halo rows a chunk needs are the previous chunk's last rows, still in LDS -> no halo re-read;
+//   * the chunk's y1 rows arrive by LDS-DMA (global_load_lds_dwordx4, no registers), issued BEFORE the staging loads so both
+//     ride the same round trip; a wave reads back only the 1 KB blocks it fetched itself (pixels 8w..8w+7 of the 32-pixel
+//     group row), placed 0,2,1,3,4,6,5,7 inside the block so that the two pixel lanes of a 32-lane group hit different
+//     bank halves;
+//   * staging fetches the chunk's RB rows (+ the halo column) in ONE batch.
+// One dependent round trip per RB rows instead of ~14 per 9.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wk_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void wk_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int LPW, int RB>
+__global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1c_kernel(const DwSpatialBwd a) {
+    typedef bf16_t T;
+    constexpr int NT = 256, CS = 64, NG = 16 / LPW, Wqp = LPW + 1, RQ = RB + 2, W = 2 * LPW;
+    constexpr int rowdw = Wqp * CS;                                         // dwords between ring rows of one plane
+    constexpr unsigned RING_BYTES = (unsigned)NG * RQ * Wqp * CS * 4u;
+    constexpr int NEX = (RB + LPW - 1) / LPW;                              // halo-column rows a thread stages per chunk
+    __shared__ float lstat[2 * CS];
+    __shared__ __attribute__((aligned(16))) unsigned lwp[3 * 4 * CS];        // packed weights [dy][combo][channel]
+    __shared__ __attribute__((aligned(16))) float lcoef[5 * CS];             // bn1 scale, shift; BatchNorm-2 backward A1, A2, A3 (re-read per phase: registers)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cv = tid & 15, pl = tid >> 4;
+    const int grp = pl / LPW, jj = pl % LPW;
+    const int c0 = blockIdx.y * CS;
+    const int chan = c0 + cv * 4;
+    const bool chan_ok = chan < a.C;
+    const int chs = chan_ok ? chan : 0;
+    if (tid < 2 * CS) lstat[tid] = 0.f;
+    for (int i = tid; i < 5 * CS; i += NT) {
+        const int which = i / CS, c = c0 + i % CS;
+        const float* src = which == 0 ? a.y1.v1 : which == 1 ? a.y1.v2 : which == 2 ? a.dy.v1 : which == 3 ? a.dy.v2 : a.dy.v3;
+        lcoef[i] = c < a.C ? src[c] : 0.f;
+    }
+    for (int i = tid; i < 3 * CS; i += NT) {
+        const int dy = i / CS, cc = i % CS, c = c0 + cc;
+        float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+        if (c < a.C) { w0 = a.w[(i64)(dy * 3 + 0) * a.C + c]; w1 = a.w[(i64)(dy * 3 + 1) * a.C + c]; w2 = a.w[(i64)(dy * 3 + 2) * a.C + c]; }
+        lwp[(dy * 4 + 0) * CS + cc] = pk_bf16(w2, w1);
+        lwp[(dy * 4 + 1) * CS + cc] = pk_bf16(w0, 0.f);
+        lwp[(dy * 4 + 2) * CS + cc] = pk_bf16(0.f, w2);
+        lwp[(dy * 4 + 3) * CS + cc] = pk_bf16(w1, w0);
+    }
+    __syncthreads();
+
+    float dwp[9][4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { dwp[k][0] = dwp[k][1] = dwp[k][2] = dwp[k][3] = 0.f; }
+    wk_f2_t sp0[2] = {wk_f2_t{0.f, 0.f}, wk_f2_t{0.f, 0.f}}, sp1[2] = {wk_f2_t{0.f, 0.f}, wk_f2_t{0.f, 0.f}};
+
+    const int Hin = a.Hin;                          // stride 1: Hout == Hin, Wout == Win == W
+    const int ngroups = (a.planes + NG - 1) / NG;
+    const int nchunks = (Hin + RB) / RB;            // chunks cover rows 0 .. Hin (row Hin = the zero row below the plane)
+    T* dhp = reinterpret_cast<T*>(a.dh1);
+    const T* y1p = reinterpret_cast<const T*>(a.y1.p);
+    unsigned* tile = reinterpret_cast<unsigned*>(wk_smem);        // ring: [NG][RQ][Wqp][64] dwords
+    unsigned* tcol = tile + (grp * RQ * Wqp + jj) * CS + cv * 4;              // this thread's pair column, ring slot 0
+    unsigned* tlast = tile + (grp * RQ * Wqp + LPW) * CS + cv * 4;           // the halo pair column (wo = W-1 | outside), slot 0
+    const unsigned y1row = (unsigned)W * (unsigned)a.y1.ld, dhrow = (unsigned)W * (unsigned)a.C;
+    const unsigned dyrow = (unsigned)W * (unsigned)a.dy.ld;
+    // ---- y1 by LDS-DMA: lane -> (pixel slot, 16-byte channel chunk) of this wave's 1 KB block of a group row
+    const int dslot = lane >> 3, c16 = lane & 7;
+    const int dq = (dslot & 4) | ((dslot & 1) << 1) | ((dslot >> 1) & 1);     // pixel of the block that lives in slot dslot
+    const int dp = wave * 8 + dq;                                              // pixel of the 32-pixel group row
+    const int dgrp = dp / W, dx = dp % W;
+    const int dce = (c0 + c16 * 8 < a.C) ? c0 + c16 * 8 : c0;                   // channel tail: any valid address (never read back)
+    const unsigned lds_y1 = (unsigned)(size_t)wk_smem + RING_BYTES + (unsigned)wave * 1024u;
+    // ... and where this thread finds its two pixels (2jj, 2jj+1) of a row in that block: slots s0 and s0 + 2
+    const int jq = pl & 3;
+    const unsigned char* yld = wk_smem + RING_BYTES + wave * 1024 + (((jq & 1) + ((jq >> 1) << 2)) * 128) + cv * 8;
+    // staging constants
+    const unsigned cmask = (jj > 0 ? 0x0000ffffu : 0u) | 0xffff0000u;          // pair jj = (wo = 2jj-1, wo = 2jj)
+    const unsigned colhi = (unsigned)(2 * jj) * (unsigned)a.dy.ld;
+    const unsigned lodelta = jj > 0 ? (unsigned)a.dy.ld : 0u;          // jj == 0: the low pixel is the halo (masked)
+    const unsigned collast = (unsigned)(W - 1) * (unsigned)a.dy.ld;
+
+    for (int pg = blockIdx.x; pg < ngroups; pg += gridDim.x) {
+        const int plane = pg * NG + grp;
+        const bool pvalid = plane < a.planes && chan_ok;
+        const int psafe = plane < a.planes ? plane : 0;
+        const i64 pbase = (i64)psafe * Hin * W * a.dy.ld + chs;
+        const T* dp0 = reinterpret_cast<const T*>(a.dy.p) + pbase;
+        const T* dq0 = reinterpret_cast<const T*>(a.dy.q) + pbase;
+        const int dplane = pg * NG + dgrp < a.planes ? pg * NG + dgrp : 0;
+        const T* ysrc0 = y1p + ((i64)dplane * Hin * W + dx) * a.y1.ld + dce;
+        const i64 prow = (i64)psafe * Hin * W;
+        const T* y10 = y1p + prow * a.y1.ld;      // (unused for loads: y1 comes from LDS)
+        (void)y10;
+        T* dh0 = dhp + prow * a.C + chan + (unsigned)(2 * jj) * (unsigned)a.C;
+        // row -1 of the ring (slot 0) is the zero row above the plane
+        *reinterpret_cast<uint4*>(tcol) = make_uint4(0, 0, 0, 0);
+        if (jj == 0) *reinterpret_cast<uint4*>(tlast) = make_uint4(0, 0, 0, 0);
+        int slot_s = 1;                            // ring slot of gradient row s = chunk * RB   (slot(r) = (r + 1) mod RQ)
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int s = chunk * RB;
+            // ---------------- y1 rows s-1 .. s+RB-2 -> LDS (DMA, this wave's pixels only)
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int row = s - 1 + i;
+                if ((unsigned)row < (unsigned)Hin)
+                    wk_glds16(ysrc0 + (unsigned)row * y1row, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_y1 + (unsigned)i * 4096u)));
+            }
+            // ---------------- stage dL/dy2 rows s .. s+RB-1 (BatchNorm-backward affine), x-pair-packed, into their ring slots
+            {
+                uint2 rp[RB][2], rq[RB][2], ep[NEX], eq[NEX];
+                bool ok[RB], eok[NEX];
+                const float4 c1 = *reinterpret_cast<const float4*>(&lcoef[2 * CS + cv * 4]);
+                const float4 c2 = *reinterpret_cast<const float4*>(&lcoef[3 * CS + cv * 4]);
+                const float4 c3 = *reinterpret_cast<const float4*>(&lcoef[4 * CS + cv * 4]);
+                const wk_f2_t a1v[2] = {wk_f2_t{c1.x, c1.y}, wk_f2_t{c1.z, c1.w}}, a2v[2] = {wk_f2_t{c2.x, c2.y}, wk_f2_t{c2.z, c2.w}};
+                const wk_f2_t a3v[2] = {wk_f2_t{c3.x, c3.y}, wk_f2_t{c3.z, c3.w}};
+                auto affine_pack = [&](const uint2& plo, const uint2& qlo, const uint2& phi, const uint2& qhi) {
+                    wk_f2_t p0, p1, q0, q1, gl0, gl1, gh0, gh1;
+                    wk_unpack(plo, p0, p1); wk_unpack(qlo, q0, q1);
+                    gl0 = a1v[0] * p0 + (a2v[0] * q0 + a3v[0]); gl1 = a1v[1] * p1 + (a2v[1] * q1 + a3v[1]);
+                    wk_unpack(phi, p0, p1); wk_unpack(qhi, q0, q1);
+                    gh0 = a1v[0] * p0 + (a2v[0] * q0 + a3v[0]); gh1 = a1v[1] * p1 + (a2v[1] * q1 + a3v[1]);
+                    return make_uint4(pk_bf16(gl0.x, gh0.x), pk_bf16(gl0.y, gh0.y), pk_bf16(gl1.x, gh1.x), pk_bf16(gl1.y, gh1.y));
+                };
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    const int ho = s + u;
+                    ok[u] = pvalid && ho < Hin;
+                    const unsigned off = ok[u] ? (unsigned)ho * dyrow + colhi : lodelta;
+                    rp[u][1] = wk_ld8(dp0 + off); rq[u][1] = wk_ld8(dq0 + off);
+                    rp[u][0] = wk_ld8(dp0 + off - lodelta); rq[u][0] = wk_ld8(dq0 + off - lodelta);
+                }
+#pragma unroll
+                for (int e = 0; e < NEX; ++e) {
+                    const int ho = s + jj + e * LPW;
+                    eok[e] = pvalid && jj + e * LPW < RB && ho < Hin;
+                    const unsigned off = eok[e] ? (unsigned)ho * dyrow + collast : 0u;
+                    ep[e] = wk_ld8(dp0 + off); eq[e] = wk_ld8(dq0 + off);
+                }
+                int sl = slot_s;
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    uint4 o = affine_pack(rp[u][0], rq[u][0], rp[u][1], rq[u][1]);
+                    const unsigned m = ok[u] ? cmask : 0u;
+                    o.x &= m; o.y &= m; o.z &= m; o.w &= m;
+                    *reinterpret_cast<uint4*>(tcol + sl * rowdw) = o;
+                    sl = sl + 1 == RQ ? 0 : sl + 1;
+                }
+#pragma unroll
+                for (int e = 0; e < NEX; ++e) {
+                    const int u = jj + e * LPW;
+                    if (u < RB) {
+                        uint4 o = affine_pack(ep[e], eq[e], ep[e], eq[e]);
+                        const unsigned m = eok[e] ? 0x0000ffffu : 0u;
+                        o.x &= m; o.y &= m; o.z &= m; o.w &= m;
+                        int se = slot_s + u; se = se >= RQ ? se - RQ : se;
+                        *reinterpret_cast<uint4*>(tlast + se * rowdw) = o;
+                    }
+                }
+            }
+            wk_wait_vm0();                          // this wave's y1 blocks have landed (it is their only reader)
+            __syncthreads();
+            // ---------------- walk rows s-1 .. s+RB-2 of this thread's pixel-pair column
+            const int r_lo = s > 0 ? s - 1 : 0;
+            const int r_hi = s + RB - 1 < Hin ? s + RB - 1 : Hin;          // exclusive
+            if (pvalid && r_lo < r_hi) {
+                // ring slots of gradient rows r_lo - 1, r_lo, r_lo + 1
+                int sl0 = slot_s + (r_lo - s) - 1; sl0 = sl0 < 0 ? sl0 + RQ : sl0;
+                int sl1 = sl0 + 1 == RQ ? 0 : sl0 + 1;
+                int sl2 = sl1 + 1 == RQ ? 0 : sl1 + 1;
+                const float4 s4 = *reinterpret_cast<const float4*>(&lcoef[cv * 4]), t4 = *reinterpret_cast<const float4*>(&lcoef[CS + cv * 4]);
+                const wk_f2_t bs2[2] = {wk_f2_t{s4.x, s4.y}, wk_f2_t{s4.z, s4.w}}, bt2[2] = {wk_f2_t{t4.x, t4.y}, wk_f2_t{t4.z, t4.w}};
+                uint4 gw[3][2];
+                gw[0][0] = *reinterpret_cast<const uint4*>(tcol + sl0 * rowdw); gw[0][1] = *reinterpret_cast<const uint4*>(tcol + sl0 * rowdw + CS);
+                gw[1][0] = *reinterpret_cast<const uint4*>(tcol + sl1 * rowdw); gw[1][1] = *reinterpret_cast<const uint4*>(tcol + sl1 * rowdw + CS);
+                auto row_step = [&](const int r, uint4 (&g0)[2], uint4 (&g1)[2], uint4 (&g2)[2]) {
+                    g2[0] = *reinterpret_cast<const uint4*>(tcol + sl2 * rowdw);
+                    g2[1] = *reinterpret_cast<const uint4*>(tcol + sl2 * rowdw + CS);
+                    sl2 = sl2 + 1 == RQ ? 0 : sl2 + 1;
+                    const unsigned char* yr = yld + (r - (s - 1)) * 4096;
+                    const uint2 ry[2] = {*reinterpret_cast<const uint2*>(yr), *reinterpret_cast<const uint2*>(yr + 256)};
+                    wk_f2_t y[2][2], z1[2][2], dsl[2][2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        wk_unpack(ry[h], y[h][0], y[h][1]);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const wk_f2_t hh = y[h][q] * bs2[q] + bt2[q];
+                            const wk_f2_t sg = wk_f2_t{sigmoidf_(hh.x), sigmoidf_(hh.y)};
+                            z1[h][q] = hh * sg;
+                            dsl[h][q] = sg * (1.0f + hh * (1.0f - sg));
+                        }
+                    }
+                    const unsigned Z[4] = {pk_bf16(z1[0][0].x, z1[1][0].x), pk_bf16(z1[0][0].y, z1[1][0].y),
+                                           pk_bf16(z1[0][1].x, z1[1][1].x), pk_bf16(z1[0][1].y, z1[1][1].y)};
+                    float dz0[4] = {0.f, 0.f, 0.f, 0.f}, dz1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        __builtin_amdgcn_sched_barrier(0);        // one stencil row's weight vectors live at a time (registers)
+                        const uint4 G0 = dy == 0 ? g2[0] : dy == 1 ? g1[0] : g0[0];
+                        const uint4 G1 = dy == 0 ? g2[1] : dy == 1 ? g1[1] : g0[1];
+                        const uint4 Wa = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 0) * CS + cv * 4]);
+                        const uint4 Wb = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 1) * CS + cv * 4]);
+                        const uint4 Wc = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 2) * CS + cv * 4]);
+                        const uint4 Wd = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 3) * CS + cv * 4]);
+                        const unsigned ga[4] = {G0.x, G0.y, G0.z, G0.w}, gb[4] = {G1.x, G1.y, G1.z, G1.w};
+                        const unsigned wa[4] = {Wa.x, Wa.y, Wa.z, Wa.w}, wb[4] = {Wb.x, Wb.y, Wb.z, Wb.w};
+                        const unsigned wc[4] = {Wc.x, Wc.y, Wc.z, Wc.w}, wd[4] = {Wd.x, Wd.y, Wd.z, Wd.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            dz0[q] = wk_dot2(ga[q], wa[q], dz0[q]);
+                            dz0[q] = wk_dot2(gb[q], wb[q], dz0[q]);
+                            dz1[q] = wk_dot2(ga[q], wc[q], dz1[q]);
+                            dz1[q] = wk_dot2(gb[q], wd[q], dz1[q]);
+                            const unsigned gm = __builtin_amdgcn_alignbit(gb[q], ga[q], 16);      // (G0.hi, G1.lo)
+                            dwp[dy * 3 + 2][q] = wk_dot2(Z[q], ga[q], dwp[dy * 3 + 2][q]);
+                            dwp[dy * 3 + 1][q] = wk_dot2(Z[q], gm, dwp[dy * 3 + 1][q]);
+                            dwp[dy * 3 + 0][q] = wk_dot2(Z[q], gb[q], dwp[dy * 3 + 0][q]);
+                        }
+                    }
+                    T* dst = dh0 + (unsigned)r * dhrow;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float* dz = h == 0 ? dz0 : dz1;
+                        const wk_f2_t d0 = wk_f2_t{dz[0], dz[1]} * dsl[h][0], d1 = wk_f2_t{dz[2], dz[3]} * dsl[h][1];
+                        const uint2 packed = make_uint2(pk_bf16(d0.x, d0.y), pk_bf16(d1.x, d1.y));
+                        *reinterpret_cast<uint2*>(dst + h * a.C) = packed;
+                        wk_f2_t r0, r1;
+                        wk_unpack(packed, r0, r1);                    // statistics of the values as stored
+                        sp0[0] += r0; sp0[1] += r1;
+                        sp1[0] += r0 * y[h][0];
+                        sp1[1] += r1 * y[h][1];
+                    }
+                };
+                for (int r = r_lo; r < r_hi; r += 3) {
+                    row_step(r, gw[0], gw[1], gw[2]);
+                    if (r + 1 < r_hi) row_step(r + 1, gw[1], gw[2], gw[0]);
+                    if (r + 2 < r_hi) row_step(r + 2, gw[2], gw[0], gw[1]);
+                }
+            }
+            __syncthreads();
+            slot_s += RB; slot_s = slot_s >= RQ ? slot_s - RQ : slot_s;
+        }
+    }
+    // ---------------- weight gradient: fold the wave's four pixel lanes (36 values -> 9 per lane), then LDS / global atomics
+    float* lw = reinterpret_cast<float*>(wk_smem);               // [9][64], the ring is dead
+    for (int i = tid; i < 9 * CS; i += NT) lw[i] = 0.f;
+    __syncthreads();
+    {
+        float v[36], o[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[k * 4 + q] = dwp[k][q];
+        wk_fold4<9>(v, o, lane);
+        const int r = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int vi = i + 9 * (r >> 1) + 18 * (r & 1);          // value index = tap*4 + q
+            atomicAdd(&lw[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * CS; i += NT) {
+        const int k = i / CS, c = c0 + i % CS;
+        if (c < a.C) atomicAdd(&a.dw[(i64)c * 9 + k], lw[i]);
+    }
+    if (a.stats) {
+        float bm[4], bi[4];
+        ldc4(a.y1.v3 + chs, bm); ldc4(a.y1.v4 + chs, bi);
+        float v[8] = {sp0[0].x, sp0[0].y, sp0[1].x, sp0[1].y,
+                      bi[0] * fmaf(-bm[0], sp0[0].x, sp1[0].x), bi[1] * fmaf(-bm[1], sp0[0].y, sp1[0].y),
+                      bi[2] * fmaf(-bm[2], sp0[1].x, sp1[1].x), bi[3] * fmaf(-bm[3], sp0[1].y, sp1[1].y)}, o[2];
+        wk_fold4<2>(v, o, lane);
+        const int r = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int vi = i + 2 * (r >> 1) + 4 * (r & 1);           // 0..3: Σdh1 of channel vi; 4..7: Σdh1·ŷ1 of channel vi-4
+            atomicAdd(&lstat[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
+        }
+        __syncthreads();
+        if (tid < 2 * CS) {
+            const int which = tid / CS, c = c0 + tid % CS;
+            if (c < a.C) stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.C, which, c, lstat[tid]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // stride 2.  A thread owns one QUAD of input pixels (columns 4m .. 4m+3) of an input row and walks down the rows.
 // With the output-column pairs Gq[k] = (g[wo = 2k-1], g[wo = 2k]) and M = (g[wo = 2m], g[wo = 2m+1]) = align(Gq[m], Gq[m+1]),
 // a tap row (dy, output row ho) contributes
@@ -617,7 +911,43 @@ static int launch_s2(const DwSpatialBwd& a, hipStream_t s) {
     return 0;
 }
 
+template <int LPW, int RB>
+static int launch_s1c(const DwSpatialBwd& a, hipStream_t s) {
+    constexpr int NG = 16 / LPW, Wqp = LPW + 1;
+    const size_t lds = (size_t)NG * (RB + 2) * Wqp * 256 + (size_t)RB * 4096;
+    auto kern = dw_spatial_bwd_s1c_kernel<LPW, RB>;
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        (void)hipGetLastError();
+    int bpc = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kern, 256, lds) != hipSuccess || bpc < 1) { (void)hipGetLastError(); bpc = 2; }
+    const int slices = (a.C + 63) / 64;
+    const i64 work = (a.planes + NG - 1) / NG;
+    i64 gx = (256 * bpc) / slices;
+    if (gx < 1) gx = 1;
+    if (gx > work) gx = work;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, slices), dim3(256), lds, s, a);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+// chained stride-1 kernel: rows per chunk from a.rows_band / DWN_DWS_CHAIN_RB (4 = three workgroups per CU)
+template <int LPW>
+static int launch_s1c_rb(const DwSpatialBwd& a, hipStream_t s) {
+    const char* e = getenv("DWN_DWS_CHAIN_RB");
+    // measured best at the metric shapes (tools/bwd_chain_check.py): 4 rows per chunk at 18x32 planes, 2 at 9x16 and 5x8
+    int rb = a.rows_band > 0 ? a.rows_band : (e ? atoi(e) : (LPW == 16 ? 4 : 2));
+    if (rb <= 2) return launch_s1c<LPW, 2>(a, s);
+    if (rb <= 4) return launch_s1c<LPW, 4>(a, s);
+    if (rb <= 6) return launch_s1c<LPW, 6>(a, s);
+    return launch_s1c<LPW, 8>(a, s);
+}
+
 int launch_dw_spatial_bwd_walk(const DwSpatialBwd& a, hipStream_t s) {
+    const char* ch = getenv("DWN_DWS_CHAIN");            // read per call: A/B inside one process
+    if (a.stride == 1 && !(ch && ch[0] == '0')) {
+        if (a.Win == 32) return launch_s1c_rb<16>(a, s);
+        if (a.Win == 16) return launch_s1c_rb<8>(a, s);
+        return launch_s1c_rb<4>(a, s);
+    }
     if (a.stride == 1) {
         if (a.Win == 32) return launch_s1<16>(a, s);
         if (a.Win == 16) return launch_s1<8>(a, s);

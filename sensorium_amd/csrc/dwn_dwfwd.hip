@@ -331,6 +331,336 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_walk_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------------
+// CHAINED bands (round 3): same arithmetic and dot2 order as dw_spatial_fwd_walk_kernel (y2 bit-identical), other schedule.
+// A workgroup walks a whole plane group top to bottom in chunks of RB output rows and keeps the activated tile as a RING of
+// row slots: the halo rows a chunk needs are the previous chunk's last rows, still in LDS, so no input row is fetched or
+// activated twice (the banded kernel re-read 2 of 11 rows at stride 1 and 1 of 5 at stride 2), and a chunk's rows are
+// fetched in ONE batch (one dependent round trip per chunk instead of three or four per band).
+//   stride 1: chunk c stages input rows s .. s+RB-1 (s = c*RB) and produces output rows s-1 .. s+RB-2; ring of RB+2 rows
+//   stride 2: chunk c stages input rows 2s .. 2s+2RB-1 and produces output rows s .. s+RB-1;          ring of 2RB+1 rows
+// ring slot of input row r = (r + 1) mod RQ; row -1 (slot 0) is the zero row above the plane.
+// ------------------------------------------------------------------------------------------------
+template <int ST, int LPW, int RB>
+__global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(const DwSpatialFwd a) {
+    typedef bf16_t T;
+    constexpr int NT = 256, CS = 64, NG = 16 / LPW, NPC = ST * LPW + 1;
+    constexpr int NWC = ST == 1 ? 4 : 2;
+    constexpr int NR = ST * RB;                          // input rows staged per chunk
+    constexpr int RQ = ST == 1 ? RB + 2 : 2 * RB + 1;
+    constexpr int rowdw = NPC * CS;
+    __shared__ float lstat[2 * CS];
+    __shared__ __attribute__((aligned(16))) float lcoef[2 * CS];             // BatchNorm-1 scale, shift (re-read per phase: registers)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int cv = tid & 15, pl = tid >> 4;
+    const int grp = pl / LPW, jj = pl % LPW;
+    const int c0 = blockIdx.y * CS;
+    const int chan = c0 + cv * 4;
+    const bool chan_ok = chan < a.C;
+    const int chs = chan_ok ? chan : 0;
+    if (tid < 2 * CS) {
+        lstat[tid] = 0.f;
+        const int c = c0 + (tid & (CS - 1));
+        lcoef[tid] = c < a.C ? (tid < CS ? a.in.v1[c] : a.in.v2[c]) : 0.f;
+    }
+    __syncthreads();
+
+    unsigned wp[3][NWC][4];
+    {
+        float w[9][4];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            ldc4(a.w + (i64)k * a.C + chs, w[k]);
+            if (!chan_ok) { w[k][0] = w[k][1] = w[k][2] = w[k][3] = 0.f; }
+        }
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                wp[dy][0][q] = pk_bf16(w[dy * 3 + 0][q], w[dy * 3 + 1][q]);
+                wp[dy][1][q] = pk_bf16(w[dy * 3 + 2][q], 0.f);
+                if constexpr (ST == 1) {
+                    wp[dy][2][q] = pk_bf16(0.f, w[dy * 3 + 0][q]);
+                    wp[dy][3][q] = pk_bf16(w[dy * 3 + 1][q], w[dy * 3 + 2][q]);
+                }
+            }
+    }
+    wf_f2_t st0[2] = {wf_f2_t{0.f, 0.f}, wf_f2_t{0.f, 0.f}}, st1[2] = {wf_f2_t{0.f, 0.f}, wf_f2_t{0.f, 0.f}};
+
+    const int Hin = a.Hin, Win = a.Win, Hout = a.Hout, Wout = a.Wout;
+    const int ngroups = (a.planes + NG - 1) / NG;
+    const int nchunks = ST == 1 ? (Hin + RB) / RB : (Hout + RB - 1) / RB;
+    const T* inp = reinterpret_cast<const T*>(a.in.p);
+    T* outp = reinterpret_cast<T*>(a.out);
+    unsigned* tile = reinterpret_cast<unsigned*>(wf_smem);        // ring: [NG][RQ][NPC][64] dwords
+    unsigned* tplane = tile + grp * RQ * rowdw + cv * 4;
+    const unsigned inrow = (unsigned)Win * (unsigned)a.in.ld, outrow = (unsigned)Wout * (unsigned)a.C;
+    // staging roles: stride 1 = the walk role (4 channels, own output pair column); stride 2 = 8 channels per lane, one lane
+    // per input pair column (16-byte loads)
+    constexpr int SLW = 2 * LPW;
+    const int scv = tid & 7, spl = tid >> 3;
+    const int sgrp = ST == 1 ? grp : spl / SLW, kc = ST == 1 ? jj : spl % SLW;
+    const int sch = ST == 1 ? chan : c0 + scv * 8;
+    const int schs = sch < a.C ? sch : 0;
+    unsigned* splane_t = ST == 1 ? tplane : tile + sgrp * RQ * rowdw + scv * 8;
+    const unsigned cmask = (kc > 0 ? 0x0000ffffu : 0u) | 0xffff0000u;
+    const unsigned colhi = (unsigned)(2 * kc) * (unsigned)a.in.ld;
+    const unsigned lodelta = kc > 0 ? (unsigned)a.in.ld : 0u;
+    const unsigned collast = (unsigned)(Win - 1) * (unsigned)a.in.ld;
+    constexpr int NLC = ST == 1 ? LPW : SLW;                      // staging lanes per plane row
+    constexpr int NEX = (NR + NLC - 1) / NLC;                     // halo-column rows a lane stages per chunk
+
+    for (int pg = blockIdx.x; pg < ngroups; pg += gridDim.x) {
+        const int plane = pg * NG + grp;
+        const bool pvalid = plane < a.planes && chan_ok;
+        const int splane = pg * NG + sgrp;
+        const bool svalid = splane < a.planes && sch < a.C;
+        const T* in0 = inp + (i64)(splane < a.planes ? splane : 0) * Hin * Win * a.in.ld + schs;
+        T* out0 = outp + (i64)(plane < a.planes ? plane : 0) * Hout * Wout * a.C + chan + (unsigned)(2 * jj) * (unsigned)a.C;
+        // row -1 of the ring (slot 0): zeros
+        {
+            unsigned* z = splane_t + kc * CS;
+            if constexpr (ST == 1) *reinterpret_cast<uint4*>(z) = make_uint4(0, 0, 0, 0);
+            else { reinterpret_cast<uint4*>(z)[0] = make_uint4(0, 0, 0, 0); reinterpret_cast<uint4*>(z)[1] = make_uint4(0, 0, 0, 0); }
+            if (kc == 0) {
+                unsigned* zl = splane_t + (NPC - 1) * CS;
+                if constexpr (ST == 1) *reinterpret_cast<uint4*>(zl) = make_uint4(0, 0, 0, 0);
+                else { reinterpret_cast<uint4*>(zl)[0] = make_uint4(0, 0, 0, 0); reinterpret_cast<uint4*>(zl)[1] = make_uint4(0, 0, 0, 0); }
+            }
+        }
+        int slot_s = 1;                                  // ring slot of input row ST*s
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int s = chunk * RB;
+            const int hi_s = ST * s;                     // first input row staged by this chunk
+            // ---------------- stage SiLU(BN1(y1)) rows hi_s .. hi_s + NR - 1, x-pair-packed, into their ring slots
+            if constexpr (ST == 1) {
+                const float4 s4 = *reinterpret_cast<const float4*>(&lcoef[cv * 4]), t4 = *reinterpret_cast<const float4*>(&lcoef[CS + cv * 4]);
+                const wf_f2_t bs2[2] = {wf_f2_t{s4.x, s4.y}, wf_f2_t{s4.z, s4.w}}, bt2[2] = {wf_f2_t{t4.x, t4.y}, wf_f2_t{t4.z, t4.w}};
+                auto act_pack = [&](const uint2& rlo, const uint2& rhi) {
+                    wf_f2_t y0, y1v, z[2][2];
+                    wf_unpack(rlo, y0, y1v);
+                    {
+                        const wf_f2_t h0 = y0 * bs2[0] + bt2[0], h1 = y1v * bs2[1] + bt2[1];
+                        z[0][0] = h0 * wf_f2_t{sigmoidf_(h0.x), sigmoidf_(h0.y)};
+                        z[0][1] = h1 * wf_f2_t{sigmoidf_(h1.x), sigmoidf_(h1.y)};
+                    }
+                    wf_unpack(rhi, y0, y1v);
+                    {
+                        const wf_f2_t h0 = y0 * bs2[0] + bt2[0], h1 = y1v * bs2[1] + bt2[1];
+                        z[1][0] = h0 * wf_f2_t{sigmoidf_(h0.x), sigmoidf_(h0.y)};
+                        z[1][1] = h1 * wf_f2_t{sigmoidf_(h1.x), sigmoidf_(h1.y)};
+                    }
+                    return make_uint4(pk_bf16(z[0][0].x, z[1][0].x), pk_bf16(z[0][0].y, z[1][0].y), pk_bf16(z[0][1].x, z[1][1].x), pk_bf16(z[0][1].y, z[1][1].y));
+                };
+                uint2 rr[NR][2], er[NEX];
+                bool ok[NR], eok[NEX];
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    const int hi = hi_s + u;
+                    ok[u] = svalid && hi < Hin;
+                    const unsigned off = ok[u] ? (unsigned)hi * inrow + colhi : lodelta;
+                    rr[u][1] = wf_ld8(in0 + off);
+                    rr[u][0] = wf_ld8(in0 + off - lodelta);
+                }
+#pragma unroll
+                for (int e = 0; e < NEX; ++e) {
+                    const int u = kc + e * NLC;
+                    eok[e] = svalid && u < NR && hi_s + u < Hin;
+                    er[e] = wf_ld8(in0 + (eok[e] ? (unsigned)(hi_s + u) * inrow + collast : 0u));
+                }
+                int sl = slot_s;
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    uint4 o = act_pack(rr[u][0], rr[u][1]);
+                    const unsigned m = ok[u] ? cmask : 0u;
+                    o.x &= m; o.y &= m; o.z &= m; o.w &= m;
+                    *reinterpret_cast<uint4*>(splane_t + kc * CS + sl * rowdw) = o;
+                    sl = sl + 1 == RQ ? 0 : sl + 1;
+                }
+#pragma unroll
+                for (int e = 0; e < NEX; ++e) {
+                    const int u = kc + e * NLC;
+                    if (u < NR) {
+                        uint4 o = act_pack(er[e], er[e]);
+                        const unsigned m = eok[e] ? 0x0000ffffu : 0u;
+                        o.x &= m; o.y &= m; o.z &= m; o.w &= m;
+                        int se = slot_s + u; se = se >= RQ ? se - RQ : se;
+                        *reinterpret_cast<uint4*>(splane_t + (NPC - 1) * CS + se * rowdw) = o;
+                    }
+                }
+            } else {
+                wf_f2_t s8[4], t8[4];
+                {
+                    const float4 sa = *reinterpret_cast<const float4*>(&lcoef[scv * 8]), sb = *reinterpret_cast<const float4*>(&lcoef[scv * 8 + 4]);
+                    const float4 ta = *reinterpret_cast<const float4*>(&lcoef[CS + scv * 8]), tb = *reinterpret_cast<const float4*>(&lcoef[CS + scv * 8 + 4]);
+                    s8[0] = wf_f2_t{sa.x, sa.y}; s8[1] = wf_f2_t{sa.z, sa.w}; s8[2] = wf_f2_t{sb.x, sb.y}; s8[3] = wf_f2_t{sb.z, sb.w};
+                    t8[0] = wf_f2_t{ta.x, ta.y}; t8[1] = wf_f2_t{ta.z, ta.w}; t8[2] = wf_f2_t{tb.x, tb.y}; t8[3] = wf_f2_t{tb.z, tb.w};
+                }
+                auto act_pack8 = [&](const uint4& rlo, const uint4& rhi, const unsigned m, unsigned* dst) {
+                    const unsigned wa[4] = {rlo.x, rlo.y, rlo.z, rlo.w}, wb[4] = {rhi.x, rhi.y, rhi.z, rhi.w};
+                    unsigned o[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const wf_f2_t ya = wf_f2_t{__uint_as_float(wa[i] << 16), __uint_as_float(wa[i] & 0xffff0000u)};
+                        const wf_f2_t yb = wf_f2_t{__uint_as_float(wb[i] << 16), __uint_as_float(wb[i] & 0xffff0000u)};
+                        const wf_f2_t ha = ya * s8[i] + t8[i], hb = yb * s8[i] + t8[i];
+                        const wf_f2_t za = ha * wf_f2_t{sigmoidf_(ha.x), sigmoidf_(ha.y)};
+                        const wf_f2_t zb = hb * wf_f2_t{sigmoidf_(hb.x), sigmoidf_(hb.y)};
+                        o[2 * i] = pk_bf16(za.x, zb.x) & m;
+                        o[2 * i + 1] = pk_bf16(za.y, zb.y) & m;
+                    }
+                    reinterpret_cast<uint4*>(dst)[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                    reinterpret_cast<uint4*>(dst)[1] = make_uint4(o[4], o[5], o[6], o[7]);
+                };
+                uint4 rr[NR][2], er[NEX];
+                bool ok[NR], eok[NEX];
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    const int hi = hi_s + u;
+                    ok[u] = svalid && hi < Hin;
+                    const unsigned off = ok[u] ? (unsigned)hi * inrow + colhi : lodelta;
+                    rr[u][1] = *reinterpret_cast<const uint4*>(in0 + off);
+                    rr[u][0] = *reinterpret_cast<const uint4*>(in0 + off - lodelta);
+                }
+#pragma unroll
+                for (int e = 0; e < NEX; ++e) {
+                    const int u = kc + e * NLC;
+                    eok[e] = svalid && u < NR && hi_s + u < Hin;
+                    er[e] = *reinterpret_cast<const uint4*>(in0 + (eok[e] ? (unsigned)(hi_s + u) * inrow + collast : 0u));
+                }
+                int sl = slot_s;
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    act_pack8(rr[u][0], rr[u][1], ok[u] ? cmask : 0u, splane_t + kc * CS + sl * rowdw);
+                    sl = sl + 1 == RQ ? 0 : sl + 1;
+                }
+#pragma unroll
+                for (int e = 0; e < NEX; ++e) {
+                    const int u = kc + e * NLC;
+                    if (u < NR) {
+                        int se = slot_s + u; se = se >= RQ ? se - RQ : se;
+                        act_pack8(er[e], er[e], eok[e] ? 0x0000ffffu : 0u, splane_t + (NPC - 1) * CS + se * rowdw);
+                    }
+                }
+            }
+            __syncthreads();
+            // ---------------- walk down this chunk's output rows of the thread's output pair column (outputs 2jj, 2jj+1)
+            const int o_lo = ST == 1 ? (s > 0 ? s - 1 : 0) : s;
+            const int o_hi = ST == 1 ? (s + RB - 1 < Hout ? s + RB - 1 : Hout) : (s + RB < Hout ? s + RB : Hout);      // exclusive
+            if (pvalid && o_lo < o_hi) {
+                const unsigned* tc = tplane + (ST == 1 ? jj : 2 * jj) * CS;       // first ring pair of this output pair
+                auto finish = [&](const int oy, const float* acc0, const float* acc1) {
+                    T* dst = out0 + (unsigned)oy * outrow;
+                    const uint2 pk0 = make_uint2(pk_bf16(acc0[0], acc0[1]), pk_bf16(acc0[2], acc0[3]));
+                    const uint2 pk1 = make_uint2(pk_bf16(acc1[0], acc1[1]), pk_bf16(acc1[2], acc1[3]));
+                    *reinterpret_cast<uint2*>(dst) = pk0;
+                    *reinterpret_cast<uint2*>(dst + a.C) = pk1;
+                    wf_f2_t r0, r1;
+                    wf_unpack(pk0, r0, r1);
+                    st0[0] += r0; st0[1] += r1; st1[0] += r0 * r0; st1[1] += r1 * r1;
+                    wf_unpack(pk1, r0, r1);
+                    st0[0] += r0; st0[1] += r1; st1[0] += r0 * r0; st1[1] += r1 * r1;
+                };
+                if constexpr (ST == 1) {
+                    // ring slots of input rows o_lo - 1, o_lo, o_lo + 1
+                    int sl0 = slot_s + (o_lo - s) - 1; sl0 = sl0 < 0 ? sl0 + RQ : sl0;
+                    const int sl1 = sl0 + 1 == RQ ? 0 : sl0 + 1;
+                    int sl2 = sl1 + 1 == RQ ? 0 : sl1 + 1;
+                    uint4 tw[3][2];
+                    tw[0][0] = *reinterpret_cast<const uint4*>(tc + sl0 * rowdw); tw[0][1] = *reinterpret_cast<const uint4*>(tc + sl0 * rowdw + CS);
+                    tw[1][0] = *reinterpret_cast<const uint4*>(tc + sl1 * rowdw); tw[1][1] = *reinterpret_cast<const uint4*>(tc + sl1 * rowdw + CS);
+                    auto row_step = [&](const int oy, const uint4 (&t0)[2], const uint4 (&t1)[2], uint4 (&t2)[2]) {
+                        t2[0] = *reinterpret_cast<const uint4*>(tc + sl2 * rowdw);
+                        t2[1] = *reinterpret_cast<const uint4*>(tc + sl2 * rowdw + CS);
+                        sl2 = sl2 + 1 == RQ ? 0 : sl2 + 1;
+                        float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const uint4 p0 = dy == 0 ? t0[0] : dy == 1 ? t1[0] : t2[0];
+                            const uint4 p1 = dy == 0 ? t0[1] : dy == 1 ? t1[1] : t2[1];
+                            const unsigned x0[4] = {p0.x, p0.y, p0.z, p0.w}, x1[4] = {p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                acc0[q] = wf_dot2(x0[q], wp[dy][0][q], acc0[q]);
+                                acc0[q] = wf_dot2(x1[q], wp[dy][1][q], acc0[q]);
+                                acc1[q] = wf_dot2(x0[q], wp[dy][NWC - 2][q], acc1[q]);
+                                acc1[q] = wf_dot2(x1[q], wp[dy][NWC - 1][q], acc1[q]);
+                            }
+                        }
+                        finish(oy, acc0, acc1);
+                    };
+                    for (int oy = o_lo; oy < o_hi; oy += 3) {
+                        row_step(oy, tw[0], tw[1], tw[2]);
+                        if (oy + 1 < o_hi) row_step(oy + 1, tw[1], tw[2], tw[0]);
+                        if (oy + 2 < o_hi) row_step(oy + 2, tw[2], tw[0], tw[1]);
+                    }
+                } else {
+                    // output row o reads input rows 2o-1, 2o, 2o+1 = ring slots sa, sa+1, sa+2 (mod RQ), sa = slot_s - 1 + 2(o - s)
+                    int sa = slot_s - 1; sa = sa < 0 ? sa + RQ : sa;
+                    uint4 ta[3], tb[3], tcw[3];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) ta[m] = *reinterpret_cast<const uint4*>(tc + sa * rowdw + m * CS);
+                    auto row_step = [&](const int oy, const uint4 (&r0)[3], uint4 (&r1)[3], uint4 (&r2)[3]) {
+                        const int sb = sa + 1 >= RQ ? sa + 1 - RQ : sa + 1;
+                        const int sc = sb + 1 >= RQ ? sb + 1 - RQ : sb + 1;
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) {
+                            r1[m] = *reinterpret_cast<const uint4*>(tc + sb * rowdw + m * CS);
+                            r2[m] = *reinterpret_cast<const uint4*>(tc + sc * rowdw + m * CS);
+                        }
+                        sa = sc;
+                        float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const uint4 p0 = dy == 0 ? r0[0] : dy == 1 ? r1[0] : r2[0];
+                            const uint4 p1 = dy == 0 ? r0[1] : dy == 1 ? r1[1] : r2[1];
+                            const uint4 p2 = dy == 0 ? r0[2] : dy == 1 ? r1[2] : r2[2];
+                            const unsigned x0[4] = {p0.x, p0.y, p0.z, p0.w}, x1[4] = {p1.x, p1.y, p1.z, p1.w}, x2[4] = {p2.x, p2.y, p2.z, p2.w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                acc0[q] = wf_dot2(x0[q], wp[dy][0][q], acc0[q]);
+                                acc0[q] = wf_dot2(x1[q], wp[dy][1][q], acc0[q]);
+                                acc1[q] = wf_dot2(x1[q], wp[dy][0][q], acc1[q]);
+                                acc1[q] = wf_dot2(x2[q], wp[dy][1][q], acc1[q]);
+                            }
+                        }
+                        finish(oy, acc0, acc1);
+                    };
+                    for (int oy = o_lo; oy < o_hi; oy += 2) {
+                        row_step(oy, ta, tb, tcw);
+                        if (oy + 1 < o_hi) row_step(oy + 1, tcw, tb, ta);
+                    }
+                }
+            }
+            __syncthreads();
+            slot_s += NR; slot_s = slot_s >= RQ ? slot_s - RQ : slot_s;
+        }
+    }
+    if (a.stats) {
+        const unsigned v[8] = {__float_as_uint(st0[0].x), __float_as_uint(st0[0].y), __float_as_uint(st0[1].x), __float_as_uint(st0[1].y),
+                               __float_as_uint(st1[0].x), __float_as_uint(st1[0].y), __float_as_uint(st1[1].x), __float_as_uint(st1[1].y)};
+        float c4[4], d2[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const wf_u32x2_t r = __builtin_amdgcn_permlane16_swap(v[k], v[k + 4], false, false);
+            c4[k] = __uint_as_float(r.x) + __uint_as_float(r.y);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const wf_u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c4[k]), __float_as_uint(c4[k + 2]), false, false);
+            d2[k] = __uint_as_float(r.x) + __uint_as_float(r.y);
+        }
+        const int r = lane >> 4;                          // lane row r holds value index (r&1)*4 + (r>>1)*2 + {0,1}
+#pragma unroll
+        for (int k = 0; k < 2; ++k) atomicAdd(&lstat[(r & 1) * CS + cv * 4 + (r >> 1) * 2 + k], d2[k]);
+        __syncthreads();
+        if (tid < 2 * CS) {
+            const int which = tid / CS, c = c0 + tid % CS;
+            if (c < a.C) stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.C, which, c, lstat[tid]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
 #ifndef WF_LDS_BUDGET
@@ -379,7 +709,55 @@ static int launch_fw(const DwSpatialFwd& a, hipStream_t s) {
     return 0;
 }
 
+template <int ST, int LPW, int RB>
+static int launch_fc(const DwSpatialFwd& a, hipStream_t s) {
+    constexpr int NG = 16 / LPW, NPC = ST * LPW + 1, RQ = ST == 1 ? RB + 2 : 2 * RB + 1;
+    const size_t lds = (size_t)NG * RQ * NPC * 256;
+    auto kern = dw_spatial_fwd_chain_kernel<ST, LPW, RB>;
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        (void)hipGetLastError();
+    int bpc = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kern, 256, lds) != hipSuccess || bpc < 1) { (void)hipGetLastError(); bpc = 2; }
+    const int slices = (a.C + 63) / 64;
+    const i64 work = (a.planes + NG - 1) / NG;
+    i64 gx = (256 * bpc) / slices;
+    if (gx < 1) gx = 1;
+    if (gx > work) gx = work;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, slices), dim3(256), lds, s, a);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+// chained kernels: output rows per chunk from a.rows_band / DWN_DWS_FCHAIN_RB
+template <int ST, int LPW>
+static int launch_fc_rb(const DwSpatialFwd& a, hipStream_t s) {
+    const char* e = getenv("DWN_DWS_FCHAIN_RB");
+    // measured best at the metric shapes (tools/fwd_chain_check.py)
+    const int rb = a.rows_band > 0 ? a.rows_band : (e ? atoi(e) : (ST == 1 ? (LPW == 16 ? 4 : 6) : (LPW == 4 ? 1 : 2)));
+    if constexpr (ST == 1) {
+        if (rb <= 2) return launch_fc<1, LPW, 2>(a, s);
+        if (rb <= 4) return launch_fc<1, LPW, 4>(a, s);
+        if (rb <= 6) return launch_fc<1, LPW, 6>(a, s);
+        return launch_fc<1, LPW, 8>(a, s);
+    } else {
+        if (rb <= 1) return launch_fc<2, LPW, 1>(a, s);
+        if (rb <= 2) return launch_fc<2, LPW, 2>(a, s);
+        if (rb <= 3) return launch_fc<2, LPW, 3>(a, s);
+        return launch_fc<2, LPW, 4>(a, s);
+    }
+}
+
 int launch_dw_spatial_fwd_walk(const DwSpatialFwd& a, hipStream_t s) {
+    const char* ch = getenv("DWN_DWS_FCHAIN");            // read per call: A/B inside one process ("0": banded round-2 kernels)
+    if (!(ch && ch[0] == '0')) {
+        if (a.stride == 1) {
+            if (a.Wout == 32) return launch_fc_rb<1, 16>(a, s);
+            if (a.Wout == 16) return launch_fc_rb<1, 8>(a, s);
+            return launch_fc_rb<1, 4>(a, s);
+        }
+        if (a.Wout == 32) return launch_fc_rb<2, 16>(a, s);
+        if (a.Wout == 16) return launch_fc_rb<2, 8>(a, s);
+        return launch_fc_rb<2, 4>(a, s);
+    }
     if (a.stride == 1) {
         if (a.Wout == 32) return launch_fw<1, 16>(a, s);
         if (a.Wout == 16) return launch_fw<1, 8>(a, s);

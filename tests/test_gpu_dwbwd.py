@@ -25,7 +25,9 @@ def _desc(p, ld, **kw):
     return d
 
 
-def _both(planes, Hin, Win, Cc, stride, rows_band=0, seed=0):
+def _both(planes, Hin, Win, Cc, stride, rows_band=0, seed=0, impl="chain"):
+    """impl: "chain" = the round-3 chained stride-1 kernel (ring of row slots + LDS-DMA y1, the default), "banded" = the
+    round-2 banded row-walk kernel (stride 2 has only the banded kernel)."""
     d = dev()
     s = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device=d); g.manual_seed(seed)
@@ -39,9 +41,11 @@ def _both(planes, Hin, Win, Cc, stride, rows_band=0, seed=0):
     w = (torch.randn(9, Cc, device=d, generator=g) / 3.0).to(BF).float()
     out = {}
     old_env = os.environ.get("DWN_DWS_WALK_OFF")
+    old_chain = os.environ.get("DWN_DWS_CHAIN")
     try:
         for mode in ("old", "new"):
             os.environ["DWN_DWS_WALK_OFF"] = "1" if mode == "old" else "0"
+            os.environ["DWN_DWS_CHAIN"] = "1" if impl == "chain" else "0"
             dh1 = torch.full_like(y1, float("nan"))
             dw = torch.zeros(Cc, 9, device=d)
             st = torch.zeros(32 * 2 * Cc, dtype=torch.float64, device=d)
@@ -59,6 +63,10 @@ def _both(planes, Hin, Win, Cc, stride, rows_band=0, seed=0):
             os.environ.pop("DWN_DWS_WALK_OFF", None)
         else:
             os.environ["DWN_DWS_WALK_OFF"] = old_env
+        if old_chain is None:
+            os.environ.pop("DWN_DWS_CHAIN", None)
+        else:
+            os.environ["DWN_DWS_CHAIN"] = old_chain
     return out["old"], out["new"]
 
 
@@ -67,12 +75,16 @@ CASES = [
     (3, 18, 32, 64, 1), (5, 9, 16, 128, 1), (7, 5, 8, 64, 1), (2, 3, 32, 72, 1), (9, 1, 8, 64, 1), (1, 20, 16, 64, 1),
     (3, 36, 64, 64, 2), (5, 18, 32, 128, 2), (7, 9, 16, 64, 2), (2, 4, 64, 72, 2), (9, 1, 16, 64, 2), (3, 7, 32, 64, 2),
     (130, 9, 16, 448, 1), (130, 9, 16, 448, 2), (131, 5, 8, 448, 1), (129, 18, 32, 448, 2),
+    (1, 2, 32, 64, 1), (4, 7, 8, 200, 1), (33, 18, 32, 448, 1),
 ]
 
 
+@pytest.mark.parametrize("impl", ["chain", "banded"])
 @pytest.mark.parametrize("case", CASES)
-def test_walk_kernels_match_replaced_kernels(case):
-    (d0, w0, s0), (d1, w1, s1) = _both(*case)
+def test_walk_kernels_match_replaced_kernels(case, impl):
+    if impl == "banded" and case[4] == 2:
+        pytest.skip("stride 2 has one implementation (covered under impl=chain)")
+    (d0, w0, s0), (d1, w1, s1) = _both(*case, impl=impl)
     assert not torch.isnan(d1.float()).any()
     if case[4] == 1:
         assert torch.equal(d0.view(torch.int16), d1.view(torch.int16)), "dh1 differs"
@@ -87,10 +99,13 @@ def test_walk_kernels_match_replaced_kernels(case):
     assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-4
 
 
+@pytest.mark.parametrize("impl", ["chain", "banded"])
 @pytest.mark.parametrize("stride,rows_band", [(1, 1), (1, 2), (1, 4), (1, 7), (2, 2), (2, 4), (2, 6)])
-def test_walk_kernels_band_heights(stride, rows_band):
+def test_walk_kernels_band_heights(stride, rows_band, impl):
+    if impl == "banded" and stride == 2:
+        pytest.skip("stride 2 has one implementation")
     H, W = (18, 32) if stride == 1 else (36, 64)
-    (d0, w0, s0), (d1, w1, s1) = _both(3, H, W, 64, stride, rows_band=rows_band)
+    (d0, w0, s0), (d1, w1, s1) = _both(3, H, W, 64, stride, rows_band=rows_band, impl=impl)
     assert float((d0.float() != d1.float()).float().mean()) < (1e-3 if stride == 2 else 1e-30)
     assert float((w0 - w1).norm() / w0.norm()) < 2e-3
     assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-4

@@ -1,6 +1,7 @@
-"""Row-walk spatial depth-wise forward kernel (sensorium_amd/csrc/dwn_dwfwd.hip; reference op src/models/dwiseneuro.py:96-102)
-against the pair kernel it replaces, through dwn_dw_spatial_fwd with DWN_DWS_WALK_OFF toggled per call: y2 BIT-identical,
-BatchNorm-2 sums to summation order.  (The pair kernel is pinned to the oracle by tests/test_gpu_block.py.)"""
+"""Row-walk spatial depth-wise forward kernels (sensorium_amd/csrc/dwn_dwfwd.hip; reference op src/models/dwiseneuro.py:96-102)
+— the banded round-2 kernel and the chained round-3 kernel (ring of row slots, default) — against the pair kernel they replace,
+through dwn_dw_spatial_fwd with DWN_DWS_WALK_OFF / DWN_DWS_FCHAIN toggled per call: y2 BIT-identical, BatchNorm-2 sums to
+summation order, both strides.  (The pair kernel is pinned to the oracle by tests/test_gpu_block.py.)"""
 import ctypes as C
 import os
 
@@ -15,7 +16,7 @@ from tests.gpu_helpers import dev  # noqa: E402
 BF = torch.bfloat16
 
 
-def _both(planes, Hin, Win, Cc, stride, rows_band=0, seed=0):
+def _both(planes, Hin, Win, Cc, stride, rows_band=0, seed=0, impl="chain"):
     d = dev()
     s = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device=d); g.manual_seed(seed)
@@ -24,10 +25,11 @@ def _both(planes, Hin, Win, Cc, stride, rows_band=0, seed=0):
     coef = torch.cat([torch.rand(Cc, device=d, generator=g) + 0.5, torch.randn(Cc, device=d, generator=g) * 0.3])
     w = torch.randn(9, Cc, device=d, generator=g) / 3.0
     out = {}
-    saved = os.environ.get("DWN_DWS_WALK_OFF")
+    saved = {k: os.environ.get(k) for k in ("DWN_DWS_WALK_OFF", "DWN_DWS_FCHAIN")}
     try:
         for mode in ("old", "new"):
             os.environ["DWN_DWS_WALK_OFF"] = "1" if mode == "old" else "0"
+            os.environ["DWN_DWS_FCHAIN"] = "1" if impl == "chain" else "0"
             y2 = torch.full((planes * Hout * Wout, Cc), float("nan"), dtype=BF, device=d)
             st = torch.zeros(32 * 2 * Cc, dtype=torch.float64, device=d)
             a = L.DwSpatialFwdArgs()
@@ -41,24 +43,32 @@ def _both(planes, Hin, Win, Cc, stride, rows_band=0, seed=0):
             torch.cuda.synchronize()
             out[mode] = (y2, st.view(32, 2, Cc).sum(0))
     finally:
-        if saved is None:
-            os.environ.pop("DWN_DWS_WALK_OFF", None)
-        else:
-            os.environ["DWN_DWS_WALK_OFF"] = saved
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     return out["old"], out["new"]
 
 
+@pytest.mark.parametrize("impl", ["chain", "banded"])
 @pytest.mark.parametrize("case", [(3, 18, 32, 64, 1), (5, 9, 16, 128, 1), (7, 5, 8, 64, 1), (2, 3, 32, 72, 1), (9, 1, 8, 64, 1),
-                                  (1, 20, 16, 64, 1), (130, 9, 16, 448, 1), (131, 5, 8, 448, 1)])
-def test_fwd_walk_matches_pair_kernel(case):
-    (y0, s0), (y1, s1) = _both(*case)
+                                  (1, 20, 16, 64, 1), (130, 9, 16, 448, 1), (131, 5, 8, 448, 1), (1, 2, 32, 64, 1), (4, 7, 8, 200, 1),
+                                  # stride 2 (on by default since round 2; same cases as tests/test_gpu_dwbwd.py)
+                                  (3, 36, 64, 64, 2), (7, 9, 16, 64, 2), (2, 4, 64, 72, 2), (129, 18, 32, 448, 2), (5, 18, 32, 128, 2),
+                                  (9, 1, 16, 64, 2), (3, 7, 32, 64, 2), (3, 5, 16, 64, 2), (130, 9, 16, 448, 2)])
+def test_fwd_walk_matches_pair_kernel(case, impl):
+    (y0, s0), (y1, s1) = _both(*case, impl=impl)
     assert not torch.isnan(y1.float()).any()
     assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
     assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-5
 
 
-@pytest.mark.parametrize("rows_band", [1, 2, 4, 7])
-def test_fwd_walk_band_heights(rows_band):
-    (y0, s0), (y1, s1) = _both(3, 18, 32, 64, 1, rows_band=rows_band)
+@pytest.mark.parametrize("impl", ["chain", "banded"])
+@pytest.mark.parametrize("stride,rows_band", [(1, 1), (1, 2), (1, 4), (1, 7), (2, 1), (2, 2), (2, 3), (2, 4)])
+def test_fwd_walk_band_heights(stride, rows_band, impl):
+    """rows_band = output rows per band (banded) / per chunk (chained: rounded up to a built chunk height)."""
+    H, W = (18, 32) if stride == 1 else (36, 64)
+    (y0, s0), (y1, s1) = _both(3, H, W, 64, stride, rows_band=rows_band, impl=impl)
     assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
     assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-5
