@@ -251,6 +251,8 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="time every kernel family (adds event overhead)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU testing)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--ddp-comm", default="f32", choices=["f32", "bf16"], help="gradient exchange type (bf16: half the bytes "
+                    "on xGMI, fp32 master buckets)")
     ap.add_argument("--dry-run", action="store_true", help="testing only: launcher + rendezvous + timing plumbing, no GPU work")
     args = ap.parse_args()
 
@@ -284,6 +286,7 @@ def main():
     params = model_params(expansion, num_neurons)
     params["device"] = str(dev)
     params["amp"] = args.dtype == "bf16"
+    params["ddp_comm_dtype"] = args.ddp_comm
     torch.manual_seed(1234)            # identical init on every rank (GradBuckets also broadcasts rank 0)
     model = MouseModel(params)
     # reference init rule (src/utils.py:46-56): conv ~ N(0, sqrt(2/fan_out)), BN weight 1 / bias 0
@@ -467,6 +470,13 @@ def main():
                               f"{prof_steps} extra untimed steps with events around every launch",
             "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
         }
+        if model.buckets is not None:
+            out["ddp"] = {"backend": dist.get_backend(), "buckets": len(model.buckets.buckets),
+                          "bucket_mb": [round(b["flat"].numel() * 4 / 2 ** 20, 1) for b in model.buckets.buckets],
+                          "comm_dtype": args.ddp_comm,
+                          "ring_bytes_sent_per_rank_per_step": model.buckets.bytes_on_wire_per_step(),
+                          "gradients": "written by the HIP backward straight into the flat buckets; all-reduce (mean) per "
+                                       "bucket launched from autograd hooks, overlapped with the rest of backward"}
         if args.profile_all:
             out["family_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in fam_ms.items()}
         elif fam_all:

@@ -17,6 +17,7 @@ instead of a python loop over ``argwhere``; under ``torch.distributed`` gradient
 from __future__ import annotations
 
 import logging
+import os
 from typing import Optional
 
 import torch
@@ -140,7 +141,10 @@ class MouseModel(Model):
         params = [p for p in self.nn_module.parameters() if p.requires_grad]
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if distributed:
-            self.buckets = GradBuckets(self.nn_module)       # broadcasts rank 0's parameters and buffers
+            # broadcasts rank 0's parameters and buffers; params["ddp_comm_dtype"] / DWN_DDP_COMM=bf16: exchange bf16 copies
+            comm = self.params.get("ddp_comm_dtype", os.environ.get("DWN_DDP_COMM"))
+            comm = torch.bfloat16 if comm in (torch.bfloat16, "bf16", "bfloat16") else None
+            self.buckets = GradBuckets(self.nn_module, comm_dtype=comm)
             if self._model_ema is not None:                   # ... so the EMA copy taken earlier must follow (val_step uses it)
                 self._model_ema.set(self.nn_module)
         self.optimizer = MouseModel.optimizer[oname](params, **okwargs)

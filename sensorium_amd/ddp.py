@@ -79,16 +79,18 @@ class GradBuckets:
                 off += t.numel()
 
     def _add_bucket(self, params, optional: bool = False):
-        n = sum(p.numel() for p in params)
-        # optional buckets carry one "used by this rank" flag per parameter behind the gradients
-        flat = torch.zeros(n + (len(params) if optional else 0), dtype=params[0].dtype, device=params[0].device)
+        # every slice starts on a 16-byte boundary (the backward kernels clear / write their outputs with 16-byte stores)
         offsets, off = [], 0
         for p in params:
             offsets.append(off)
-            off += p.numel()
+            off += (p.numel() + 3) // 4 * 4
+        n = off
+        # optional buckets carry one "used by this rank" flag per parameter behind the gradients
+        flat = torch.zeros(n + (len(params) if optional else 0), dtype=params[0].dtype, device=params[0].device)
         views = [flat[o:o + p.numel()].view_as(p) for p, o in zip(params, offsets)]
         comm = torch.zeros_like(flat, dtype=self.comm_dtype) if self.comm_dtype is not None else None
         self.buckets.append(dict(params=params, flat=flat, offsets=offsets, views=views, numel=n, comm=comm,
+                                 true_numel=sum(p.numel() for p in params),
                                  index={id(p): i for i, p in enumerate(params)}, arrived=[False] * len(params),
                                  flags_sent=None, pending=len(params), count=len(params), optional=optional, launched=False))
 
@@ -191,7 +193,7 @@ class GradBuckets:
                         p.grad = v
 
     def num_elements(self) -> int:
-        return sum(b["numel"] for b in self.buckets)
+        return sum(b["true_numel"] for b in self.buckets)
 
     def bytes_on_wire_per_step(self) -> int:
         """Bytes one rank sends (= receives) per step for the ring all-reduce of every bucket: 2 (N-1)/N x bucket bytes."""

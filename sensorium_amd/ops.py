@@ -56,6 +56,22 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
 
+def grad_out(param: torch.Tensor, zero: bool = False) -> torch.Tensor:
+    """The fp32 tensor a backward kernel writes ``param``'s gradient into.  Under data parallelism ``GradBuckets`` gives
+    every parameter a slice of a flat all-reduce bucket (``param._dwn_grad_slot``): the gradient is produced *there* — a
+    fresh view object, so autograd adopts it as ``param.grad`` without a copy and the bucket needs no gather pass.  When a
+    gradient is already being accumulated (``param.grad`` set: argus ``iter_size`` > 1) or no bucket exists, a new tensor in
+    the parameter's own shape (same memory layout as the kernels' 2-D views, so autograd can take ownership)."""
+    slot = getattr(param, "_dwn_grad_slot", None)
+    if slot is not None and param.grad is None:
+        flat, off = slot
+        g = flat[off:off + param.numel()].view(param.shape)
+        return g.zero_() if zero else g
+    if zero:
+        return torch.zeros_like(param, dtype=torch.float32)
+    return torch.empty_like(param, dtype=torch.float32)
+
+
 # ------------------------------------------------------------------------------------------------
 # index maps / positional-encoding tables (host side, cached by the modules)
 # ------------------------------------------------------------------------------------------------
@@ -138,9 +154,9 @@ class StemFn(torch.autograd.Function):
         B, Cin, T, H, W = x.shape
         C0 = weight.shape[0]
         dout = dout.contiguous()
-        dw = torch.zeros_like(weight, dtype=torch.float32)
-        dgamma = torch.empty(C0, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(C0, dtype=torch.float32, device=dev)
+        dw = grad_out(ctx.mod.stem[0].weight, zero=True)
+        dgamma = grad_out(bn.weight)
+        dbeta = grad_out(bn.bias)
         a = L.StemArgs()
         a.dtype = _DT[ctx.dtype]; a.training = 1; a.B = B; a.Cin = Cin; a.C0 = C0; a.S = T * H * W
         a.eps = bn.eps; a.momentum = bn.momentum
@@ -260,8 +276,8 @@ class BlockFn(torch.autograd.Function):
         a.y1 = y1.data_ptr(); a.y2 = y2.data_ptr(); a.y3 = y3.data_ptr(); a.y4 = y4.data_ptr()
         a.z3 = z3.data_ptr()
         bns = blk.bn_modules()
-        dg = [torch.empty(c, **f32) for c in (Cmid, Cmid, Cmid, Cout, Cout)]
-        db = [torch.empty(c, **f32) for c in (Cmid, Cmid, Cmid, Cout, Cout)]
+        dg = [grad_out(bn.weight) for bn in bns]
+        db = [grad_out(bn.bias) for bn in bns]
         a.bn1, a.bn2, a.bn3, a.bn4, a.bnsc = (_bn_struct(bn, cf, g_, b_) for bn, cf, g_, b_ in zip(bns, coefs, dg, db))
         m_in, m_out = B * T * Hin * Win, B * T * Hout * Wout
         buf_a = torch.empty(max(m_in, m_out) * Cmid, dtype=dtype, device=dev)
@@ -273,12 +289,13 @@ class BlockFn(torch.autograd.Function):
         # gradients are allocated in the parameters' own shapes (same memory layout as the kernels' 2-D views) so
         # that autograd can take ownership instead of cloning a view
         # (dwn_block_backward clears the four atomically accumulated weight gradients itself, in its prep launch)
-        dw_pw = torch.empty_like(blk.conv_pw[0].weight, dtype=torch.float32)
-        dw_dws = torch.empty_like(blk.spat_covn_dw[0].weight, dtype=torch.float32)
-        dw_dwt = torch.empty_like(blk.temp_covn_dw[0].weight, dtype=torch.float32)
-        dw_pwl = torch.empty_like(blk.conv_pwl[0].weight, dtype=torch.float32)
-        dse_wr = torch.empty_like(blk.se.conv_reduce.weight, dtype=torch.float32); dse_br = torch.empty(R, **f32)
-        dse_we = torch.empty_like(blk.se.conv_expand.weight, dtype=torch.float32); dse_be = torch.empty(Cmid, **f32)
+        # ... or, under data parallelism, straight into the parameters' slices of the all-reduce buckets (grad_out)
+        dw_pw = grad_out(blk.conv_pw[0].weight)
+        dw_dws = grad_out(blk.spat_covn_dw[0].weight)
+        dw_dwt = grad_out(blk.temp_covn_dw[0].weight)
+        dw_pwl = grad_out(blk.conv_pwl[0].weight)
+        dse_wr = grad_out(blk.se.conv_reduce.weight); dse_br = grad_out(blk.se.conv_reduce.bias)
+        dse_we = grad_out(blk.se.conv_expand.weight); dse_be = grad_out(blk.se.conv_expand.bias)
         a.dout = dout.data_ptr(); a.dx = dx.data_ptr()
         a.buf_a = buf_a.data_ptr(); a.buf_b = buf_b.data_ptr(); a.dy4 = dy4.data_ptr(); a.da0 = da0.data_ptr()
         a.dw_pw = dw_pw.data_ptr(); a.dw_dws = dw_dws.data_ptr(); a.dw_dwt = dw_dwt.data_ptr()
@@ -371,8 +388,8 @@ class CortexFn(torch.autograd.Function):
         Cc = layer.out_features
         bn, bnsc = layer.bn.bn, layer.bn_sc.bn
         f32 = dict(dtype=torch.float32, device=dev)
-        dgm, dbm, dgs, dbs = (torch.empty(Cc, **f32) for _ in range(4))
-        dw = torch.zeros_like(weight, dtype=torch.float32)
+        dgm, dbm, dgs, dbs = grad_out(bn.weight), grad_out(bn.bias), grad_out(bnsc.weight), grad_out(bnsc.bias)
+        dw = grad_out(layer.conv.weight, zero=True)
         dx = torch.empty_like(x)
         a = L.CortexArgs()
         a.dtype = _DT[dtype]; a.training = 1; a.B = B; a.T = T; a.Cin = Cin; a.C = Cc
@@ -428,8 +445,9 @@ class ReadoutFn(torch.autograd.Function):
         B, T, Cin = x.shape
         n = mod.out_features
         dx = torch.empty_like(x)
-        dw = torch.zeros_like(weight, dtype=torch.float32)
-        db = torch.zeros(bias.shape[0], dtype=torch.float32, device=dev)
+        conv = mod.layer[1]
+        dw = grad_out(conv.weight, zero=True)
+        db = grad_out(conv.bias, zero=True)
         a = L.ReadoutArgs()
         a.dtype = _DT[x.dtype]; a.B = B; a.T = T; a.Cin = Cin; a.groups = mod.groups; a.n_out = n
         a.softplus_beta = mod.softplus_beta

@@ -88,17 +88,18 @@ class FusedAdamWEma(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
-            params = [p for p in group["params"] if p.grad is not None]
-            if not params:
+        for gi, group in enumerate(self.param_groups):
+            live = [p for p in group["params"] if p.grad is not None]
+            if not live:
                 continue
-            dev = params[0].device
-            if not params[0].is_cuda:
+            dev = live[0].device
+            if not live[0].is_cuda:
                 raise RuntimeError("FusedAdamWEma: parameters must be on a GPU (no CPU fallback)")
-            entries = np.zeros(len(params), dtype=_ENTRY_DTYPE)
-            step = None
-            keep = []
-            for i, p in enumerate(params):
+            # one launch per distinct step count: parameters a step left without a gradient (the other mice's readouts under
+            # forward(x, index), dwiseneuro.py:404-405) are skipped like torch.optim.AdamW skips them, so their bias
+            # corrections lag; ordinarily every parameter shares one count and this is a single launch
+            by_step = {}
+            for p in live:
                 if p.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError("FusedAdamWEma: fp32 contiguous parameters only")
                 st = self.state[p]
@@ -107,23 +108,28 @@ class FusedAdamWEma(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
-                step = st["step"] if step is None else step
-                if st["step"] != step:
-                    raise RuntimeError("FusedAdamWEma: parameters of one group must share the step count")
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                keep.append(g)
-                ema = self._ema_of.get(id(p))
-                entries[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                              0 if ema is None else ema.data_ptr(), p.numel(), 0, 0)
-            table = self._tables.setdefault(id(group), _TableCache()).get(entries, dev)
+                by_step.setdefault(int(st["step"]), []).append(p)
             b1, b2 = group["betas"]
-            L.check(L.lib.dwn_adamw_ema_multi(table.data_ptr(), len(params), self.max_blocks, float(group["lr"]),
-                                              float(b1), float(b2), float(group["eps"]),
-                                              float(group["weight_decay"]), int(step), self.ema_decay,
-                                              float(self.grad_scale), dev.index,
-                                              torch.cuda.current_stream(dev).cuda_stream),
-                    "dwn_adamw_ema_multi")
-            del keep
+            for step, params in sorted(by_step.items()):
+                entries = np.zeros(len(params), dtype=_ENTRY_DTYPE)
+                keep = []
+                for i, p in enumerate(params):
+                    st = self.state[p]
+                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    keep.append(g)
+                    ema = self._ema_of.get(id(p))
+                    entries[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                  0 if ema is None else ema.data_ptr(), p.numel(), 0, 0)
+                # the table cache is keyed by the set of parameters taking part, so alternating sets do not thrash it
+                key = (gi, tuple(id(p) for p in params)) if len(params) != len(group["params"]) else (gi, None)
+                table = self._tables.setdefault(key, _TableCache()).get(entries, dev)
+                L.check(L.lib.dwn_adamw_ema_multi(table.data_ptr(), len(params), self.max_blocks, float(group["lr"]),
+                                                  float(b1), float(b2), float(group["eps"]),
+                                                  float(group["weight_decay"]), int(step), self.ema_decay,
+                                                  float(self.grad_scale), dev.index,
+                                                  torch.cuda.current_stream(dev).cuda_stream),
+                        "dwn_adamw_ema_multi")
+                del keep
         return loss
 
 

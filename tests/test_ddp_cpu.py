@@ -143,11 +143,29 @@ def _worker_optional(rank, world, port, ret):
         for n, p in model.named_parameters():
             assert p.grad is not None, n               # unused readouts receive the other rank's (averaged) gradient
             assert torch.allclose(p.grad, ref[n], rtol=1e-5, atol=1e-6), n
-        # a second step where nobody uses readout 1: its averaged gradient is exactly zero, nothing hangs
+        # a second step where nobody uses readout 1: nothing hangs, and — as in a single process — it keeps grad None on
+        # every rank (the "used" flags ride in the bucket tail), so the optimizer skips it everywhere alike
         buckets.zero_grad()
         model(torch.randn(4, 6), index=0).sum().backward()
         buckets.finish()
-        assert float(model.readouts[1].weight.grad.abs().max()) == 0.0
+        assert model.readouts[1].weight.grad is None and model.readouts[1].bias.grad is None
+        assert model.readouts[0].weight.grad is not None and model.trunk.weight.grad is not None
+        # third step: rank 0 uses readout 0, rank 1 uses readout 1 again -> flags change back, values are right
+        buckets.zero_grad()
+        torch.manual_seed(40 + rank)
+        model(torch.randn(4, 6), index=rank).pow(2).sum().backward()
+        buckets.finish()
+        ref = {n: torch.zeros_like(p) for n, p in model.named_parameters()}
+        for r in range(world):
+            m2 = _TwoHeads()
+            m2.load_state_dict(model.state_dict())
+            torch.manual_seed(40 + r)
+            m2(torch.randn(4, 6), index=r).pow(2).sum().backward()
+            for n, p in m2.named_parameters():
+                if p.grad is not None:
+                    ref[n] += p.grad / world
+        for n, p in model.named_parameters():
+            assert p.grad is not None and torch.allclose(p.grad, ref[n], rtol=1e-5, atol=1e-6), n
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
@@ -159,6 +177,93 @@ def test_grad_buckets_optional_readouts_world2():
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     procs = [ctx.Process(target=_worker_optional, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    for p in procs:
+        assert p.exitcode == 0, "a rank failed"
+    assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+class _DirectLinear(torch.autograd.Function):
+    """y = x W^T whose backward writes dW where ops.grad_out says — the way the HIP backward passes do."""
+
+    @staticmethod
+    def forward(ctx, x, w, holder):
+        ctx.save_for_backward(x)
+        ctx.holder = holder
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        from sensorium_amd.ops import grad_out
+        (x,) = ctx.saved_tensors
+        w = ctx.holder.weight
+        dw = grad_out(w)
+        dw.copy_(dy.t() @ x)
+        return dy @ w, dw, None
+
+
+class _DirectNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(6, 5, bias=False)
+        self.b = torch.nn.Linear(5, 3, bias=False)
+
+    def forward(self, x):
+        return _DirectLinear.apply(torch.tanh(_DirectLinear.apply(x, self.a.weight, self.a)), self.b.weight, self.b)
+
+
+def _worker_direct(rank, world, port, ret, comm_dtype):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sensorium_amd.ddp import GradBuckets
+        torch.manual_seed(5)
+        model = _DirectNet()
+        buckets = GradBuckets(model, comm_dtype=comm_dtype)
+        tol = dict(rtol=1e-5, atol=1e-6) if comm_dtype is None else dict(rtol=2e-2, atol=1e-3)
+        for n_bwd in (1, 2):                                       # 2 = gradient accumulation (argus iter_size)
+            buckets.zero_grad(n_bwd)
+            for c in range(n_bwd):
+                torch.manual_seed(9 + rank + 10 * c)
+                model(torch.randn(4, 6)).pow(2).sum().backward()
+                if c == 0:
+                    # the gradient was produced inside the bucket: autograd adopted the view, no copy
+                    for b in buckets.buckets:
+                        for p, v in zip(b["params"], b["views"]):
+                            assert p.grad.data_ptr() == v.data_ptr()
+            buckets.finish()
+            ref = {n: 0 for n, _ in model.named_parameters()}
+            for r in range(world):
+                m2 = torch.nn.Sequential(torch.nn.Linear(6, 5, bias=False), torch.nn.Tanh(), torch.nn.Linear(5, 3, bias=False))
+                m2[0].weight.data.copy_(model.a.weight.data); m2[2].weight.data.copy_(model.b.weight.data)
+                for c in range(n_bwd):
+                    torch.manual_seed(9 + r + 10 * c)
+                    m2(torch.randn(4, 6)).pow(2).sum().backward()
+                ref["a.weight"] = ref["a.weight"] + m2[0].weight.grad / world
+                ref["b.weight"] = ref["b.weight"] + m2[2].weight.grad / world
+            for n, p in model.named_parameters():
+                assert torch.allclose(p.grad, ref[n], **tol), (n, n_bwd, (p.grad - ref[n]).abs().max())
+        # 2 (N-1)/N x bytes, N = 2; slices padded to 16 bytes: 30 -> 32 and 15 -> 16 elements
+        assert buckets.bytes_on_wire_per_step() == (48 * (4 if comm_dtype is None else 2))
+        for b in buckets.buckets:
+            assert all(v.data_ptr() % 16 == 0 for v in b["views"])
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("comm_dtype", [None, torch.bfloat16])
+def test_grad_buckets_direct_write_and_comm_dtype_world2(comm_dtype):
+    """Gradients written straight into the bucket slices (ops.grad_out) — no gather pass — with and without gradient
+    accumulation, exchanged in fp32 or as bf16 copies (fp32 master bucket)."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker_direct, args=(r, world, port, ret, comm_dtype)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
