@@ -409,12 +409,26 @@ static size_t rc_fwd_lds_bytes(int Cin, int E, int Win, int stride, int R, int* 
     return (size_t)2 * FP * Cin * 2 + (size_t)FP * 256 + (size_t)2 * rc_blob_bytes_c(Cin) + (size_t)8 * E + (size_t)(RC_NT / 64) * 512;
 }
 
+// ONE predicate for "a band of R output rows can be launched": the tile must fit the LDS *and* one of the two compiled
+// register geometries — (MU_A pair tiles per wave, MI_A pixel pairs per thread) or (MU_B, MI_B).  rc_supported() (what the
+// block forward asks before it drops conv_pw) and the launcher both use it, so a plane the launcher would refuse (e.g.
+// Cin = 64, stride 1, Win = 130: the LDS fits, no geometry does) falls back to conv_pw + stencil instead of failing.
+static bool rc_fits(int Cin, int E, int Win, int Wout, int stride, int R, bool* few) {
+    int FPq = 0;
+    if (rc_fwd_lds_bytes(Cin, E, Win, stride, R, &FPq) > RC_LDS_MAX) return false;
+    const int units = ((FPq >> 4) + RC_NT / 256 - 1) / (RC_NT / 256);
+    const int items = (R * ((Wout + 1) >> 1) + RC_NT / 16 - 1) / (RC_NT / 16);
+    if (units <= RC_MU_B && items <= RC_MI_B(Cin)) { if (few) *few = false; return true; }
+    if (units <= RC_MU_A && items <= RC_MI_A) { if (few) *few = true; return true; }
+    return false;
+}
+
 static bool rc_supported(int dtype, int Cin, int E, int ks, int stride, int Hin, int Win) {
     static const bool off = getenv("DWN_RC_OFF") != nullptr;
     if (off || dtype != DWN_BF16 || ks != 3 || (stride != 1 && stride != 2)) return false;
     if ((Cin != 64 && Cin != 128) || E % 64 || E <= 0) return false;
     if (Hin < 1 || Win < 2) return false;
-    return rc_fwd_lds_bytes(Cin, E, Win, stride, 1, nullptr) <= RC_LDS_MAX;
+    return rc_fits(Cin, E, Win, (Win - 1) / stride + 1, stride, 1, nullptr);
 }
 
 #ifdef RC_PROFILE
@@ -458,17 +472,8 @@ int dwn_dw_spatial_fwd_rc(const dwn_dw_spatial_rc_fwd_args* ap, int device, void
     k.a0 = (const bf16_t*)x.a0; k.a0_ld = x.a0_ld; k.blob = (const unsigned char*)x.blob; k.out = (bf16_t*)x.out;
     k.stats = x.stats; k.planes = x.planes; k.Hin = x.Hin; k.Win = x.Win; k.Hout = x.Hout; k.Wout = x.Wout; k.E = x.E;
     k.round_y1 = x.round_y1;
-    // a tile must fit the LDS and one of the two compiled register geometries: (MU_A pair tiles per wave, MI_A pixel pairs
-    // per thread) or (MU_B, MI_B); among the fitting band heights the largest wins, split evenly over the plane
-    auto fits = [&](int R, bool* few) {
-        int FPq = 0;
-        if (rc_fwd_lds_bytes(x.Cin, x.E, x.Win, x.stride, R, &FPq) > RC_LDS_MAX) return false;
-        const int units = ((FPq >> 4) + RC_NT / 256 - 1) / (RC_NT / 256);
-        const int items = (R * ((x.Wout + 1) >> 1) + RC_NT / 16 - 1) / (RC_NT / 16);
-        if (units <= RC_MU_B && items <= RC_MI_B(x.Cin)) { *few = false; return true; }
-        if (units <= RC_MU_A && items <= RC_MI_A) { *few = true; return true; }
-        return false;
-    };
+    // among the band heights that fit (rc_fits) the largest wins, split evenly over the plane
+    auto fits = [&](int R, bool* few) { return rc_fits(x.Cin, x.E, x.Win, x.Wout, x.stride, R, few); };
     int R = x.rows_band;
     bool few_items = false;
     if (R <= 0) {

@@ -327,12 +327,15 @@ class DwiseNeuro(nn.Module):
         layers = [m for m in self.modules() if isinstance(m, DropPath) and m.drop_prob > 0.0 and m.training]
         if not layers:
             return
-        keep = getattr(self, "_dp_keep", None)
-        if keep is None or keep.device != device or keep.shape[0] != len(layers):
-            keep = torch.tensor([1.0 - m.drop_prob for m in layers], dtype=torch.float32, device=device).unsqueeze(1)
-            self._dp_keep = keep
+        probs = tuple(m.drop_prob for m in layers)
+        cache = getattr(self, "_dp_keep", None)
+        if cache is None or cache[0] != probs or cache[1].device != device:      # rebuilt when a drop-path schedule changes a rate
+            cache = (probs, torch.tensor([1.0 - q for q in probs], dtype=torch.float32, device=device).unsqueeze(1))
+            self._dp_keep = cache
+        keep = cache[1]
         u = torch.rand(len(layers), batch, dtype=torch.float32, device=device)
-        factors = torch.floor(u + keep) / keep               # floor(u + keep) is 1 with probability keep
+        # floor(u + keep) is 1 with probability keep; keep == 0 (drop_prob 1): factor 0, as DropPath.sample (no 0/0)
+        factors = torch.where(keep > 0, torch.floor(u + keep) / keep.clamp_min(1e-30), torch.zeros_like(u))
         for m, row in zip(layers, factors.unbind(0)):
             m._pooled = row
 

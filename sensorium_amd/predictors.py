@@ -95,10 +95,12 @@ class Predictor:
         """Accepts the reference's call ``predict_trial(video, behavior, pupil_center, mouse_index)`` (numpy arrays in the
         on-disk layout, src/predictors.py:36-41) and the pre-processed form ``predict_trial(inputs, mouse_index)`` with
         ``inputs`` = (5, L, H, W) as produced by an inputs processor."""
-        if pupil_center is None and mouse_index is None:
-            if behavior is None:
+        if pupil_center is None and (mouse_index is None or behavior is None):
+            # pre-processed form: predict_trial(inputs, k) or predict_trial(inputs, mouse_index=k)
+            index = behavior if mouse_index is None else mouse_index
+            if index is None:
                 raise TypeError("predict_trial: mouse_index is required")
-            return (video if torch.is_tensor(video) else torch.from_numpy(np.asarray(video))), int(behavior)
+            return (video if torch.is_tensor(video) else torch.from_numpy(np.asarray(video))), int(index)
         if mouse_index is None:
             raise TypeError("predict_trial: mouse_index is required")
         if self.inputs_processor is None:
@@ -111,8 +113,11 @@ class Predictor:
                       num_neurons: Optional[int] = None) -> np.ndarray:
         """Returns (N, L) fp32: every window ending at frame ``index`` adds its prediction to the frames it covers, and the
         sum is divided by the accumulated blend weights (src/predictors.py:43-55; like the reference, the predictions themselves
-        are not multiplied by the blend weights).  Accumulation happens on the device, one deterministic pass per window
-        position (frames are distinct within a pass), one device-to-host copy per trial."""
+        are not multiplied by the blend weights).  Accumulation happens on the device, one pass per window position (frames
+        are distinct within a pass: the blend itself is order-independent), one device-to-host copy per trial.
+        Reproducibility: the bf16 eval forward sums the SqueezeExcite pooling with fp32 atomics inside the temporal kernel, so
+        two runs agree to summation order (~1e-6 relative), not bit for bit; set DWN_EVAL_Z3_OFF=1 for the separate,
+        order-fixed pooling pass."""
         inputs, mouse_index = self._make_inputs(video, behavior, pupil_center, mouse_index)
         gen = self.indexes_generator
         device = self.model.device

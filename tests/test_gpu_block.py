@@ -51,6 +51,15 @@ CASES = [
     (8, 16, 2, 3, 4, 2, 3, 1, 5),
     (24, 40, 2, 7, 4, 2, 4, 7, 9),
     (16, 16, 1, 5, 4, 2, 1, 4, 1),
+    # the plane widths the chained / row-walk bf16 stencils are built for (32 / 16 / 8 output columns, both strides, the 5x8
+    # planes of the last block), straight against the oracle
+    (64, 64, 1, 7, 32, 1, 4, 18, 32),
+    (64, 64, 2, 7, 32, 1, 3, 36, 64),
+    (64, 128, 2, 7, 32, 1, 4, 18, 32),
+    (128, 128, 1, 7, 32, 2, 4, 5, 8),
+    (64, 64, 2, 7, 32, 2, 3, 9, 16),
+    # a plane too wide for either register geometry of the y1-rebuilding eval stencil (LDS fits): eval must fall back
+    (64, 64, 1, 7, 32, 1, 2, 4, 130),
 ]
 
 
@@ -122,10 +131,11 @@ def test_block_train_forward_backward(case, dtype, drop):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case_id", [1, 3, 4])
+@pytest.mark.parametrize("case_id", [1, 3, 4, 9, 10, 12, 14])
 def test_block_eval_forward(dtype, case_id):
-    """Eval-mode forward.  Cases 3 and 4 (64 input channels, bf16) take the y1-recomputing stencil (dwn_dw_spatial_fwd_rc:
-    conv_pw never runs as its own pass); case 1 and every fp32 run take the materialised path."""
+    """Eval-mode forward.  The cases with 64 / 128 input channels take, in bf16, the y1-recomputing stencil
+    (dwn_dw_spatial_fwd_rc: conv_pw never runs as its own pass) — except case 14, whose 130-pixel rows fit neither register
+    geometry of that kernel and must fall back to conv_pw + stencil; case 1 and every fp32 run take the materialised path."""
     cin, cout, stride, exp, ser, B, T, H, W = CASES[case_id]
     blk, pe = make_block(cin, cout, stride, exp, ser, seed=3)
     sd = {"blk." + k: v.clone().double() if v.is_floating_point() else v.clone() for k, v in blk.state_dict().items()}

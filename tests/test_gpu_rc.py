@@ -99,6 +99,10 @@ def test_rc_unsupported_configuration_is_refused():
     assert L.lib.dwn_dw_spatial_rc_supported(L.DWN_F32, 64, 448, 3, 1, 18, 32) == 0
     assert L.lib.dwn_dw_spatial_rc_supported(L.DWN_BF16, 256, 1792, 3, 1, 5, 8) == 0
     assert L.lib.dwn_dw_spatial_rc_supported(L.DWN_BF16, 64, 440, 3, 1, 18, 32) == 0
+    # planes whose one-row tile fits the LDS but neither register geometry: refused by the SAME predicate the launcher uses
+    assert L.lib.dwn_dw_spatial_rc_supported(L.DWN_BF16, 64, 448, 3, 1, 18, 130) == 0
+    assert L.lib.dwn_dw_spatial_rc_supported(L.DWN_BF16, 64, 448, 3, 2, 18, 160) == 0
+    assert L.lib.dwn_dw_spatial_rc_supported(L.DWN_BF16, 64, 448, 3, 1, 18, 64) == 1
     ra = L.DwSpatialRcFwdArgs()
     dummy = torch.zeros(64, dtype=torch.uint8, device=dev())
     ra.a0 = dummy.data_ptr(); ra.blob = dummy.data_ptr(); ra.out = dummy.data_ptr(); ra.a0_ld = 256

@@ -165,7 +165,62 @@ def test_grad_bucket_layout_for_the_benchmark_model():
     sizes = [b["flat"].numel() * 4 / 2 ** 20 for b in buckets.buckets]
     params = [p for p in model.parameters() if p.requires_grad]
     assert buckets.buckets[0]["params"][0] is params[-1]                    # last registered parameter leads
-    assert sum(b["flat"].numel() for b in buckets.buckets) == sum(p.numel() for p in params)
+    assert buckets.num_elements() == sum(p.numel() for p in params)
+    # slices are padded to 16 bytes (the backward kernels write them with 16-byte stores) + one "used" flag per optional
+    # parameter: < 0.01 % over the parameter count, every slice aligned
+    extra = sum(b["flat"].numel() for b in buckets.buckets) - sum(p.numel() for p in params)
+    assert 0 <= extra <= 4 * len(params)
+    assert all(o % 4 == 0 for b in buckets.buckets for o in b["offsets"])
     assert sizes[0] > 60 and all(s < 20 for s in sizes[1:]) and len(sizes) >= 3, sizes
     assert sizes[-1] < 12, sizes                                            # the only bucket exposed after backward
 
+
+
+def test_pooled_drop_path_draws_follow_the_reference_rates():
+    """DwiseNeuro._draw_drop_paths: one uniform draw for all stochastic-depth layers of a forward pass.  Per layer the factor
+    is Bernoulli(keep) / keep with keep = 1 - 0.1 * i / 9 in core block i and 0.9 in every cortex layer
+    (reference: src/models/dwiseneuro.py:46-54, 317, 256/382); a layer consumes its draw exactly once."""
+    import torch
+    from sensorium_amd.dwiseneuro import DropPath, DwiseNeuro
+    net = DwiseNeuro(readout_outputs=(8,), core_features=(8,) * 9, spatial_strides=(1,) * 9, cortex_features=(16, 16, 16),
+                     expansion_ratio=3, se_reduce_ratio=4, drop_path_rate=0.1)
+    net.train()
+    layers = [m for m in net.modules() if isinstance(m, DropPath)]
+    assert len(layers) == 12
+    want = [0.1 * i / 9 for i in range(9)] + [0.1] * 3
+    assert [round(m.drop_prob, 6) for m in layers] == [round(p, 6) for p in want]
+    torch.manual_seed(0)
+    B, rounds = 512, 40
+    kept = torch.zeros(12)
+    for _ in range(rounds):
+        net._draw_drop_paths(B, torch.device("cpu"))
+        for i, m in enumerate(layers):
+            if m.drop_prob == 0.0:
+                assert m._pooled is None and m.sample(B, torch.device("cpu")) is None        # layer 0 never drops
+                continue
+            f = m.sample(B, torch.device("cpu"))
+            assert m._pooled is None, "a layer's draw must be consumed exactly once"
+            keep = 1.0 - m.drop_prob
+            vals = torch.unique(f)
+            assert all(float(v) == 0.0 or abs(float(v) - 1.0 / keep) < 1e-6 for v in vals), vals
+            kept[i] += float((f > 0).sum())
+    n = B * rounds
+    for i, m in enumerate(layers):
+        if m.drop_prob == 0.0:
+            continue
+        keep = 1.0 - m.drop_prob
+        sigma = (keep * (1 - keep) / n) ** 0.5
+        assert abs(kept[i] / n - keep) < 5 * sigma + 1e-9, (i, kept[i] / n, keep)
+    # a stale pooled draw of another batch size is not used
+    net._draw_drop_paths(4, torch.device("cpu"))
+    f = layers[5].sample(7, torch.device("cpu"))
+    assert f.shape == (7,) and layers[5]._pooled is None
+    # a changed rate (drop-path schedule) rebuilds the cached keep table; drop_prob 1.0 gives factor 0, not NaN
+    layers[5].drop_prob = 1.0
+    net._draw_drop_paths(16, torch.device("cpu"))
+    f = layers[5].sample(16, torch.device("cpu"))
+    assert torch.equal(f, torch.zeros(16))
+    # eval: no draws
+    net.eval()
+    net._draw_drop_paths(4, torch.device("cpu"))
+    assert all(m.sample(4, torch.device("cpu")) is None for m in layers)
