@@ -247,6 +247,8 @@ def main():
                     "forward + soft-label fill (ratio 0.36) + expansion-6 student step")
     ap.add_argument("--roofline-family", default="dws_bwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inference", action="store_true", help="skip the 7-fold sliding-window inference leg (BASELINE.json "
+                    "configs[4]) that runs after the timed training region")
     ap.add_argument("--no-rooflines", action="store_true", help="skip the extra untimed steps that time every kernel family")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel family (adds event overhead)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU testing)")
@@ -481,6 +483,28 @@ def main():
             out["family_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in fam_ms.items()}
         elif fam_all:
             out["family_ms_per_step"] = {k: round(v[0] / prof_steps, 3) for k, v in fam_all.items()}
+        if world == 1 and not args.no_inference and default_shape:
+            # BASELINE.json configs[4] (scripts/predict.py:44-50 + src/predictors.py:36-55): after the timed region, the
+            # training model freed; fp32 is the reference's prediction precision (src/argus_models.py:89-99)
+            del model, batch0, last
+            torch.cuda.empty_cache()
+            sys.path.insert(0, str(ROOT / "tools"))
+            from bench_predict import ensemble_bench
+            inf = {"workload": "7-fold ensemble, one 300-frame trial at 64x64, window 16 step 2, 32 windows per forward, all "
+                               "folds in one captured hipGraph per window batch, blend on the device",
+                   "hbm_frac_is": "bytes the eval-mode pass structure executes (tools/bench_predict.py::eval_executed_bytes) "
+                                  "/ time / 8 TB/s"}
+            for dt_ in ("bf16", "fp32"):
+                inf[dt_] = ensemble_bench(dtype=dt_, device=dev)
+            ptraf = ROOT / "profiles" / "r3_predict_pmc.json"
+            if ptraf.exists():
+                try:
+                    pj = json.loads(ptraf.read_text())
+                    if pj.get("lib_sha16") == lib_sha16():
+                        inf["pmc_traffic"] = pj
+                except ValueError:
+                    pass
+            out["inference"] = inf
         if world == 1 and not args.no_cpu_baseline and args.mice == 1 and not args.distill:
             out["cpu_baseline"] = cpu_baseline(args.frames, args.height, args.width, args.expansion)
         print(json.dumps(out), flush=True)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DWN_ABI_VERSION 1
+#define DWN_ABI_VERSION 2
 #define DWN_F32 0
 #define DWN_BF16 1
 #define DWN_NREP 32 /* replicas of every cross-workgroup statistics buffer: double[DWN_NREP][2][C] */
@@ -177,11 +177,14 @@ typedef struct dwn_stem_args {
     dwn_bn bn;
     const float *pe_t, *pe_h, *pe_w;   /* optional: positional encoding of the FIRST block, added to `out`  */
     int T, H, W;                       /* (dwiseneuro.py:184-192); S = T*H*W                                 */
-    void* y0;            /* raw conv output [B*S][C0] (saved) */
+    void* y0;            /* unused since ABI 2 (the raw conv output is never materialised); may be NULL */
     void* out;           /* BN output [B*S][C0] */
     const void* dout;    /* backward: grad wrt out */
-    float* dw;           /* backward: [C0][Cin], zeroed by caller */
+    float* dw;           /* backward: [C0][Cin], written (not accumulated) */
     void* ws; size_t ws_bytes;
+    double* xmom;        /* [8 + 8*8] input moments: sum x_k, sum x_k x_l — written by the training forward, read by the
+                          * backward (y0 = W0 x is linear in the <= 8 input channels: BatchNorm statistics and the weight
+                          * gradient follow from them; saved instead of y0) */
 } dwn_stem_args;
 
 /* one InvertedResidual3d preceded by its PositionalEncoding3d — dwiseneuro.py:136-144, 184-192 */

@@ -91,7 +91,7 @@ class StemArgs(C.Structure):
                 ("eps", c_f), ("momentum", c_f), ("x", c_p), ("w", c_p), ("bn", BN),
                 ("pe_t", c_p), ("pe_h", c_p), ("pe_w", c_p), ("T", c_i), ("H", c_i), ("W", c_i),
                 ("y0", c_p), ("out", c_p),
-                ("dout", c_p), ("dw", c_p), ("ws", c_p), ("ws_bytes", c_sz)]
+                ("dout", c_p), ("dw", c_p), ("ws", c_p), ("ws_bytes", c_sz), ("xmom", c_p)]
 
 
 class BlockArgs(C.Structure):
@@ -232,7 +232,7 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.dwn_abi_version() != 1:
+    if lib.dwn_abi_version() != 2:
         raise ImportError("libdwiseneuro_hip.so ABI version mismatch")
     for cname, struct in _STRUCTS.items():
         n = lib.dwn_sizeof(cname.encode())

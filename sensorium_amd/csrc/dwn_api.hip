@@ -310,35 +310,45 @@ int dwn_pack_weight(const float* src, void* dst, int groups, int R, int C, int t
 
 // ------------------------------------------------------------------------------------------------ stem
 size_t dwn_stem_workspace_bytes(const dwn_stem_args* a) {
-    return (nstat(a->C0) * sizeof(double) + 3 * (size_t)a->C0 * sizeof(float) + 1024);
+    return ((size_t)DWN_NREP * stem_moment_count() * sizeof(double) + 256 +
+            (size_t)DWN_NREP * a->C0 * stem_acc_stride() * sizeof(double) + 1024);
 }
+// Conv3d(Cin -> C0, 1x1x1) + BatchNorm3d (dwiseneuro.py:306-309).  y0 = W0 x is linear in the Cin <= 8 input channels, so the
+// batch statistics come from the input moments (xmom) and y0 is never written: a->y0 is ignored (kept in the struct for
+// layout compatibility), a->xmom receives [8] sums + [8][8] second moments (doubles) that the backward reads.
 int dwn_stem_forward(const dwn_stem_args* a, int device, void* stream) {
     ENTER(device);
     hipStream_t s = (hipStream_t)stream;
     if (a->C0 % 8) return dwn_set_error(-2, "stem: C0 must be a multiple of 8");
+    if (a->pe_t && (i64)a->T * a->H * a->W != a->S) return dwn_set_error(-2, "stem: T*H*W != S");
     Carver c(a->ws, a->ws_bytes);
-    double* st = c.take<double>(nstat(a->C0));
+    double* mom = c.take<double>((size_t)DWN_NREP * stem_moment_count());
     if (!c.ok()) return dwn_set_error(-6, "stem: workspace too small");
     const i64 M = (i64)a->B * a->S;
-    if (a->training) TRY(k_zero(st, nstat(a->C0) * sizeof(double), s));
-    TRY(k_stem_fwd(a->x, a->w, a->y0, a->B, a->Cin, a->S, a->C0, a->training ? st : nullptr, a->dtype, s));
-    TRY(bn_finalize(st, a->C0, (double)M, a->bn, a->C0, a->training, a->momentum, a->eps, s));
-    if (a->pe_t && (i64)a->T * a->H * a->W != a->S) return dwn_set_error(-2, "stem: T*H*W != S");
-    return k_stem_bn_pe(a->y0, a->bn.coef, a->pe_t, a->pe_h, a->pe_w, a->T, a->H, a->W, M, a->C0, a->out, a->dtype, s);
+    if (a->training) {
+        if (!a->xmom) return dwn_set_error(-1, "stem_forward: xmom buffer required in training mode");
+        TRY(k_zero(mom, (size_t)DWN_NREP * stem_moment_count() * sizeof(double), s));
+        TRY(k_stem_xmom(a->x, a->B, a->Cin, a->S, mom, s));
+        TRY(k_stem_bn_finalize(mom, (double)M, a->w, a->bn.gamma, a->bn.beta, a->bn.running_mean, a->bn.running_var,
+                               a->bn.num_batches_tracked, a->momentum, a->eps, a->bn.coef, a->xmom, a->C0, a->Cin, s));
+    } else {
+        TRY(bn_finalize(nullptr, a->C0, (double)M, a->bn, a->C0, 0, a->momentum, a->eps, s));
+    }
+    return k_stem_out(a->x, a->w, a->bn.coef, a->pe_t, a->pe_h, a->pe_w, a->T, a->H, a->W, a->B, a->Cin, a->S, a->C0, a->out,
+                      a->dtype, s);
 }
 int dwn_stem_backward(const dwn_stem_args* a, int device, void* stream) {
     ENTER(device);
     hipStream_t s = (hipStream_t)stream;
+    if (!a->xmom) return dwn_set_error(-1, "stem_backward: xmom (saved by the forward) required");
     Carver c(a->ws, a->ws_bytes);
-    double* st = c.take<double>(nstat(a->C0));
-    float* abc = c.take<float>(3 * (size_t)a->C0);
+    (void)c.take<double>((size_t)DWN_NREP * stem_moment_count());
+    double* acc = c.take<double>((size_t)DWN_NREP * a->C0 * stem_acc_stride());
     if (!c.ok()) return dwn_set_error(-6, "stem: workspace too small");
     const i64 M = (i64)a->B * a->S;
-    TRY(k_zero(st, nstat(a->C0) * sizeof(double), s));
-    TRY(k_bn_bwd_reduce_plain(a->dout, a->y0, a->bn.coef, M, a->C0, st, a->dtype, s));
-    TRY(k_bn_bwd_finalize(st, (double)M, a->bn.coef, a->bn.dgamma, a->bn.dbeta, abc, a->C0, s));
-    LoadDesc dy = ld_affine2(a->dout, a->y0, a->C0, abc, a->C0);
-    return k_stem_bwd(dy, a->x, a->dw, a->B, a->Cin, a->S, a->C0, a->dtype, s);
+    TRY(k_zero(acc, (size_t)DWN_NREP * a->C0 * stem_acc_stride() * sizeof(double), s));
+    TRY(k_stem_bwd_acc(a->dout, a->x, a->xmom, (double)M, a->B, a->Cin, a->S, a->C0, acc, a->dtype, s));
+    return k_stem_bwd_finalize(acc, a->xmom, a->w, a->bn.coef, (double)M, a->bn.dgamma, a->bn.dbeta, a->dw, a->C0, a->Cin, s);
 }
 
 // ------------------------------------------------------------------------------------------------ block

@@ -30,6 +30,17 @@ __device__ __forceinline__ void wf_unpack(const uint2& r, wf_f2_t& lo, wf_f2_t& 
 }
 __device__ __forceinline__ uint2 wf_ld8(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
 
+// workgroup barrier for LDS hand-offs only (__syncthreads() also drains vmcnt: the write acknowledgements of every y2 store)
+__device__ __forceinline__ void wf_lds_barrier() {
+#ifdef WK_FULL_BARRIER
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#endif
+}
+
 // LPW = output pixel pairs per plane row (Wout == 2*LPW in {32, 16, 8}); NG = 16/LPW planes side by side in one tile.
 // The staged tile has NPC = ST*LPW + 1 pair columns k = (wi = 2k-1, wi = 2k) and rows hi_first .. hi_first + rows_in - 1.
 template <int ST, int LPW>
@@ -542,7 +553,7 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(cons
                     }
                 }
             }
-            __syncthreads();
+            wf_lds_barrier();
             // ---------------- walk down this chunk's output rows of the thread's output pair column (outputs 2jj, 2jj+1)
             const int o_lo = ST == 1 ? (s > 0 ? s - 1 : 0) : s;
             const int o_hi = ST == 1 ? (s + RB - 1 < Hout ? s + RB - 1 : Hout) : (s + RB < Hout ? s + RB : Hout);      // exclusive
@@ -631,7 +642,7 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(cons
                     }
                 }
             }
-            __syncthreads();
+            wf_lds_barrier();
             slot_s += NR; slot_s = slot_s >= RQ ? slot_s - RQ : slot_s;
         }
     }

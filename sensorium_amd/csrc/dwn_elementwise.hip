@@ -278,176 +278,347 @@ int k_colstats(const LoadDesc& d, int kind, i64 rows, int C, double* stats, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// stem: Conv3d(C_in -> C0, 1x1x1, no bias) on the NCDHW fp32 input (dwiseneuro.py:306), raw output + Σ/Σ²
+// stem, round 3: BatchNorm through the input moments.  y0 = W0 x is LINEAR in the 5 input channels, so the batch statistics
+// of every output channel follow from Σx (Cin values) and Σ x x^T (Cin x Cin) — a pass over the 47 MB input instead of a
+// write + read of the 300 MB y0 — and the backward needs only Σ dout (x - x̄)^T (C0 x Cin) and Σ dout:
+//   mean_c = w_c . x̄,  var_c = w_c^T Cov w_c;   dW_c = A1 Σ dout_c (x - x̄) + A2 n Cov w_c   (Σ dy0 = 0 kills the A3 term)
+// y0 is never materialised: forward = moments pass + one pass x -> out, backward = one pass over (dout, x).
+// xmom (saved): [Cin] Σx, [Cin][Cin] Σ x x^T as doubles.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const float* w, T* y, int B, int Cin, i64 S,
-                                                       int C0, double* stats) {
-    SLICE_SETUP(C0)
-    constexpr int MAXCIN = 8;
-    __shared__ float lstat[2 * NCV * KC];
-    if (tid < 2 * NCV * KC) lstat[tid] = 0.f;
+constexpr int STEM_MAXCIN = 8;
+constexpr int STEM_NM = STEM_MAXCIN + STEM_MAXCIN * STEM_MAXCIN;          // moments per replica (padded to the maximum Cin)
+
+__global__ __launch_bounds__(256) void stem_xmom_kernel(const float* x, int B, int Cin, i64 S, double* mom) {
+    __shared__ double lsum[STEM_NM];
+    const int tid = threadIdx.x;
+    if (tid < STEM_NM) lsum[tid] = 0.0;
     __syncthreads();
-    float s0[KC], s1[KC], wr[MAXCIN][KC];
+    float sx[STEM_MAXCIN], xx[STEM_MAXCIN][STEM_MAXCIN];
 #pragma unroll
-    for (int i = 0; i < KC; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+    for (int a_ = 0; a_ < STEM_MAXCIN; ++a_) {
+        sx[a_] = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXCIN; ++c)
-#pragma unroll
-        for (int i = 0; i < KC; ++i) wr[c][i] = (chan_ok && c < Cin) ? w[(chan + i) * Cin + c] : 0.f;
+        for (int b_ = 0; b_ < STEM_MAXCIN; ++b_) xx[a_][b_] = 0.f;
+    }
     const i64 rows = (i64)B * S;
-    if (chan_ok)
-        for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
-            i64 b = row / S, sp = row - b * S;
-            float xv[MAXCIN];
+    for (i64 row = (i64)blockIdx.x * 256 + tid; row < rows; row += (i64)gridDim.x * 256) {
+        const i64 b = row / S, sp = row - b * S;
+        float xv[STEM_MAXCIN];
 #pragma unroll
-            for (int c = 0; c < MAXCIN; ++c) xv[c] = c < Cin ? x[(b * Cin + c) * S + sp] : 0.f;
-            float acc[KC];
+        for (int c = 0; c < STEM_MAXCIN; ++c) xv[c] = c < Cin ? x[(b * Cin + c) * S + sp] : 0.f;
 #pragma unroll
-            for (int i = 0; i < KC; ++i) acc[i] = 0.f;
+        for (int a_ = 0; a_ < STEM_MAXCIN; ++a_) {
+            sx[a_] += xv[a_];
 #pragma unroll
-            for (int c = 0; c < MAXCIN; ++c)
-#pragma unroll
-                for (int i = 0; i < KC; ++i) acc[i] = fmaf(wr[c][i], xv[c], acc[i]);
-            st_vec<T>(y + row * C0 + chan, acc);
-#pragma unroll
-            for (int i = 0; i < KC; ++i) {
-                float r = round_t<T>(acc[i]);
-                s0[i] += r;
-                s1[i] += r * r;
-            }
+            for (int b_ = a_; b_ < STEM_MAXCIN; ++b_) xx[a_][b_] = fmaf(xv[a_], xv[b_], xx[a_][b_]);
         }
-    if (stats) slice_stats_flush<KC>(lstat, s0, s1, cv, c0, C0, stats, blockIdx.x % DWN_NREP);
+    }
+    // wave reduction in double, then one LDS add per wave and value
+#pragma unroll
+    for (int a_ = 0; a_ < STEM_MAXCIN; ++a_) {
+        if (a_ >= Cin) break;
+        double v = (double)sx[a_];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((tid & 63) == 0) atomicAdd(&lsum[a_], v);
+#pragma unroll
+        for (int b_ = a_; b_ < STEM_MAXCIN; ++b_) {
+            if (b_ >= Cin) break;
+            double q = (double)xx[a_][b_];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            if ((tid & 63) == 0) atomicAdd(&lsum[STEM_MAXCIN + a_ * STEM_MAXCIN + b_], q);
+        }
+    }
+    __syncthreads();
+    if (tid < STEM_NM) {
+        const double v = lsum[tid];
+        if (v != 0.0) atomicAdd(mom + (i64)(blockIdx.x % DWN_NREP) * STEM_NM + tid, v);
+    }
 }
 
-// stem backward: dW[o][c] = sum_rows dy0[row][o] * x[b][c][sp], dy0 through LD_AFFINE2(dx0, y0)
-template <typename T>
-__global__ __launch_bounds__(256) void stem_bwd_kernel(LoadDesc dy, const float* x, float* dw, int B, int Cin, i64 S,
-                                                       int C0) {
-    SLICE_SETUP(C0)
-    constexpr int MAXCIN = 8;
-    __shared__ float lacc[MAXCIN * NCV * KC];
-    for (int i = tid; i < MAXCIN * NCV * KC; i += 256) lacc[i] = 0.f;
+// one workgroup: replica reduce of the moments -> xmom, then per output channel the BatchNorm coefficients + running stats
+__global__ __launch_bounds__(256) void stem_bn_finalize_kernel(const double* mom, double count, const float* w, const float* gamma,
+                                                               const float* beta, float* running_mean, float* running_var,
+                                                               long long* nbt, float momentum, float eps, float* coef,
+                                                               double* xmom, int C0, int Cin) {
+    __shared__ double lm[STEM_NM];
+    const int tid = threadIdx.x;
+    if (tid < STEM_NM) {
+        double v = 0.0;
+        for (int r = 0; r < DWN_NREP; ++r) v += mom[(i64)r * STEM_NM + tid];
+        lm[tid] = v;
+    }
     __syncthreads();
-    float acc[MAXCIN][KC];
+    if (tid < STEM_NM) {                    // upper triangle was accumulated: mirror it, save Σx and Σxx^T for the backward
+        const int a_ = tid < STEM_MAXCIN ? 0 : (tid - STEM_MAXCIN) / STEM_MAXCIN, b_ = tid < STEM_MAXCIN ? 0 : (tid - STEM_MAXCIN) % STEM_MAXCIN;
+        double v = lm[tid];
+        if (tid >= STEM_MAXCIN && b_ < a_) v = lm[STEM_MAXCIN + b_ * STEM_MAXCIN + a_];
+        xmom[tid] = v;
+    }
+    if (tid == 0 && nbt) *nbt += 1;
+    for (int c = tid; c < C0; c += blockDim.x) {
+        double mean = 0.0, var = 0.0;
+        for (int a_ = 0; a_ < Cin; ++a_) mean += (double)w[c * Cin + a_] * (lm[a_] / count);
+        for (int a_ = 0; a_ < Cin; ++a_)
+            for (int b_ = 0; b_ < Cin; ++b_) {
+                const double sxx = a_ <= b_ ? lm[STEM_MAXCIN + a_ * STEM_MAXCIN + b_] : lm[STEM_MAXCIN + b_ * STEM_MAXCIN + a_];
+                const double cov = sxx / count - (lm[a_] / count) * (lm[b_] / count);
+                var += (double)w[c * Cin + a_] * (double)w[c * Cin + b_] * cov;
+            }
+        if (var < 0) var = 0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float scale = gamma[c] * invstd;
+        coef[c] = scale;
+        coef[C0 + c] = beta[c] - (float)mean * scale;
+        coef[2 * C0 + c] = (float)mean;
+        coef[3 * C0 + c] = invstd;
+        if (running_mean) {
+            const double unbiased = count > 1 ? var * count / (count - 1) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+// out[row][c] = BN(W0 x) (+ positional encoding of the first block), straight from the NCDHW input
+// CINT: compile-time bound of the input-channel loops (5 = the reference's inputs, 8 = generic): with the generic bound the
+// weight / accumulator arrays cost 60 more VGPRs and a wave per SIMD
+template <typename T, int CINT>
+__global__ __launch_bounds__(256) void stem_out_kernel(const float* x, const float* w, const float* coef, const float* pe_t,
+                                                       const float* pe_h, const float* pe_w, int Tn, int H, int W, int B,
+                                                       int Cin, i64 S, int C0, T* out) {
+    SLICE_SETUP(C0)
+    constexpr int STEM_MAXCIN = CINT;
+    const int chs_ = chan_ok ? chan : 0;                   // channel-tail lanes keep running: they fetch x for their row group
+    float wr[STEM_MAXCIN][KC], sc[KC], sh[KC];
 #pragma unroll
-    for (int c = 0; c < MAXCIN; ++c)
+    for (int c = 0; c < STEM_MAXCIN; ++c)
 #pragma unroll
-        for (int i = 0; i < KC; ++i) acc[c][i] = 0.f;
-    const unsigned rows = (unsigned)((i64)B * S);          // < 2^31 (checked by the launcher)
+        for (int i = 0; i < KC; ++i) wr[c][i] = (c < Cin && chan_ok) ? w[(chan + i) * Cin + c] : 0.f;
+    ld_coef<KC>(coef + chs_, sc);
+    ld_coef<KC>(coef + C0 + chs_, sh);
+    const RasterIdx ro(H, W);
+    const UDiv32 dT((unsigned)Tn), dS((unsigned)S);
+    constexpr int RU = 2;
+    const unsigned nrows = (unsigned)((i64)B * S), stride = gridDim.x * 32u;
+    for (unsigned row0 = blockIdx.x * 32u + pl; row0 < nrows; row0 += RU * stride) {
+        // the 8 lanes of a row share its Cin input values: lane cv fetches channel cv (one load per lane and row instead of
+        // Cin eight-fold redundant ones), the group then broadcasts them with lane shuffles
+        float xm[RU], xv[RU][STEM_MAXCIN];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const unsigned row = row0 + u * stride < nrows ? row0 + u * stride : row0;
+            const unsigned b = dS.div(row), sp = row - b * (unsigned)S;
+            xm[u] = cv < Cin ? x[((i64)b * Cin + cv) * S + sp] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+#pragma unroll
+            for (int c = 0; c < STEM_MAXCIN; ++c) xv[u][c] = __shfl(xm[u], (tid & 56) | c);
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const unsigned row = row0 + u * stride;
+            if (row >= nrows || !chan_ok) break;
+            float v[KC];
+#pragma unroll
+            for (int i = 0; i < KC; ++i) v[i] = 0.f;
+#pragma unroll
+            for (int c = 0; c < STEM_MAXCIN; ++c)
+#pragma unroll
+                for (int i = 0; i < KC; ++i) v[i] = fmaf(wr[c][i], xv[u][c], v[i]);
+#pragma unroll
+            for (int i = 0; i < KC; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
+            if (pe_t) {
+                unsigned f; int h, wq;
+                ro.decode(row, f, h, wq);
+                const unsigned t = f - dT.div(f) * (unsigned)Tn;
+                float pa[KC], pb[KC], pc[KC];
+                ld_coef<KC>(pe_t + (i64)t * C0 + chan, pa);
+                ld_coef<KC>(pe_h + (i64)h * C0 + chan, pb);
+                ld_coef<KC>(pe_w + (i64)wq * C0 + chan, pc);
+#pragma unroll
+                for (int i = 0; i < KC; ++i) v[i] = round_t<T>(v[i]) + ((pa[i] + pb[i]) + pc[i]);
+            }
+            st_vec<T>(out + (i64)row * C0 + chan, v);
+        }
+    }
+}
+
+// backward accumulation: acc[rep][c][0..Cin-1] = Σ dout_c (x_k - x̄_k),  acc[rep][c][STEM_MAXCIN] = Σ dout_c
+template <typename T, int CINT>
+__global__ __launch_bounds__(256) void stem_bwd_acc_kernel(const T* dout, const float* x, const double* xmom, double count,
+                                                           int B, int Cin, i64 S, int C0, double* acc) {
+    SLICE_SETUP(C0)
+    constexpr int NVG = ::STEM_MAXCIN + 1;                  // row stride of acc (fixed layout)
+    constexpr int STEM_MAXCIN = CINT;
+    constexpr int NV = STEM_MAXCIN + 1;
+    __shared__ float lacc[NV * NCV * KC];
+    for (int i = tid; i < NV * NCV * KC; i += 256) lacc[i] = 0.f;
+    __syncthreads();
+    float a_[NV][KC];
+#pragma unroll
+    for (int c = 0; c < NV; ++c)
+#pragma unroll
+        for (int i = 0; i < KC; ++i) a_[c][i] = 0.f;
+    const float xbar_mine = cv < Cin ? (float)(xmom[cv] / count) : 0.f;
+    const unsigned rows = (unsigned)((i64)B * S);
     const UDiv32 dS((unsigned)S);
-    if (chan_ok) {
-        constexpr int RU = 4;                              // rows in flight per thread (2: 256 us at the metric shape, latency-bound)
+    const int chs_ = chan_ok ? chan : 0;                   // channel-tail lanes keep running: they fetch x for their row group
+    {
+        constexpr int RU = 4;
         const unsigned stride = gridDim.x * 32u;
         for (unsigned row0 = blockIdx.x * 32u + pl; row0 < rows; row0 += RU * stride) {
-            float g[RU][KC], xv[RU][MAXCIN];
+            float g[RU][KC], xm[RU], xv[RU][STEM_MAXCIN];
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
                 const unsigned row = row0 + u * stride < rows ? row0 + u * stride : row0;
                 const unsigned b = dS.div(row), sp = row - b * (unsigned)S;
-                load_op<LD_AFFINE2, T>(dy, (i64)row, chan, g[u]);
-#pragma unroll
-                for (int c = 0; c < MAXCIN; ++c) xv[u][c] = c < Cin ? x[((i64)b * Cin + c) * S + sp] : 0.f;
+                ld_vec<T>(dout + (i64)row * C0 + chs_, g[u]);
+                xm[u] = cv < Cin ? x[((i64)b * Cin + cv) * S + sp] - xbar_mine : 0.f;      // lane cv: channel cv of its row
             }
+#pragma unroll
+            for (int u = 0; u < RU; ++u)
+#pragma unroll
+                for (int c = 0; c < STEM_MAXCIN; ++c) xv[u][c] = __shfl(xm[u], (tid & 56) | c);
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
-                if (row0 + u * stride >= rows) break;
+                if (row0 + u * stride >= rows || !chan_ok) break;
 #pragma unroll
-                for (int c = 0; c < MAXCIN; ++c)
+                for (int c = 0; c < STEM_MAXCIN; ++c)
 #pragma unroll
-                    for (int i = 0; i < KC; ++i) acc[c][i] = fmaf(g[u][i], xv[u][c], acc[c][i]);
+                    for (int i = 0; i < KC; ++i) a_[c][i] = fmaf(g[u][i], xv[u][c], a_[c][i]);
+#pragma unroll
+                for (int i = 0; i < KC; ++i) a_[STEM_MAXCIN][i] += g[u][i];
             }
         }
     }
+    // lanes l, l+8, ... of a wave share the channel vector: xor-shuffle them together, one LDS add per wave and value
 #pragma unroll
-    for (int c = 0; c < MAXCIN; ++c)
+    for (int c = 0; c < NV; ++c) {
+        if (c < STEM_MAXCIN && c >= Cin) continue;
 #pragma unroll
-        for (int i = 0; i < KC; ++i) atomicAdd(&lacc[c * NCV * KC + cv * KC + i], acc[c][i]);
+        for (int i = 0; i < KC; ++i) {
+            float v = a_[c][i];
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) v += __shfl_xor(v, o);
+            if ((tid & 63) < NCV) atomicAdd(&lacc[c * NCV * KC + cv * KC + i], v);
+        }
+    }
     __syncthreads();
-    for (int i = tid; i < MAXCIN * NCV * KC; i += 256) {
-        int c = i / (NCV * KC), o = c0 + i % (NCV * KC);
-        if (c < Cin && o < C0) atomicAdd(dw + (i64)o * Cin + c, lacc[i]);
+    for (int i = tid; i < NV * NCV * KC; i += 256) {
+        const int c = i / (NCV * KC), o = c0 + i % (NCV * KC);
+        if ((c == STEM_MAXCIN || c < Cin) && o < C0)
+            atomicAdd(acc + ((i64)(blockIdx.x % DWN_NREP) * C0 + o) * NVG + (c == STEM_MAXCIN ? ::STEM_MAXCIN : c), (double)lacc[i]);
     }
 }
 
-// out[row][c] = scale*y0 + shift (+ positional encoding of the first block)
-template <typename T>
-__global__ __launch_bounds__(256) void stem_bn_pe_kernel(const T* y0, const float* coef, const float* pe_t,
-                                                         const float* pe_h, const float* pe_w, int Tn, int H, int W,
-                                                         i64 rows, int C, T* out) {
-    SLICE_SETUP(C)
-    if (!chan_ok) return;
-    float sc[KC], sh[KC];
-    ld_coef<KC>(coef + chan, sc);
-    ld_coef<KC>(coef + C + chan, sh);
-    const RasterIdx ro(H, W);
-    const UDiv32 dT((unsigned)Tn);
-    constexpr int RU = 2;                                    // rows in flight per thread
-    const unsigned nrows = (unsigned)rows, stride = gridDim.x * 32u;
-    for (unsigned row0 = blockIdx.x * 32u + pl; row0 < nrows; row0 += RU * stride) {
-        uint4 raw[RU];
-#pragma unroll
-        for (int u = 0; u < RU; ++u) {
-            const unsigned row = row0 + u * stride < nrows ? row0 + u * stride : row0;
-            raw[u] = *reinterpret_cast<const uint4*>(y0 + (i64)row * C + chan);
+// one workgroup: dgamma, dbeta, dW from the accumulated sums (see the header of this section)
+__global__ __launch_bounds__(256) void stem_bwd_finalize_kernel(const double* acc, const double* xmom, const float* w,
+                                                                const float* coef, double count, float* dgamma, float* dbeta,
+                                                                float* dw, int C0, int Cin) {
+    constexpr int NV = STEM_MAXCIN + 1;
+    // four lanes per channel, eight replicas each (a single-thread loop over 32 replicas is a chain of dependent loads)
+    const int part = threadIdx.x & 3;
+    for (int cb = 0; cb < C0; cb += blockDim.x / 4) {
+        const int c = cb + (threadIdx.x >> 2);
+        const bool ok = c < C0;
+        double dx[STEM_MAXCIN], s1 = 0.0;
+        for (int k = 0; k < STEM_MAXCIN; ++k) dx[k] = 0.0;
+        for (int r = part * (DWN_NREP / 4); r < (part + 1) * (DWN_NREP / 4); ++r) {
+            const double* p = acc + ((i64)r * C0 + (ok ? c : 0)) * NV;
+            for (int k = 0; k < Cin; ++k) dx[k] += p[k];
+            s1 += p[STEM_MAXCIN];
         }
-#pragma unroll
-        for (int u = 0; u < RU; ++u) {
-            const unsigned row = row0 + u * stride;
-            if (row >= nrows) break;
-            float v[KC];
-            unpack16<T>(raw[u], v);
-#pragma unroll
-            for (int i = 0; i < KC; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
-            if (pe_t) {
-                unsigned f; int h, w;
-                ro.decode(row, f, h, w);
-                const unsigned t = f - dT.div(f) * (unsigned)Tn;
-                float pa[KC], pb[KC], pc[KC];
-                ld_coef<KC>(pe_t + (i64)t * C + chan, pa);
-                ld_coef<KC>(pe_h + (i64)h * C + chan, pb);
-                ld_coef<KC>(pe_w + (i64)w * C + chan, pc);
-#pragma unroll
-                for (int i = 0; i < KC; ++i) v[i] = round_t<T>(v[i]) + ((pa[i] + pb[i]) + pc[i]);
-            }
-            st_vec<T>(out + (i64)row * C + chan, v);
+        for (int o = 1; o < 4; o <<= 1) {
+            for (int k = 0; k < STEM_MAXCIN; ++k) dx[k] += __shfl_xor(dx[k], o);
+            s1 += __shfl_xor(s1, o);
+        }
+        if (!ok || part != 0) continue;
+        const double scale = coef[c], invstd = coef[3 * C0 + c];
+        double dyc = 0.0;                                   // Σ dout (y0 - mean)
+        for (int k = 0; k < Cin; ++k) dyc += (double)w[c * Cin + k] * dx[k];
+        const double s2 = invstd * dyc;                     // Σ dout ŷ
+        if (dgamma) dgamma[c] = (float)s2;
+        if (dbeta) dbeta[c] = (float)s1;
+        const double a2 = -scale * invstd * (s2 / count);
+        for (int k = 0; k < Cin; ++k) {
+            double cw = 0.0;                                // n (Cov w)_k = Σ_l w_l (Σ x_l x_k - n x̄_l x̄_k)
+            for (int l = 0; l < Cin; ++l)
+                cw += (double)w[c * Cin + l] * (xmom[STEM_MAXCIN + l * STEM_MAXCIN + k] - xmom[l] * xmom[k] / count);
+            dw[c * Cin + k] = (float)(scale * dx[k] + a2 * cw);
         }
     }
-}
-int k_stem_bn_pe(const void* y0, const float* coef, const float* pe_t, const float* pe_h, const float* pe_w, int Tn,
-                 int H, int W, i64 rows, int C, void* out, int dtype, hipStream_t s) {
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL((stem_bn_pe_kernel<bf16_t>), slice_grid(rows, C, 8), dim3(256), 0, s, (const bf16_t*)y0, coef, pe_t, pe_h, pe_w, Tn, H, W, rows, C, (bf16_t*)out),
-        hipLaunchKernelGGL((stem_bn_pe_kernel<float>), slice_grid(rows, C, 4), dim3(256), 0, s, (const float*)y0, coef, pe_t, pe_h, pe_w, Tn, H, W, rows, C, (float*)out));
-    DWN_CHECK_LAUNCH();
-    return 0;
 }
 
-int k_stem_fwd(const float* x, const float* w, void* y, int B, int Cin, i64 S, int C0, double* stats, int dtype,
-               hipStream_t s) {
-    if (Cin > 8) return dwn_set_error(-4, "stem: in_channels > 8 not built");
-    if (dtype == DWN_BF16) {
-        dim3 grid = slice_grid((i64)B * S, C0, 8);
-        hipLaunchKernelGGL((stem_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, x, w, (bf16_t*)y, B, Cin, S, C0, stats);
+int k_stem_xmom(const float* x, int B, int Cin, i64 S, double* mom, hipStream_t s) {
+    if (Cin > STEM_MAXCIN) return dwn_set_error(-4, "stem: in_channels > 8 not built");
+    i64 bx = ((i64)B * S + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(stem_xmom_kernel, dim3((unsigned)bx), dim3(256), 0, s, x, B, Cin, S, mom);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int k_stem_bn_finalize(const double* mom, double count, const float* w, const float* gamma, const float* beta, float* rm,
+                       float* rv, long long* nbt, float momentum, float eps, float* coef, double* xmom, int C0, int Cin,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(stem_bn_finalize_kernel, dim3(1), dim3(256), 0, s, mom, count, w, gamma, beta, rm, rv, nbt, momentum, eps,
+                       coef, xmom, C0, Cin);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+template <typename T, int CINT>
+static void stem_out_launch(const float* x, const float* w, const float* coef, const float* pe_t, const float* pe_h, const float* pe_w,
+                            int Tn, int H, int W, int B, int Cin, i64 S, int C0, void* out, hipStream_t s) {
+    auto kern = stem_out_kernel<T, CINT>;
+    hipLaunchKernelGGL(kern, resident_slice_grid(kern, (i64)B * S, C0, TT<T>::KC), dim3(256), 0, s, x, w, coef, pe_t, pe_h, pe_w, Tn, H, W,
+                       B, Cin, S, C0, (T*)out);
+}
+int k_stem_out(const float* x, const float* w, const float* coef, const float* pe_t, const float* pe_h, const float* pe_w,
+               int Tn, int H, int W, int B, int Cin, i64 S, int C0, void* out, int dtype, hipStream_t s) {
+    if (Cin > STEM_MAXCIN) return dwn_set_error(-4, "stem: in_channels > 8 not built");
+    if ((i64)B * S >= (1ll << 31)) return dwn_set_error(-4, "stem: more than 2^31 rows");
+    if (Cin <= 5) {
+        DISPATCH_T(dtype, (stem_out_launch<bf16_t, 5>(x, w, coef, pe_t, pe_h, pe_w, Tn, H, W, B, Cin, S, C0, out, s)),
+                   (stem_out_launch<float, 5>(x, w, coef, pe_t, pe_h, pe_w, Tn, H, W, B, Cin, S, C0, out, s)));
     } else {
-        dim3 grid = slice_grid((i64)B * S, C0, 4);
-        hipLaunchKernelGGL((stem_fwd_kernel<float>), grid, dim3(256), 0, s, x, w, (float*)y, B, Cin, S, C0, stats);
+        DISPATCH_T(dtype, (stem_out_launch<bf16_t, 8>(x, w, coef, pe_t, pe_h, pe_w, Tn, H, W, B, Cin, S, C0, out, s)),
+                   (stem_out_launch<float, 8>(x, w, coef, pe_t, pe_h, pe_w, Tn, H, W, B, Cin, S, C0, out, s)));
     }
     DWN_CHECK_LAUNCH();
     return 0;
 }
-int k_stem_bwd(const LoadDesc& dy, const float* x, float* dw, int B, int Cin, i64 S, int C0, int dtype, hipStream_t s) {
-    if (Cin > 8) return dwn_set_error(-4, "stem: in_channels > 8 not built");
-    if (dtype == DWN_BF16) {
-        dim3 grid = slice_grid((i64)B * S, C0, 8, 1024);
-        hipLaunchKernelGGL((stem_bwd_kernel<bf16_t>), grid, dim3(256), 0, s, dy, x, dw, B, Cin, S, C0);
+template <typename T, int CINT>
+static void stem_bwd_acc_launch(const void* dout, const float* x, const double* xmom, double count, int B, int Cin, i64 S, int C0,
+                                double* acc, hipStream_t s) {
+    auto kern = stem_bwd_acc_kernel<T, CINT>;
+    // exactly one resident round of workgroups (accumulators are flushed once per workgroup; no ragged second round)
+    hipLaunchKernelGGL(kern, resident_slice_grid(kern, (i64)B * S, C0, TT<T>::KC), dim3(256), 0, s, (const T*)dout, x, xmom, count, B, Cin,
+                       S, C0, acc);
+}
+int k_stem_bwd_acc(const void* dout, const float* x, const double* xmom, double count, int B, int Cin, i64 S, int C0,
+                   double* acc, int dtype, hipStream_t s) {
+    if (Cin > STEM_MAXCIN) return dwn_set_error(-4, "stem: in_channels > 8 not built");
+    if ((i64)B * S >= (1ll << 31)) return dwn_set_error(-4, "stem: more than 2^31 rows");
+    if (Cin <= 5) {
+        DISPATCH_T(dtype, (stem_bwd_acc_launch<bf16_t, 5>(dout, x, xmom, count, B, Cin, S, C0, acc, s)),
+                   (stem_bwd_acc_launch<float, 5>(dout, x, xmom, count, B, Cin, S, C0, acc, s)));
     } else {
-        dim3 grid = slice_grid((i64)B * S, C0, 4, 1024);
-        hipLaunchKernelGGL((stem_bwd_kernel<float>), grid, dim3(256), 0, s, dy, x, dw, B, Cin, S, C0);
+        DISPATCH_T(dtype, (stem_bwd_acc_launch<bf16_t, 8>(dout, x, xmom, count, B, Cin, S, C0, acc, s)),
+                   (stem_bwd_acc_launch<float, 8>(dout, x, xmom, count, B, Cin, S, C0, acc, s)));
     }
     DWN_CHECK_LAUNCH();
     return 0;
 }
+int k_stem_bwd_finalize(const double* acc, const double* xmom, const float* w, const float* coef, double count, float* dgamma,
+                        float* dbeta, float* dw, int C0, int Cin, hipStream_t s) {
+    hipLaunchKernelGGL(stem_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, acc, xmom, w, coef, count, dgamma, dbeta, dw, C0, Cin);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+int stem_moment_count() { return STEM_NM; }
+int stem_acc_stride() { return STEM_MAXCIN + 1; }
+
 
 // ------------------------------------------------------------------------------------------------
 // shortcut (interpolate_shortcut, dwiseneuro.py:125-134) + residual (:143)
@@ -1751,39 +1922,6 @@ int k_prep(const PrepArgs& pa, int dtype, hipStream_t s) {
     return 0;
 }
 
-// Σg, Σg·ŷ for a linear (no activation) BatchNorm: g, y plain tensors [rows][C]
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_plain_kernel(const T* g, const T* y, const float* coef, i64 rows,
-                                                                  int C, double* stats) {
-    SLICE_SETUP(C)
-    __shared__ float lstat[2 * NCV * KC];
-    if (tid < 2 * NCV * KC) lstat[tid] = 0.f;
-    __syncthreads();
-    float s0[KC], s1[KC];
-#pragma unroll
-    for (int i = 0; i < KC; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
-    if (chan_ok) {
-        float mu[KC], is[KC];
-        ld_coef<KC>(coef + 2 * C + chan, mu);
-        ld_coef<KC>(coef + 3 * C + chan, is);
-        for (i64 row = (i64)blockIdx.x * 32 + pl; row < rows; row += (i64)gridDim.x * 32) {
-            float gv[KC], yv[KC];
-            ld_vec<T>(g + row * C + chan, gv);
-            ld_vec<T>(y + row * C + chan, yv);
-#pragma unroll
-            for (int i = 0; i < KC; ++i) { s0[i] += gv[i]; s1[i] += gv[i] * (yv[i] - mu[i]) * is[i]; }
-        }
-    }
-    slice_stats_flush<KC>(lstat, s0, s1, cv, c0, C, stats, blockIdx.x % DWN_NREP);
-}
-int k_bn_bwd_reduce_plain(const void* g, const void* y, const float* coef, i64 rows, int C, double* stats, int dtype,
-                          hipStream_t s) {
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL((bn_bwd_reduce_plain_kernel<bf16_t>), resident_slice_grid(bn_bwd_reduce_plain_kernel<bf16_t>, rows, C, 8), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, coef, rows, C, stats),
-        hipLaunchKernelGGL((bn_bwd_reduce_plain_kernel<float>), resident_slice_grid(bn_bwd_reduce_plain_kernel<float>, rows, C, 4), dim3(256), 0, s, (const float*)g, (const float*)y, coef, rows, C, stats));
-    DWN_CHECK_LAUNCH();
-    return 0;
-}
 
 
 // ------------------------------------------------------------------------------------------------

@@ -26,15 +26,23 @@ int k_bn_bwd_finalize(const double* stats, double count, const float* coef, floa
                       int C, hipStream_t s);
 int k_ew_apply(const LoadDesc& d, int kind, void* out, i64 ldo, i64 rows, int C, int dtype, hipStream_t s);
 int k_colstats(const LoadDesc& d, int kind, i64 rows, int C, double* stats, int dtype, hipStream_t s);
-int k_stem_fwd(const float* x, const float* w, void* y, int B, int Cin, i64 S, int C0, double* stats, int dtype,
-               hipStream_t s);
-int k_stem_bwd(const LoadDesc& dy, const float* x, float* dw, int B, int Cin, i64 S, int C0, int dtype, hipStream_t s);
+// stem through the input moments (no y0 round trip; dwn_elementwise.hip)
+int k_stem_xmom(const float* x, int B, int Cin, i64 S, double* mom, hipStream_t s);
+int k_stem_bn_finalize(const double* mom, double count, const float* w, const float* gamma, const float* beta, float* rm,
+                       float* rv, long long* nbt, float momentum, float eps, float* coef, double* xmom, int C0, int Cin,
+                       hipStream_t s);
+int k_stem_out(const float* x, const float* w, const float* coef, const float* pe_t, const float* pe_h, const float* pe_w,
+               int Tn, int H, int W, int B, int Cin, i64 S, int C0, void* out, int dtype, hipStream_t s);
+int k_stem_bwd_acc(const void* dout, const float* x, const double* xmom, double count, int B, int Cin, i64 S, int C0,
+                   double* acc, int dtype, hipStream_t s);
+int k_stem_bwd_finalize(const double* acc, const double* xmom, const float* w, const float* coef, double count, float* dgamma,
+                        float* dbeta, float* dw, int C0, int Cin, hipStream_t s);
+int stem_moment_count();
+int stem_acc_stride();
 int k_shortcut_stats(const LoadDesc& xin, const ResGeom& gm, double* stats, int dtype, hipStream_t s);
 int k_residual_fwd(const LoadDesc& xin, const void* y4, const float* coef4, const float* coefsc, const float* dscale,
                    const ResGeom& gm, const float* ope_t, const float* ope_h, const float* ope_w, void* out, int dtype,
                    hipStream_t s);
-int k_stem_bn_pe(const void* y0, const float* coef, const float* pe_t, const float* pe_h, const float* pe_w, int Tn,
-                 int H, int W, i64 rows, int C, void* out, int dtype, hipStream_t s);
 int k_residual_bwd_reduce(const LoadDesc& xin, const void* y4, const void* dout, const float* coef4,
                           const float* coefsc, const float* dscale, const ResGeom& gm, double* stats4,
                           double* statssc, int dtype, hipStream_t s);
@@ -83,8 +91,6 @@ int k_assemble_inputs(const dwn_clip_desc* descs, int B, int T, int H0, int W0, 
                       hipStream_t s);
 int k_assemble_targets(const dwn_clip_desc* descs, int B, int T, float* const* targets, const int* n_neurons,
                        int n_mice, int max_neurons, float* mice_weights, hipStream_t s);
-int k_bn_bwd_reduce_plain(const void* g, const void* y, const float* coef, i64 rows, int C, double* stats, int dtype,
-                          hipStream_t s);
 int k_zero(void* p, size_t nbytes, hipStream_t s);
 int k_pw_bwd_prep(const float* w1, const float* abc, int E, int C, void* bp, float* gacc, float* r3, int dtype,
                   hipStream_t s);

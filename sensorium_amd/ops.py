@@ -126,14 +126,15 @@ class StemFn(torch.autograd.Function):
         B, Cin, T, H, W = x.shape
         C0 = weight.shape[0]
         dev = x.device
-        y0 = torch.empty(B, T, H, W, C0, dtype=dtype, device=dev)
-        out = torch.empty_like(y0)
+        out = torch.empty(B, T, H, W, C0, dtype=dtype, device=dev)
         coef = torch.empty(4 * C0, dtype=torch.float32, device=dev)
+        # the input moments (sum x, sum x x^T): what the backward needs instead of the raw conv output (never materialised)
+        xmom = torch.empty(72, dtype=torch.float64, device=dev)
         a = L.StemArgs()
         a.dtype = _DT[dtype]; a.training = int(bn.training); a.B = B; a.Cin = Cin; a.C0 = C0; a.S = T * H * W
         a.eps = bn.eps; a.momentum = bn.momentum
         a.x = x.data_ptr(); a.w = weight.data_ptr(); a.bn = _bn_struct(bn, coef)
-        a.y0 = y0.data_ptr(); a.out = out.data_ptr()
+        a.out = out.data_ptr(); a.xmom = xmom.data_ptr()
         if pe is not None:       # positional encoding of the first block, folded into the stem's output pass
             a.pe_t, a.pe_h, a.pe_w = (t.data_ptr() for t in pe)
         a.T, a.H, a.W = T, H, W
@@ -141,12 +142,12 @@ class StemFn(torch.autograd.Function):
         a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
         L.check(L.lib.dwn_stem_forward(C.byref(a), dev.index, _stream(dev)), "dwn_stem_forward")
         ctx.mod = mod; ctx.dtype = dtype; ctx.was_training = bn.training
-        ctx.save_for_backward(x, weight, y0, coef)
+        ctx.save_for_backward(x, weight, xmom, coef)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, weight, y0, coef = ctx.saved_tensors
+        x, weight, xmom, coef = ctx.saved_tensors
         if not ctx.was_training:
             raise RuntimeError("sensorium_amd: backward through eval-mode BatchNorm is not built")
         bn = ctx.mod.stem[1].bn
@@ -154,14 +155,14 @@ class StemFn(torch.autograd.Function):
         B, Cin, T, H, W = x.shape
         C0 = weight.shape[0]
         dout = dout.contiguous()
-        dw = grad_out(ctx.mod.stem[0].weight, zero=True)
+        dw = grad_out(ctx.mod.stem[0].weight)
         dgamma = grad_out(bn.weight)
         dbeta = grad_out(bn.bias)
         a = L.StemArgs()
         a.dtype = _DT[ctx.dtype]; a.training = 1; a.B = B; a.Cin = Cin; a.C0 = C0; a.S = T * H * W
         a.eps = bn.eps; a.momentum = bn.momentum
         a.x = x.data_ptr(); a.w = weight.data_ptr(); a.bn = _bn_struct(bn, coef, dgamma, dbeta)
-        a.y0 = y0.data_ptr(); a.dout = dout.data_ptr(); a.dw = dw.data_ptr()
+        a.xmom = xmom.data_ptr(); a.dout = dout.data_ptr(); a.dw = dw.data_ptr()
         ws = _ws(L.lib.dwn_stem_workspace_bytes(C.byref(a)), dev)
         a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
         L.check(L.lib.dwn_stem_backward(C.byref(a), dev.index, _stream(dev)), "dwn_stem_backward")

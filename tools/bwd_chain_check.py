@@ -12,19 +12,27 @@ import torch
 import sensorium_amd._lib as L
 from tools.bwd_check import desc, stream, timeit, dev, BF
 
-MODES = [("pair", {"DWN_DWS_WALK_OFF": "1"}), ("walk", {"DWN_DWS_WALK_OFF": "0", "DWN_DWS_CHAIN": "0"})] + \
-        [(f"chain{rb}", {"DWN_DWS_WALK_OFF": "0", "DWN_DWS_CHAIN": "1", "DWN_DWS_CHAIN_RB": str(rb)}) for rb in (2, 4, 6, 8)]
+MODES = [("pair", {"DWN_DWS_WALK_OFF": "1", "DWN_DWS_Y2RC": "0"}), ("walk", {"DWN_DWS_WALK_OFF": "0", "DWN_DWS_CHAIN": "0", "DWN_DWS_Y2RC": "0"})] + \
+        [(f"chain{rb}", {"DWN_DWS_WALK_OFF": "0", "DWN_DWS_CHAIN": "1", "DWN_DWS_CHAIN_RB": str(rb), "DWN_DWS_Y2RC": "0"}) for rb in (2, 4)] + \
+        [(f"y2rc{rb}", {"DWN_DWS_WALK_OFF": "0", "DWN_DWS_Y2RC": "1", "DWN_DWS_Y2RC_RB": str(rb)}) for rb in (1, 2)]
 
 
 def run(planes, Hin, Win, Cc, time=True, seed=0, modes=MODES):
     g = torch.Generator(device=dev); g.manual_seed(seed)
     y1 = torch.randn(planes * Hin * Win, Cc, device=dev, generator=g).to(BF)
     dh2 = torch.randn(planes * Hin * Win, Cc, device=dev, generator=g).to(BF)
-    y2 = torch.randn(planes * Hin * Win, Cc, device=dev, generator=g).to(BF)
+    y2 = torch.empty(planes * Hin * Win, Cc, device=dev, dtype=BF)
     coef = torch.cat([torch.rand(Cc, device=dev, generator=g) + 0.5, torch.randn(Cc, device=dev, generator=g) * 0.3,
                       torch.randn(Cc, device=dev, generator=g) * 0.2, torch.rand(Cc, device=dev, generator=g) + 0.5])
     abc = torch.randn(3 * Cc, device=dev, generator=g) * 0.5
     w = (torch.randn(9, Cc, device=dev, generator=g) / 3.0).to(BF).float()
+    # y2 = the forward stencil of SiLU(BN1(y1)): what the backward of a real block sees (the y2-rebuilding kernel recomputes it)
+    fa = L.DwSpatialFwdArgs()
+    fa.inp = desc(y1, Cc, v1=coef, v2=coef[Cc:], act=1)
+    fa.w = w.data_ptr(); fa.out = y2.data_ptr(); fa.planes = planes; fa.Hin = Hin; fa.Win = Win; fa.Hout = Hin; fa.Wout = Win
+    fa.C = Cc; fa.stride = 1; fa.ks = 3; fa.stats = None; fa.rows_band = 0
+    L.check(L.lib.dwn_dw_spatial_fwd(C.byref(fa), L.DWN_BF16, 0, stream()), "dwsf")
+    torch.cuda.synchronize()
     res = {}
     for name, env in modes:
         os.environ.update(env)
@@ -53,7 +61,13 @@ def run(planes, Hin, Win, Cc, time=True, seed=0, modes=MODES):
         neq = int((d0.view(torch.int16) != d1.view(torch.int16)).sum())
         wrel = float((w0 - w1).norm() / w0.norm())
         srel = float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max())
-        good = nan == 0 and neq == 0 and wrel < 1e-3 and srel < 1e-3
+        if name.startswith("y2rc"):
+            # y2 rebuilt with another tap pairing: a few results one bf16 ulp off
+            drel = float((d0.float() - d1.float()).norm() / d0.float().norm()) if nan == 0 else float("nan")
+            good = nan == 0 and neq < 2e-3 * d0.numel() and drel < 1e-3 and wrel < 1e-3 and srel < 1e-3
+            line += f" [neq {neq / d0.numel():.1e} rel {drel:.1e}]"
+        else:
+            good = nan == 0 and neq == 0 and wrel < 1e-3 and srel < 1e-3
         ok &= good
         line += f" | {name}: {'ok' if good else f'BAD nan={nan} neq={neq} dW={wrel:.1e} st={srel:.1e}'}"
         if time:
