@@ -210,6 +210,12 @@ typedef struct dwn_block_args {
     void *dy4, *da0;                         /* scratch [M_out][Cout], [M_in][Cin] */
     float *dw_pw, *dw_dws, *dw_dwt, *dw_pwl, *dse_wr, *dse_br, *dse_we, *dse_be;   /* overwritten (16-byte aligned) */
     void* ws; size_t ws_bytes;
+    /* backward: 1 = leave out the conv_pw weight gradient where it is a launch of its own (blocks whose conv_pw backward
+     * is not the fused data + weight kernel: dwn_block_pw_wgrad_deferred() says which); the caller then runs
+     * dwn_block_backward_pw_wgrad() with the SAME arguments and workspace — typically on a second stream, after an event
+     * recorded behind dwn_block_backward: nothing on the data-gradient chain waits for it (dw_pw is cleared by
+     * dwn_block_backward either way) */
+    int defer_pw_wgrad;
 } dwn_block_args;
 
 /* AdaptiveAvgPool3d((None,1,1)) — dwiseneuro.py:374,400 */
@@ -314,6 +320,10 @@ int dwn_stem_backward(const dwn_stem_args* a, int device, void* stream);
 size_t dwn_block_workspace_bytes(const dwn_block_args* a, int backward);
 int dwn_block_forward(const dwn_block_args* a, int device, void* stream);
 int dwn_block_backward(const dwn_block_args* a, int device, void* stream);
+/* 1 when dwn_block_backward(a) with a->defer_pw_wgrad = 1 would leave the conv_pw weight gradient to the call below */
+int dwn_block_pw_wgrad_deferred(const dwn_block_args* a);
+/* dW1 += dy1^T a0 (dwiseneuro.py:91 backward) from the buffers / workspace a finished dwn_block_backward(a) left behind */
+int dwn_block_backward_pw_wgrad(const dwn_block_args* a, int device, void* stream);
 int dwn_pool_forward(const dwn_pool_args* a, int device, void* stream);
 int dwn_pool_backward(const dwn_pool_args* a, int device, void* stream);
 size_t dwn_cortex_workspace_bytes(const dwn_cortex_args* a, int backward);

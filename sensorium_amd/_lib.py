@@ -111,7 +111,7 @@ class BlockArgs(C.Structure):
                 ("dout", c_p), ("dx", c_p), ("buf_a", c_p), ("buf_b", c_p), ("dy4", c_p), ("da0", c_p),
                 ("dw_pw", c_p), ("dw_dws", c_p), ("dw_dwt", c_p), ("dw_pwl", c_p), ("dse_wr", c_p),
                 ("dse_br", c_p), ("dse_we", c_p), ("dse_be", c_p),
-                ("ws", c_p), ("ws_bytes", c_sz)]
+                ("ws", c_p), ("ws_bytes", c_sz), ("defer_pw_wgrad", c_i)]
 
 
 class PoolArgs(C.Structure):
@@ -194,6 +194,8 @@ SYMBOLS = {
     "dwn_block_workspace_bytes": (c_sz, [_P(BlockArgs), c_i]),
     "dwn_block_forward": (c_i, [_P(BlockArgs), c_i, c_p]),
     "dwn_block_backward": (c_i, [_P(BlockArgs), c_i, c_p]),
+    "dwn_block_pw_wgrad_deferred": (c_i, [_P(BlockArgs)]),
+    "dwn_block_backward_pw_wgrad": (c_i, [_P(BlockArgs), c_i, c_p]),
     "dwn_pool_forward": (c_i, [_P(PoolArgs), c_i, c_p]),
     "dwn_pool_backward": (c_i, [_P(PoolArgs), c_i, c_p]),
     "dwn_cortex_workspace_bytes": (c_sz, [_P(CortexArgs), c_i]),

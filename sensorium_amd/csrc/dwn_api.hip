@@ -585,13 +585,36 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
             g.epi = EPI_STORE_CAT; g.a2 = xin.p; g.a2_ld = a.Cin; g.K1 = a.Cmid; g.bias = w.r3;
             PROF(DWN_FAM_PW_DGRAD, launch_gemm_nn(g, dt, s));
         }
-        {   // weight gradient: dW1 = dy1^T a0 with the BatchNorm-backward affine applied while loading (dh1, y1)
+        if (!a.defer_pw_wgrad) {   // weight gradient: dW1 = dy1^T a0 with the BatchNorm-backward affine applied while loading (dh1, y1)
             LoadDesc dy1 = ld_affine2(dh1, a.y1, a.Cmid, w.abc1, a.Cmid);
             GemmTN g = tn_base(dy1, LD_AFFINE2, xin, LD_PLAIN, (int)Min, a.Cmid, a.Cin, a.dw_pw, a.Cin, 1);
             PROF(DWN_FAM_PW_WGRAD, launch_gemm_tn(g, dt, s));
         }
     }
     PROF(DWN_FAM_RESID_BWD, k_residual_bwd_dx(xin, a.da0, a.dout, w.abcsc, gm, a.dx, dt, s));
+    return 0;
+}
+
+int dwn_block_pw_wgrad_deferred(const dwn_block_args* ap) {
+    const dwn_block_args& a = *ap;
+    const i64 Min = (i64)a.B * a.T * a.Hin * a.Win;
+    return (a.defer_pw_wgrad && !dwn_pw_bwd_fused_supported(a.dtype, Min, a.Cmid, a.Cin)) ? 1 : 0;
+}
+// The conv_pw weight gradient on its own (see dwn_block_args.defer_pw_wgrad): reads dh1 (buf_a), y1, the block input and
+// the BatchNorm-1 backward coefficients dwn_block_backward left in the workspace.
+int dwn_block_backward_pw_wgrad(const dwn_block_args* ap, int device, void* stream) {
+    ENTER(device);
+    const dwn_block_args& a = *ap;
+    hipStream_t s = (hipStream_t)stream;
+    TRY(check_block(a));
+    if (!dwn_block_pw_wgrad_deferred(ap)) return dwn_set_error(-2, "block_backward_pw_wgrad: nothing was deferred for these arguments");
+    BlockWs w = carve_block(a, 1, a.ws, a.ws_bytes);
+    if (w.bytes > a.ws_bytes) return dwn_set_error(-6, "block_backward_pw_wgrad: workspace too small");
+    const i64 Min = (i64)a.B * a.T * a.Hin * a.Win;
+    LoadDesc xin = ld_plain(a.x_has_pe ? a.x : a.a0, a.Cin);
+    LoadDesc dy1 = ld_affine2(a.buf_a, a.y1, a.Cmid, w.abc1, a.Cmid);
+    GemmTN g = tn_base(dy1, LD_AFFINE2, xin, LD_PLAIN, (int)Min, a.Cmid, a.Cin, a.dw_pw, a.Cin, 1);
+    PROF(DWN_FAM_PW_WGRAD, launch_gemm_tn(g, a.dtype, s));
     return 0;
 }
 

@@ -49,7 +49,8 @@ def eval_executed_bytes(batch, frames, height, width, expansion, esize, n_neuron
     return int(total)
 
 
-def ensemble_bench(folds=7, length=300, height=64, width=64, expansion=7, dtype="bf16", windows=32, repeats=3, device=None):
+def ensemble_bench(folds=7, length=300, height=64, width=64, expansion=7, dtype="bf16", windows=32, repeats=3, device=None,
+                   use_graph=True, warmup=True):
     """BASELINE.json configs[4]: `folds` models (scripts/predict.py:44-50), one trial of `length` frames at 64x64, window 16
     step 2 (src/predictors.py:36-55), every fold inside one captured hipGraph per window batch.  Returns trials/s and the
     HBM fraction of the bytes the eval path executes (not of the training pass structure)."""
@@ -73,8 +74,9 @@ def ensemble_bench(folds=7, length=300, height=64, width=64, expansion=7, dtype=
     inputs = torch.zeros(5, length, height, width)
     inputs[0] = torch.randint(0, 256, (length, height, width), generator=g).float()
     inputs[1:] = (torch.rand(4, length, 1, 1, generator=g) * 50)
-    ens = EnsemblePredictor(models, frame_stack_size=16, frame_stack_step=2, windows_per_batch=windows, use_graph=True)
-    r = ens.predict_trial(inputs, 0)
+    ens = EnsemblePredictor(models, frame_stack_size=16, frame_stack_step=2, windows_per_batch=windows, use_graph=use_graph)
+    if warmup:
+        r = ens.predict_trial(inputs, 0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(repeats):
@@ -111,7 +113,14 @@ def main():
     ap.add_argument("--repeats", type=int, default=3)
     ap.add_argument("--folds", type=int, default=7, help="fold models of the ensemble leg (scripts/predict.py:44-50: 7)")
     ap.add_argument("--windows", type=int, default=32, help="windows per forward of the ensemble leg")
+    ap.add_argument("--pmc-trial", action="store_true", help="exactly ONE ensemble trial, eager launches (no hipGraph, no warm-up): "
+                    "the command to run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (tools/predict_pmc.py sums the passes)")
     args = ap.parse_args()
+    if args.pmc_trial:
+        print(json.dumps(ensemble_bench(folds=args.folds, length=args.length, height=args.height, width=args.width,
+                                        expansion=args.expansion, dtype="bf16" if args.dtype == "bf16" else "fp32",
+                                        windows=args.windows, repeats=1, use_graph=False, warmup=False)))
+        return
     from bench import HBM_PEAK_GBS, NUM_NEURONS_MOUSE0, family_work, model_params
     from sensorium_amd.argus_models import MouseModel
     from sensorium_amd.predictors import EnsemblePredictor, Predictor
