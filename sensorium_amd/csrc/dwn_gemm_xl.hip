@@ -159,9 +159,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nn_xl_kernel(const XlArgs g) {
         xl_wait_vm0();
         xl_lds_barrier();
         for (int step = 0; step < nsteps; ++step) {
-            if (step + 1 < nsteps) issue(ks1, mt1, (step + 1) & 1);      // in flight under this step's MFMAs (and epilogue)
+            // the loads of step+1 are issued BETWEEN this step's MFMA groups, one instruction at a time: issued in one burst
+            // at the top of the step, the second-dispatched waves sat 2200-3900 cycles in queue back-pressure before their
+            // first MFMA (in-order issue) while the first-dispatched ones idled at the barrier (in-kernel stamps)
+            bool fast = false;
+            const bf16_t *pa = nullptr, *pb = nullptr;
+            unsigned sdst = 0;
+            if (step + 1 < nsteps) {
+                const int k0 = ks1 * BK;
+                if (mt1 != aptr_mt) {
+                    aptr_mt = mt1; mfull = mt1 * BM + BM <= g.M;
+                    const int m = mt1 * BM + wave * 8 + rin < g.M ? mt1 * BM + wave * 8 + rin : g.M - 1;
+                    a0p = Ag + (i64)m * g.lda + klane;
+                }
+                fast = mfull && nfull && k0 + BK <= g.K;
+                if (fast) { pa = a0p + k0; pb = b0 + k0; sdst = lds0 + (unsigned)((step + 1) & 1) * STG + (unsigned)wave * 1024u; }
+                else issue(ks1, mt1, (step + 1) & 1);                    // ragged tile / K tail: everything up front
+            }
             const unsigned char* tA = xl_smem + (step & 1) * STG;
             const unsigned char* tB = tA + A_BYTES;
+            constexpr int NL = A_CH + B_CH, SP = (2 * RM) / NL;           // loads per wave and step, MFMA groups between two of them
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const int chunk = kb * 4 + lg;
@@ -171,17 +188,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nn_xl_kernel(const XlArgs g) {
                     const int row = n_base + j * 16 + lr;
                     bfr[j] = *reinterpret_cast<const uint4*>(tB + row * 128 + ((chunk ^ (row & 7)) << 4));
                 }
+                // activation fragments two 16-row groups ahead of their MFMAs (all RM of them live at once spill at 256 VGPRs)
+                auto lda = [&](const int i) {
+                    const int row = m_base + i * 16 + lr;
+                    return *reinterpret_cast<const uint4*>(tA + row * 128 + ((chunk ^ (row & 7)) << 4));
+                };
+                af[0] = lda(0);
+                af[1] = lda(1);
 #pragma unroll
                 for (int i = 0; i < RM; ++i) {
-                    const int row = m_base + i * 16 + lr;
-                    af[i] = *reinterpret_cast<const uint4*>(tA + row * 128 + ((chunk ^ (row & 7)) << 4));
-                }
-#pragma unroll
-                for (int i = 0; i < RM; ++i)
+                    if (i + 2 < RM) af[i + 2] = lda(i + 2);
 #pragma unroll
                     for (int j = 0; j < RN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xl_bf16x8_t, bfr[j]),
                                                                             __builtin_bit_cast(xl_bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
+                    const int slot = kb * RM + i;
+                    if (slot % SP == 0 && slot / SP < NL) {
+                        const int q = slot / SP;
+                        if (fast) {
+                            if (q < A_CH) xl_glds16(pa + q * astride, (unsigned)__builtin_amdgcn_readfirstlane((int)(sdst + (unsigned)q * 8192u)));
+                            else xl_glds16(pb + (q - A_CH) * bstride, (unsigned)__builtin_amdgcn_readfirstlane((int)(sdst + A_BYTES + (unsigned)(q - A_CH) * 8192u)));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);          // pins the fragment-read / MFMA / load-issue interleave
+                }
             }
             if (ks0 == nk - 1) {
                 // ---------------- epilogue of tile mt0.  The stage just multiplied is free once every wave is past its MFMAs:
