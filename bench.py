@@ -255,6 +255,8 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--ddp-comm", default="f32", choices=["f32", "bf16"], help="gradient exchange type (bf16: half the bytes "
                     "on xGMI, fp32 master buckets)")
+    ap.add_argument("--ddp-shard", action="store_true", help="readout buckets: reduce-scatter -> AdamW/EMA on the owned 1/N slice "
+                    "-> all-gather of the parameters (hidden behind the next core forward) instead of all-reduce + full optimizer")
     ap.add_argument("--dry-run", action="store_true", help="testing only: launcher + rendezvous + timing plumbing, no GPU work")
     args = ap.parse_args()
 
@@ -289,6 +291,7 @@ def main():
     params["device"] = str(dev)
     params["amp"] = args.dtype == "bf16"
     params["ddp_comm_dtype"] = args.ddp_comm
+    params["ddp_shard_optimizer"] = bool(args.ddp_shard)
     torch.manual_seed(1234)            # identical init on every rank (GradBuckets also broadcasts rank 0)
     model = MouseModel(params)
     # reference init rule (src/utils.py:46-56): conv ~ N(0, sqrt(2/fan_out)), BN weight 1 / bias 0
@@ -475,7 +478,7 @@ def main():
         if model.buckets is not None:
             out["ddp"] = {"backend": dist.get_backend(), "buckets": len(model.buckets.buckets),
                           "bucket_mb": [round(b["flat"].numel() * 4 / 2 ** 20, 1) for b in model.buckets.buckets],
-                          "comm_dtype": args.ddp_comm,
+                          "comm_dtype": args.ddp_comm, "sharded_readout_optimizer": bool(model.buckets.shard),
                           "ring_bytes_sent_per_rank_per_step": model.buckets.bytes_on_wire_per_step(),
                           "gradients": "written by the HIP backward straight into the flat buckets; all-reduce (mean) per "
                                        "bucket launched from autograd hooks, overlapped with the rest of backward"}

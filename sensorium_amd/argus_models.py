@@ -119,6 +119,8 @@ class MouseModel(Model):
         if ema is None:
             self.optimizer.bind_ema(None, self.optimizer.ema_decay)
             return
+        if self.buckets is not None:
+            self.buckets.adopt_ema(ema.ema)       # sharded readout buckets: EMA copies laid out like the parameters
         by_name = dict(ema.ema.named_parameters())
         ema_params = [by_name[n] for n, p in self.nn_module.named_parameters() if p.requires_grad]
         self.optimizer.bind_ema(ema_params, ema.decay, owner=ema)
@@ -144,10 +146,14 @@ class MouseModel(Model):
             # broadcasts rank 0's parameters and buffers; params["ddp_comm_dtype"] / DWN_DDP_COMM=bf16: exchange bf16 copies
             comm = self.params.get("ddp_comm_dtype", os.environ.get("DWN_DDP_COMM"))
             comm = torch.bfloat16 if comm in (torch.bfloat16, "bf16", "bfloat16") else None
-            self.buckets = GradBuckets(self.nn_module, comm_dtype=comm)
+            # params["ddp_shard_optimizer"] / DWN_DDP_SHARD=1: reduce-scatter + sharded AdamW/EMA + all-gather for the readouts
+            shard = self.params.get("ddp_shard_optimizer", os.environ.get("DWN_DDP_SHARD", "0") == "1")
+            self.buckets = GradBuckets(self.nn_module, comm_dtype=comm, shard_optional=bool(shard))
             if self._model_ema is not None:                   # ... so the EMA copy taken earlier must follow (val_step uses it)
                 self._model_ema.set(self.nn_module)
         self.optimizer = MouseModel.optimizer[oname](params, **okwargs)
+        if self.buckets is not None and self.buckets.shard:
+            self.optimizer.set_shard_map(self.buckets.owned_range)
         if self._model_ema is not None:
             self._bind_ema_to_optimizer()
         pending = getattr(self, "_pending_optimizer_state", None)
@@ -189,18 +195,32 @@ class MouseModel(Model):
         if self.buckets is not None:
             self.buckets.finish()
         self.optimizer.step()
+        if self.buckets is not None and self.buckets.shard:
+            self.buckets.gather_params()          # awaited by the readouts' forward pre-hook: hidden behind the next core forward
         if self.model_ema is not None:
             # the fused AdamW kernel has already lerped the parameter copies iff it is bound to THIS ModelEma
             self.model_ema.update(self.nn_module, skip_parameters=self.optimizer.folds_ema_of(self.model_ema))
         return {"prediction": self.prediction_transform(deep_detach(prediction)), "target": deep_detach(target),
                 "loss": loss_value}
 
+    def sync_for_read(self):
+        """Sharded optimizer: make every rank's copy of the parameters and of the EMA network complete (the slices other ranks
+        update arrive by all-gather) before they are evaluated or written to a checkpoint.  A collective: every rank calls it."""
+        if self.buckets is not None and self.buckets.shard:
+            self.buckets.wait_params()
+            if self.model_ema is not None:
+                self.buckets.gather_ema()
+
+    def _eval_module(self):
+        self.sync_for_read()
+        return self.nn_module if self.model_ema is None else self.model_ema.ema
+
     # -- argus_models.py:73-87 -----------------------------------------------------------------------------
     def val_step(self, batch, state=None) -> dict:
         self.eval()
         with torch.no_grad():
             input, target = deep_to(batch, self.device, non_blocking=True)
-            module = self.nn_module if self.model_ema is None else self.model_ema.ema
+            module = self._eval_module()
             prediction = module(input)
             loss = self.loss(prediction, target)
             return {"prediction": self.prediction_transform(prediction), "target": target, "loss": loss.item()}
@@ -210,5 +230,5 @@ class MouseModel(Model):
         with torch.no_grad():
             self.eval()
             input = deep_to(input, self.device)
-            module = self.nn_module if self.model_ema is None else self.model_ema.ema
+            module = self._eval_module()
             return self.prediction_transform(module(input, mouse_index))

@@ -312,6 +312,9 @@ class Model:
 
     # -- persistence (argus file format: ema.py:63-72) -------------------------------------------------------
     def state_dict_for_save(self):
+        sync = getattr(self, "sync_for_read", None)
+        if sync is not None:
+            sync()
         return {k: v.detach().to("cpu") for k, v in self.nn_module.state_dict().items()}
 
     def save(self, file_path, optimizer_state: bool = False):

@@ -60,8 +60,16 @@ class FusedAdamWEma(torch.optim.Optimizer):
         self._ema_of = {}
         self._ema_owner = None          # the ModelEma whose parameter copies ride in this optimizer's kernel (or None)
         self._tables = {}
+        self._range_of = None
         if ema_params is not None:
             self.bind_ema(ema_params, ema_decay)
+
+    def set_shard_map(self, range_of):
+        """Sharded optimizer (ddp.GradBuckets(shard_optional=True)): ``range_of(p)`` returns ``None`` (update all of ``p``)
+        or the flattened element range ``(lo, hi)`` of ``p`` this rank owns: only that range is updated (moments exist for it
+        alone) and only that range of ``p.grad`` is read; the other ranks' slices arrive by all-gather."""
+        self._range_of = range_of
+        self._tables = {}
 
     def bind_ema(self, ema_params: Optional[List[torch.Tensor]], ema_decay: float, owner=None):
         """(Re)attach the EMA copies of the optimised parameters without touching the Adam moments / step counts:
@@ -107,25 +115,39 @@ class FusedAdamWEma(torch.optim.Optimizer):
                 st = self.state[p]
                 if not st:
                     st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p)
-                    st["exp_avg_sq"] = torch.zeros_like(p)
+                    rng = self._range_of(p) if self._range_of is not None else None
+                    if rng is None:
+                        st["exp_avg"] = torch.zeros_like(p)
+                        st["exp_avg_sq"] = torch.zeros_like(p)
+                    else:                             # moments for the owned slice only
+                        st["exp_avg"] = torch.zeros(rng[1] - rng[0], dtype=p.dtype, device=p.device)
+                        st["exp_avg_sq"] = torch.zeros(rng[1] - rng[0], dtype=p.dtype, device=p.device)
                 st["step"] += 1
                 by_step.setdefault(int(st["step"]), []).append(p)
             b1, b2 = group["betas"]
             for step, params in sorted(by_step.items()):
                 entries = np.zeros(len(params), dtype=_ENTRY_DTYPE)
                 keep = []
-                for i, p in enumerate(params):
+                n_live = 0
+                for p in params:
                     st = self.state[p]
                     g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                     keep.append(g)
                     ema = self._ema_of.get(id(p))
-                    entries[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                  0 if ema is None else ema.data_ptr(), p.numel(), 0, 0)
+                    rng = self._range_of(p) if self._range_of is not None else None
+                    lo, n = (0, p.numel()) if rng is None else (rng[0], rng[1] - rng[0])
+                    if n == 0:
+                        continue                      # another rank's slice
+                    entries[n_live] = (p.data_ptr() + 4 * lo, g.data_ptr() + 4 * lo, st["exp_avg"].data_ptr(),
+                                       st["exp_avg_sq"].data_ptr(), 0 if ema is None else ema.data_ptr() + 4 * lo, n, 0, 0)
+                    n_live += 1
+                if n_live == 0:
+                    continue
+                entries = entries[:n_live]
                 # the table cache is keyed by the set of parameters taking part, so alternating sets do not thrash it
                 key = (gi, tuple(id(p) for p in params)) if len(params) != len(group["params"]) else (gi, None)
                 table = self._tables.setdefault(key, _TableCache()).get(entries, dev)
-                L.check(L.lib.dwn_adamw_ema_multi(table.data_ptr(), len(params), self.max_blocks, float(group["lr"]),
+                L.check(L.lib.dwn_adamw_ema_multi(table.data_ptr(), n_live, self.max_blocks, float(group["lr"]),
                                                   float(b1), float(b2), float(group["eps"]),
                                                   float(group["weight_decay"]), int(step), self.ema_decay,
                                                   float(self.grad_scale), dev.index,

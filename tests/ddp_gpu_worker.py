@@ -12,6 +12,7 @@ import torch.distributed as dist
 
 def main():
     backend = sys.argv[1]
+    shard = len(sys.argv) > 2 and sys.argv[2] == "shard"      # reduce-scatter + sharded AdamW/EMA + all-gather for the readouts
     share = backend == "gloo"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = 0 if share else int(os.environ["LOCAL_RANK"])
@@ -27,7 +28,7 @@ def main():
               temporal_kernel=5, expansion_ratio=3, se_reduce_ratio=4, cortex_features=(32, 64), groups=2, softplus_beta=0.07,
               drop_rate=0.0, drop_path_rate=0.0)
     params = {"nn_module": ("dwiseneuro", kw), "loss": ("mice_poisson", {}), "optimizer": ("AdamW", {"lr": 1e-3, "weight_decay": 0.05}),
-              "device": str(dev), "amp": False, "iter_size": 1}
+              "device": str(dev), "amp": False, "iter_size": 1, "ddp_shard_optimizer": shard}
     torch.manual_seed(100 + rank)                     # different init per rank: the rank-0 broadcast must fix it (EMA copy too)
     model = MouseModel(params)
     model.set_ema(0.9)
@@ -66,17 +67,64 @@ def main():
     loss.backward()
     model.buckets.finish()
     ddp_g = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    if shard:
+        # a reduce-scattered bucket holds the averaged gradient in the owned slice only: compare there
+        mask = []
+        for p in net.parameters():
+            m = torch.ones(p.numel(), device=dev)
+            rng = model.buckets.owned_range(p)
+            if rng is not None:
+                m.zero_()
+                m[rng[0]:rng[1]] = 1
+            mask.append(m)
+        mask = torch.cat(mask)
+        covered = sum(gather(mask))
+        assert float(covered.min()) >= 1.0, "some gradient element is owned by no rank"
+        ddp_g = torch.where(mask > 0, ddp_g, mean_g)
     tot = float(mean_g.norm())
     err = float((ddp_g - mean_g).norm()) / tot
     assert err < 1e-4, f"all-reduced gradients differ from the mean of the per-rank gradients: {err:.3e}"
     # gradients are views of the flat buckets
     b0 = model.buckets.buckets[0]
     assert b0["params"][0].grad.data_ptr() == b0["flat"].data_ptr()
+    if shard:
+        sb = [b for b in model.buckets.buckets if b["sharded"]]
+        assert len(sb) == 2, "one sharded bucket per readout"
+        for b in sb:
+            for p, o in zip(b["params"], b["offsets"]):
+                assert p.data_ptr() == b["pflat"].data_ptr() + 4 * o
+        w = net.readouts[0].layer[1].weight
+        a, z = model.buckets.owned_range(w)
+        assert 0 <= a <= z <= w.numel() and model.buckets.owned_range(next(net.parameters())) is None
     net.load_state_dict(state0)
+    ema0 = torch.cat([p.detach().reshape(-1) for p in model.model_ema.ema.parameters()]).clone()
     out = model.train_step(batch)
+    model.sync_for_read()                             # sharded: parameter / EMA slices gathered from their owners
     torch.cuda.synchronize()
     assert np.isfinite(out["loss"])
     flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    # against torch.optim.AdamW on the averaged gradient (first step: the update is lr * g / (|g| + eps), so elements whose
+    # gradient is summation noise around zero — biases in front of a BatchNorm — move by anything in +-lr: compared where the
+    # gradient is not negligible)
+    pref = [torch.nn.Parameter(state0[n].clone()) for n in names]
+    off = 0
+    for q in pref:
+        q.grad = mean_g[off:off + q.numel()].view_as(q).clone()
+        off += q.numel()
+    torch.optim.AdamW(pref, lr=1e-3, weight_decay=0.05).step()
+    want = torch.cat([q.detach().reshape(-1) for q in pref])
+    solid = mean_g.abs() > 1e-3 * mean_g.abs().mean()
+    assert float(solid.float().mean()) > 0.8
+    bad = float((((flat - want).abs() > 1e-5) & solid).float().mean())
+    assert bad < 1e-3, f"parameters after the step differ from torch.optim.AdamW on the averaged gradient: {bad:.2e} of elements"
+    ema_want = 0.9 * ema0 + 0.1 * want
+    eflat = torch.cat([p.detach().reshape(-1) for p in model.model_ema.ema.parameters()])
+    bad_e = float((((eflat - ema_want).abs() > 1e-5) & solid).float().mean())
+    assert bad_e < 1e-3, f"EMA parameters differ from 0.9 ema + 0.1 p: {bad_e:.2e} of elements"
+    if shard:
+        st = model.optimizer.state[net.readouts[0].layer[1].weight]
+        a, z = model.buckets.owned_range(net.readouts[0].layer[1].weight)
+        assert st["exp_avg"].numel() == z - a, "moments must exist for the owned slice only"
     g = gather(flat)
     for x in g[1:]:
         # same averaged gradient + same optimizer state on every rank; fp32 atomics reorder the local sums, AVG is shared
@@ -102,18 +150,25 @@ def main():
     net(batch[0], rank % 2).float().sum().backward()
     model.buckets.finish()
     assert all(p.grad is not None for p in net.parameters())
-    model.optimizer.step()
+
+    def opt_step():
+        model.optimizer.step()
+        if shard:
+            model.buckets.gather_params()
+
+    opt_step()
     model.buckets.zero_grad(1)
     net(batch[0], 0).float().sum().backward()
     model.buckets.finish()
-    model.optimizer.step()                             # readout 1 skipped: its step count now lags the others'
+    opt_step()                                         # readout 1 skipped: its step count now lags the others'
     out = model.train_step(batch)                      # all parameters again, two distinct step counts in one group
     assert np.isfinite(out["loss"])
+    model.sync_for_read()
     flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     g = gather(flat)
     assert all(float((g[0] - x).abs().max()) == 0.0 for x in g[1:]), "parameters diverged after the index-mode steps"
     if rank == 0:
-        print(f"DDP_WORKER_OK backend={backend} world={world} grad_err={err:.2e}", flush=True)
+        print(f"DDP_WORKER_OK backend={backend} world={world} shard={int(shard)} grad_err={err:.2e}", flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

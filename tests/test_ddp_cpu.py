@@ -271,3 +271,124 @@ def test_grad_buckets_direct_write_and_comm_dtype_world2(comm_dtype):
     for p in procs:
         assert p.exitcode == 0, "a rank failed"
     assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def _worker_sharded(rank, world, port, ret, comm_dtype):
+    """shard_optional=True: reduce-scatter of the readout buckets, the optimizer on the owned slice only, all-gather of the
+    updated parameters — against a single-process AdamW on the rank-averaged gradients."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sensorium_amd.ddp import GradBuckets
+        torch.manual_seed(3)
+        model = _TwoHeads()
+        ref_model = _TwoHeads()
+        ref_model.load_state_dict(model.state_dict())
+        buckets = GradBuckets(model, bucket_cap_mb=1e-5, shard_optional=True, comm_dtype=comm_dtype)
+        sharded = [b for b in buckets.buckets if b["sharded"]]
+        assert len(sharded) == 2 and all(b["optional"] for b in sharded)          # one per readout
+        for b in sharded:
+            lo, hi = b["shard"]
+            assert (hi - lo) * world == b["flat"].numel() and lo % 4 == 0
+            for p, o in zip(b["params"], b["offsets"]):                            # parameters re-pointed into the flat buffer
+                assert p.data_ptr() == b["pflat"].data_ptr() + 4 * o
+        # the owned ranges of the two ranks tile every sharded parameter exactly
+        for b in sharded:
+            for p in b["params"]:
+                a, z = buckets.owned_range(p)
+                mine = torch.zeros(p.numel())
+                mine[a:z] = 1
+                both = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(both, mine)
+                assert torch.equal(sum(both), torch.ones(p.numel()))
+        assert buckets.owned_range(model.trunk.weight) is None
+        # optimizers: torch AdamW over the owned slices (views of the parameter storage) and the unsharded parameters
+        leaves, leaf_of = [], {}
+        for p in model.parameters():
+            rng = buckets.owned_range(p)
+            q = p if rng is None else p.data.view(-1)[rng[0]:rng[1]]
+            leaves.append(q)
+            leaf_of[id(p)] = (q, rng)
+        opt = torch.optim.AdamW([q for q in leaves if q.numel()], lr=1e-2, weight_decay=0.1)
+        ref_opt = torch.optim.AdamW(ref_model.parameters(), lr=1e-2, weight_decay=0.1)
+        tol = dict(rtol=1e-5, atol=1e-6) if comm_dtype is None else dict(rtol=2e-2, atol=2e-3)
+
+        def step(seed, index_of_rank):
+            buckets.zero_grad()
+            torch.manual_seed(seed + rank)
+            out = model(torch.randn(4, 6), index=index_of_rank(rank))
+            (sum(o.pow(2).sum() for o in out) if isinstance(out, list) else out.pow(2).sum()).backward()
+            buckets.finish()
+            for p in model.parameters():
+                q, rng = leaf_of[id(p)]
+                if rng is None:
+                    continue
+                q.grad = None if p.grad is None else p.grad.view(-1)[rng[0]:rng[1]]
+            opt.step()
+            buckets.gather_params()
+            # reference: both ranks' gradients, averaged, one AdamW step on whole parameters
+            ref_opt.zero_grad(set_to_none=True)
+            acc = {}
+            for r in range(world):
+                m2 = _TwoHeads()
+                m2.load_state_dict(ref_model.state_dict())
+                torch.manual_seed(seed + r)
+                out = m2(torch.randn(4, 6), index=index_of_rank(r))
+                (sum(o.pow(2).sum() for o in out) if isinstance(out, list) else out.pow(2).sum()).backward()
+                for (n, p) in m2.named_parameters():
+                    if p.grad is not None:
+                        acc[n] = acc.get(n, 0) + p.grad / world
+            for n, p in ref_model.named_parameters():
+                p.grad = acc.get(n)
+            ref_opt.step()
+            # the readouts' forward pre-hook waits for the all-gather: calling the model is enough
+            model(torch.zeros(1, 6))
+            for (n, p), (_, pr) in zip(model.named_parameters(), ref_model.named_parameters()):
+                assert torch.allclose(p, pr, **tol), (seed, n, float((p - pr).abs().max()))
+            return acc
+
+        step(20, lambda r: None)                 # every readout on every rank
+        step(30, lambda r: r)                    # rank r trains readout r only
+        acc = step(40, lambda r: 0)              # nobody uses readout 1: skipped everywhere, like a single process
+        assert "readouts.1.weight" not in acc
+        assert model.readouts[1].weight.grad is None and model.readouts[0].weight.grad is not None
+        step(50, lambda r: 1 - r)
+        # wire bytes: reduce-scatter (exchange type) + all-gather (fp32) for the sharded buckets, all-reduce for the others
+        es = 4 if comm_dtype is None else 2
+        want = sum((b["flat"].numel() * (es + 4) if b["sharded"] else 2 * b["flat"].numel() * es) * (world - 1) / world
+                   for b in buckets.buckets)
+        assert buckets.bytes_on_wire_per_step() == int(want)
+        # EMA copies: adopt -> owned slice updated -> gather_ema makes them whole
+        import copy
+        ema = copy.deepcopy(model)
+        buckets.adopt_ema(ema)
+        for (n, e), (_, p) in zip(ema.named_parameters(), model.named_parameters()):
+            assert torch.equal(e, p), n
+        for p, e in zip(model.parameters(), ema.parameters()):
+            rng = buckets.owned_range(p)
+            if rng is not None:
+                e.data.view(-1)[rng[0]:rng[1]] += 1.0
+        buckets.ema_dirty = True
+        buckets.gather_ema()
+        for (n, e), (_, p) in zip(ema.named_parameters(), model.named_parameters()):
+            if n.startswith("readouts."):
+                assert torch.equal(e, p + 1.0), n
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("comm_dtype", [None, torch.bfloat16], ids=["f32", "bf16"])
+def test_grad_buckets_sharded_optimizer_world2(comm_dtype):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, world, port, ret, comm_dtype)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    for p in procs:
+        assert p.exitcode == 0, "a rank failed"
+    assert dict(ret) == {0: "ok", 1: "ok"}

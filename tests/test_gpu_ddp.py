@@ -23,10 +23,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(backend):
+def _run(backend, *extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), str(ROOT / "tests" / "ddp_gpu_worker.py"), backend]
+           "--master-port", str(_free_port()), str(ROOT / "tests" / "ddp_gpu_worker.py"), backend, *extra]
     res = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "DDP_WORKER_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
 
@@ -39,3 +39,15 @@ def test_two_ranks_rccl_one_gpu_each():
 
 def test_two_ranks_sharing_one_gpu_gloo():
     _run("gloo")
+
+
+def test_two_ranks_rccl_sharded_readout_optimizer():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs (the single-device variant below runs instead)")
+    _run("nccl", "shard")
+
+
+def test_two_ranks_sharing_one_gpu_gloo_sharded_readout_optimizer():
+    """ddp_shard_optimizer: reduce-scatter of the readout buckets, fused AdamW/EMA on the owned slice, all-gather of the
+    parameters — same parameters / EMA as torch.optim.AdamW on the averaged gradient, identical on both ranks."""
+    _run("gloo", "shard")
