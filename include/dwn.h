@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DWN_ABI_VERSION 2
+#define DWN_ABI_VERSION 3
 #define DWN_F32 0
 #define DWN_BF16 1
 #define DWN_NREP 32 /* replicas of every cross-workgroup statistics buffer: double[DWN_NREP][2][C] */
@@ -247,6 +247,11 @@ typedef struct dwn_readout_args {
     float* out;                             /* [B][N][T] fp32 */
     const float* dout; void* dx; float* dw; float* dbias;   /* backward (dw, dbias zeroed by caller) */
     void* ws; size_t ws_bytes;
+    /* optional: the weight in the data gradient's operand layout, [groups][Cin/groups][Rp] in the compute type
+     * (dwn_readout_wt_bytes).  Non-null in forward: written by the same pass that packs the forward layout (one read of the
+     * fp32 weight for both).  Non-null in backward: used as is — the caller kept it from the forward of the same step —
+     * instead of packing the weight again. */
+    void* wt;
 } dwn_readout_args;
 
 typedef struct dwn_tensor_entry {
@@ -330,6 +335,7 @@ size_t dwn_cortex_workspace_bytes(const dwn_cortex_args* a, int backward);
 int dwn_cortex_forward(const dwn_cortex_args* a, int device, void* stream);
 int dwn_cortex_backward(const dwn_cortex_args* a, int device, void* stream);
 size_t dwn_readout_workspace_bytes(const dwn_readout_args* a, int backward);
+size_t dwn_readout_wt_bytes(const dwn_readout_args* a);
 int dwn_readout_forward(const dwn_readout_args* a, int device, void* stream);
 int dwn_readout_backward(const dwn_readout_args* a, int device, void* stream);
 

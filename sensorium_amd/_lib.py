@@ -129,7 +129,7 @@ class CortexArgs(C.Structure):
 class ReadoutArgs(C.Structure):
     _fields_ = [("dtype", c_i), ("B", c_i), ("T", c_i), ("Cin", c_i), ("groups", c_i), ("n_out", c_i),
                 ("softplus_beta", c_f), ("x", c_p), ("w", c_p), ("bias", c_p), ("drop_mask", c_p), ("out", c_p),
-                ("dout", c_p), ("dx", c_p), ("dw", c_p), ("dbias", c_p), ("ws", c_p), ("ws_bytes", c_sz)]
+                ("dout", c_p), ("dx", c_p), ("dw", c_p), ("dbias", c_p), ("ws", c_p), ("ws_bytes", c_sz), ("wt", c_p)]
 
 
 class TensorEntry(C.Structure):
@@ -202,6 +202,7 @@ SYMBOLS = {
     "dwn_cortex_forward": (c_i, [_P(CortexArgs), c_i, c_p]),
     "dwn_cortex_backward": (c_i, [_P(CortexArgs), c_i, c_p]),
     "dwn_readout_workspace_bytes": (c_sz, [_P(ReadoutArgs), c_i]),
+    "dwn_readout_wt_bytes": (c_sz, [_P(ReadoutArgs)]),
     "dwn_readout_forward": (c_i, [_P(ReadoutArgs), c_i, c_p]),
     "dwn_readout_backward": (c_i, [_P(ReadoutArgs), c_i, c_p]),
     "dwn_poisson_loss_forward": (c_i, [c_p, c_p, c_p, c_ll, c_ll, c_f, c_p, c_i, c_p]),
@@ -234,7 +235,7 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.dwn_abi_version() != 2:
+    if lib.dwn_abi_version() != 3:
         raise ImportError("libdwiseneuro_hip.so ABI version mismatch")
     for cname, struct in _STRUCTS.items():
         n = lib.dwn_sizeof(cname.encode())

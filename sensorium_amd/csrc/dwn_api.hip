@@ -720,7 +720,7 @@ int dwn_cortex_backward(const dwn_cortex_args* ap, int device, void* stream) {
 
 // ------------------------------------------------------------------------------------------------ readout
 namespace {
-struct ReadoutWs { void* wp; float* ones; float* zeros; void* dz; void* xd; size_t bytes; int Npad, Rg, Rp; };
+struct ReadoutWs { void* wp; void* dz; void* xd; size_t bytes; int Npad, Rg, Rp; };
 ReadoutWs carve_readout(const dwn_readout_args& a, int backward, void* base, size_t cap) {
     ReadoutWs w; memset(&w, 0, sizeof(w));
     Carver c(base, cap);
@@ -728,11 +728,9 @@ ReadoutWs carve_readout(const dwn_readout_args& a, int backward, void* base, siz
     const i64 M = (i64)a.B * a.T;
     w.Npad = (a.n_out + a.groups - 1) / a.groups * a.groups;
     w.Rg = w.Npad / a.groups;
-    w.Rp = (w.Rg + 7) / 8 * 8;
+    w.Rp = (w.Rg + 63) / 64 * 64;      // the data-gradient product contracts over Rp: whole k-tiles (LDS-DMA variant)
     const int Kg = a.Cin / a.groups;
-    w.wp = c.take<char>(backward ? (size_t)a.groups * Kg * w.Rp * ts : (size_t)w.Npad * Kg * ts);
-    w.ones = c.take<float>(a.Cin);
-    w.zeros = c.take<float>(a.Cin);
+    w.wp = c.take<char>(backward ? (a.wt ? 0 : (size_t)a.groups * Kg * w.Rp * ts) : (size_t)w.Npad * Kg * ts);
     if (backward) w.dz = c.take<char>((size_t)M * a.groups * w.Rp * ts);
     if (a.drop_mask) w.xd = c.take<char>((size_t)M * a.Cin * ts);      // x * dropout mask, materialised once
     w.bytes = c.off + 256;
@@ -743,6 +741,10 @@ ReadoutWs carve_readout(const dwn_readout_args& a, int backward, void* base, siz
 size_t dwn_readout_workspace_bytes(const dwn_readout_args* a, int backward) {
     return carve_readout(*a, backward, nullptr, 0).bytes;
 }
+size_t dwn_readout_wt_bytes(const dwn_readout_args* a) {
+    ReadoutWs w = carve_readout(*a, 0, nullptr, 0);
+    return (size_t)a->groups * (a->Cin / a->groups) * w.Rp * tsize(a->dtype);
+}
 int dwn_readout_forward(const dwn_readout_args* ap, int device, void* stream) {
     ENTER(device);
     const dwn_readout_args& a = *ap;
@@ -751,17 +753,15 @@ int dwn_readout_forward(const dwn_readout_args* ap, int device, void* stream) {
     ReadoutWs w = carve_readout(a, 0, a.ws, a.ws_bytes);
     if (w.bytes > a.ws_bytes) return dwn_set_error(-6, "readout_forward: workspace too small");
     const int M = a.B * a.T, Kg = a.Cin / a.groups, dt = a.dtype;
-    TRY(k_pack_weight(a.w, w.wp, 1, w.Npad, Kg, 0, w.Npad, Kg, dt, s));
+    TRY(k_pack_weight_dual(a.w, w.wp, a.wt, a.groups, w.Rg, Kg, w.Rp, dt, s));   // both operand layouts, one read of the weight
     LoadDesc x = ld_plain(a.x, a.Cin);
     const int kind = LD_PLAIN;
     if (a.drop_mask) {
         // Dropout1d (dwiseneuro.py:275): the masked input (8 MB) is materialised once — applying the per-(sample,
         // channel) mask inside the GEMM's operand loader put a dependent mask load in front of every A chunk
-        TRY(k_fill_f32(w.ones, 1.0f, a.Cin, s));
-        TRY(k_fill_f32(w.zeros, 0.0f, a.Cin, s));
         LoadDesc xm = x;
-        xm.v1 = w.ones; xm.v2 = w.zeros; xm.act = 0; xm.gate = a.drop_mask; xm.gate_ld = a.Cin; xm.rows_per_sample = a.T;
-        TRY(k_ew_apply(xm, LD_BNACT, w.xd, a.Cin, M, a.Cin, dt, s));
+        xm.gate = a.drop_mask; xm.gate_ld = a.Cin; xm.rows_per_sample = a.T;
+        TRY(k_ew_apply(xm, LD_GATE, w.xd, a.Cin, M, a.Cin, dt, s));
         x = ld_plain(w.xd, a.Cin);
     }
     GemmNN g = nn_base(x, kind, w.wp, Kg, nullptr, 0, M, w.Rg, Kg, a.groups);
@@ -776,26 +776,25 @@ int dwn_readout_backward(const dwn_readout_args* ap, int device, void* stream) {
     ReadoutWs w = carve_readout(a, 1, a.ws, a.ws_bytes);
     if (w.bytes > a.ws_bytes) return dwn_set_error(-6, "readout_backward: workspace too small");
     const int M = a.B * a.T, Kg = a.Cin / a.groups, dt = a.dtype;
-    TRY(k_pack_weight(a.w, w.wp, a.groups, w.Rg, Kg, 1, Kg, w.Rp, dt, s));   // per group W^T [Kg][Rp], zero padded
+    const void* wt = a.wt;                       // per group W^T [Kg][Rp], zero padded: kept from the forward, or packed now
+    if (!wt) { TRY(k_pack_weight_dual(a.w, nullptr, w.wp, a.groups, w.Rg, Kg, w.Rp, dt, s)); wt = w.wp; }
     TRY(k_readout_dz(a.dout, a.out, a.softplus_beta, a.B, a.T, a.n_out, w.Rg, w.Rp, a.groups, w.dz, a.dbias, dt, s));
     LoadDesc dz = ld_plain(w.dz, (i64)a.groups * w.Rp);
     {
-        GemmNN g = nn_base(dz, LD_PLAIN, w.wp, w.Rp, a.dx, a.Cin, M, Kg, w.Rp, a.groups);
+        GemmNN g = nn_base(dz, LD_PLAIN, wt, w.Rp, a.dx, a.Cin, M, Kg, w.Rp, a.groups);
         PROF(DWN_FAM_READOUT_BWD, launch_gemm_nn(g, dt, s));
     }
     LoadDesc x = ld_plain(a.x, a.Cin);
     const int kind = LD_PLAIN;
     if (a.drop_mask) {
-        TRY(k_fill_f32(w.ones, 1.0f, a.Cin, s));
-        TRY(k_fill_f32(w.zeros, 0.0f, a.Cin, s));
         LoadDesc xm = x;
-        xm.v1 = w.ones; xm.v2 = w.zeros; xm.act = 0; xm.gate = a.drop_mask; xm.gate_ld = a.Cin; xm.rows_per_sample = a.T;
-        TRY(k_ew_apply(xm, LD_BNACT, w.xd, a.Cin, M, a.Cin, dt, s));     // masked input for the weight gradient
+        xm.gate = a.drop_mask; xm.gate_ld = a.Cin; xm.rows_per_sample = a.T;
+        TRY(k_ew_apply(xm, LD_GATE, w.xd, a.Cin, M, a.Cin, dt, s));      // masked input for the weight gradient
         x = ld_plain(w.xd, a.Cin);
         // grad wrt the un-dropped input: dx *= mask (in place)
         LoadDesc dxm = ld_plain(a.dx, a.Cin);
-        dxm.v1 = w.ones; dxm.v2 = w.zeros; dxm.act = 0; dxm.gate = a.drop_mask; dxm.gate_ld = a.Cin; dxm.rows_per_sample = a.T;
-        TRY(k_ew_apply(dxm, LD_BNACT, a.dx, a.Cin, M, a.Cin, dt, s));
+        dxm.gate = a.drop_mask; dxm.gate_ld = a.Cin; dxm.rows_per_sample = a.T;
+        TRY(k_ew_apply(dxm, LD_GATE, a.dx, a.Cin, M, a.Cin, dt, s));
     }
     GemmTN g = tn_base(dz, LD_PLAIN, x, kind, M, w.Rg, Kg, a.dw, Kg, a.groups);
     g.R_load = w.Rp;

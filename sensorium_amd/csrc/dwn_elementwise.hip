@@ -1646,6 +1646,64 @@ int k_pack_weight(const float* src, void* dst, int groups, int R, int C, int tra
     DWN_CHECK_LAUNCH();
     return 0;
 }
+// One pass over an fp32 weight [groups*R][C] for both operand layouts the readout needs (dwiseneuro.py:276-281):
+//   plain[groups*R][C]   (forward: B operand, K = C contiguous) and
+//   tr[g][C][Rp]         (data gradient: B operand, K = Rp contiguous; rows r >= R are zero)
+// 64 x 64 tiles: coalesced float4 reads, the transposed copy goes through LDS and leaves as 16-byte row segments.
+// (The per-element pack_weight_kernel above read the transposed layout with a stride of C floats between neighbouring lanes:
+// 53 us per 16 M-element readout weight and layout, twice per step.)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_dual_kernel(const float* src, T* plain, T* tr, int R, int C, int Rp) {
+    constexpr int KC = TT<T>::KC;
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, g = blockIdx.z;
+    const int c4 = (tid & 15) * 4, rr = tid >> 4;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = r0 + rr + 16 * it, c = c0 + c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R && c < C) {                             // C % 4 == 0 (checked by the launcher)
+            v = *reinterpret_cast<const float4*>(src + ((i64)g * R + r) * C + c);
+            if (plain) {
+                T* d = plain + ((i64)g * R + r) * C + c;
+                if constexpr (TT<T>::IS_BF16) {
+                    uint2 o;
+                    o.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+                    o.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+                    *reinterpret_cast<uint2*>(d) = o;
+                } else {
+                    *reinterpret_cast<float4*>(d) = v;
+                }
+            }
+        }
+        tile[rr + 16 * it][c4 + 0] = v.x; tile[rr + 16 * it][c4 + 1] = v.y;
+        tile[rr + 16 * it][c4 + 2] = v.z; tile[rr + 16 * it][c4 + 3] = v.w;
+    }
+    if (!tr) return;
+    __syncthreads();
+    // transposed copy: thread -> (column c of the tile, KC consecutive r); Rp % 64 == 0 so whole segments are in range
+    constexpr int SEG = 64 / KC;                          // 16-byte segments per transposed row of the tile
+    for (int i = tid; i < 64 * SEG; i += 256) {
+        const int cl = i / SEG, sg = i % SEG;
+        const int c = c0 + cl;
+        if (c >= C) continue;
+        float v[KC];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) v[k] = tile[sg * KC + k][cl];
+        *reinterpret_cast<uint4*>(tr + ((i64)g * C + c) * Rp + r0 + sg * KC) = pack16<T>(v);
+    }
+}
+int k_pack_weight_dual(const float* src, void* plain, void* tr, int groups, int R, int C, int Rp, int dtype, hipStream_t s) {
+    if (C % 4 || (tr && Rp % 64)) return dwn_set_error(-2, "pack_weight_dual: C % 4 == 0 and Rp % 64 == 0 required");
+    const int rows = tr ? Rp : R;
+    dim3 grid((C + 63) / 64, (rows + 63) / 64, groups);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((pack_weight_dual_kernel<bf16_t>), grid, dim3(256), 0, s, src, (bf16_t*)plain, (bf16_t*)tr, R, C, Rp),
+        hipLaunchKernelGGL((pack_weight_dual_kernel<float>), grid, dim3(256), 0, s, src, (float*)plain, (float*)tr, R, C, Rp));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
 // per-sample gated weights: dst[b][n][k] = T(w[n][k] * gate[b][k])  — the SE gate folded into conv_pwl's weights so
 // that its GEMM streams the activated tensor z3 with a plain loader (dwiseneuro.py:40-43,117-120)
 template <typename T>

@@ -701,7 +701,8 @@ template <int ALD, int EPI> struct HasSingle2 {
 static bool nn_use_dma(const GemmNN& g, int bn) {
     static const char* e = getenv("DWN_NN_DMA");
     if (g.K % 64 != 0 || g.K < 128 || (g.epi == EPI_STORE_CAT && g.K1 % 64 != 0)) return false;
-    if (g.epi == EPI_READOUT) return false;        // softplus + transposed fp32 stores: that epilogue wants a second workgroup on the CU
+    static const char* er = getenv("DWN_NN_DMA_READOUT");
+    if (g.epi == EPI_READOUT && !(er && er[0] == '1')) return false;   // softplus + transposed fp32 stores: that epilogue wants a second workgroup on the CU
     if (e) return e[0] == '1';
     // measured (profiles/r2_gemm_dma.txt): wins 5-16 % on the gated project conv (per-sample weights, K = 448..1792) and on
     // K >= 512 products with at most ~5 tiles per CU; loses where K is four k-tiles (the epilogue dominates) and on the

@@ -491,10 +491,17 @@ class ReadoutFn(torch.autograd.Function):
         a.softplus_beta = mod.softplus_beta
         a.x = x.data_ptr(); a.w = weight.data_ptr(); a.bias = bias.data_ptr(); a.drop_mask = _ptr(drop_mask)
         a.out = out.data_ptr()
+        # a backward will follow: the pack pass also writes the weight in the data gradient's layout and backward reuses it
+        # (the optimizer only touches the weight after backward)
+        wt = None
+        if any(ctx.needs_input_grad):
+            wt = torch.empty(L.lib.dwn_readout_wt_bytes(C.byref(a)), dtype=torch.uint8, device=dev)
+            a.wt = wt.data_ptr()
         ws = _ws(L.lib.dwn_readout_workspace_bytes(C.byref(a), 0), dev)
         a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
         L.check(L.lib.dwn_readout_forward(C.byref(a), dev.index, _stream(dev)), "dwn_readout_forward")
         ctx.mod = mod; ctx.has_mask = drop_mask is not None
+        ctx.wt = wt
         tensors = [x, weight, bias, out]
         if drop_mask is not None:
             tensors.append(drop_mask)
@@ -521,6 +528,8 @@ class ReadoutFn(torch.autograd.Function):
         a.x = x.data_ptr(); a.w = weight.data_ptr(); a.bias = bias.data_ptr(); a.drop_mask = _ptr(drop_mask)
         a.out = out.data_ptr(); a.dout = dout.data_ptr(); a.dx = dx.data_ptr(); a.dw = dw.data_ptr()
         a.dbias = db.data_ptr()
+        if ctx.wt is not None:
+            a.wt = ctx.wt.data_ptr()
         ws = _ws(L.lib.dwn_readout_workspace_bytes(C.byref(a), 1), dev)
         a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
         L.check(L.lib.dwn_readout_backward(C.byref(a), dev.index, _stream(dev)), "dwn_readout_backward")
