@@ -720,7 +720,7 @@ int dwn_cortex_backward(const dwn_cortex_args* ap, int device, void* stream) {
 
 // ------------------------------------------------------------------------------------------------ readout
 namespace {
-struct ReadoutWs { void* wp; void* dz; void* xd; size_t bytes; int Npad, Rg, Rp; };
+struct ReadoutWs { void* wp; void* dz; void* xd; size_t bytes; int Npad, Rg, Rp, ldp, ldt; };
 ReadoutWs carve_readout(const dwn_readout_args& a, int backward, void* base, size_t cap) {
     ReadoutWs w; memset(&w, 0, sizeof(w));
     Carver c(base, cap);
@@ -730,7 +730,9 @@ ReadoutWs carve_readout(const dwn_readout_args& a, int backward, void* base, siz
     w.Rg = w.Npad / a.groups;
     w.Rp = (w.Rg + 63) / 64 * 64;      // the data-gradient product contracts over Rp: whole k-tiles (LDS-DMA variant)
     const int Kg = a.Cin / a.groups;
-    w.wp = c.take<char>(backward ? (a.wt ? 0 : (size_t)a.groups * Kg * w.Rp * ts) : (size_t)w.Npad * Kg * ts);
+    static const int pad = getenv("DWN_RO_PAD") ? atoi(getenv("DWN_RO_PAD")) : 0;      // tuning: operand row padding (elements)
+    w.ldp = Kg + pad; w.ldt = w.Rp + pad;
+    w.wp = c.take<char>(backward ? (a.wt ? 0 : (size_t)a.groups * Kg * w.ldt * ts) : (size_t)w.Npad * w.ldp * ts);
     if (backward) w.dz = c.take<char>((size_t)M * a.groups * w.Rp * ts);
     if (a.drop_mask) w.xd = c.take<char>((size_t)M * a.Cin * ts);      // x * dropout mask, materialised once
     w.bytes = c.off + 256;
@@ -743,7 +745,7 @@ size_t dwn_readout_workspace_bytes(const dwn_readout_args* a, int backward) {
 }
 size_t dwn_readout_wt_bytes(const dwn_readout_args* a) {
     ReadoutWs w = carve_readout(*a, 0, nullptr, 0);
-    return (size_t)a->groups * (a->Cin / a->groups) * w.Rp * tsize(a->dtype);
+    return (size_t)a->groups * (a->Cin / a->groups) * w.ldt * tsize(a->dtype);
 }
 int dwn_readout_forward(const dwn_readout_args* ap, int device, void* stream) {
     ENTER(device);
@@ -753,7 +755,7 @@ int dwn_readout_forward(const dwn_readout_args* ap, int device, void* stream) {
     ReadoutWs w = carve_readout(a, 0, a.ws, a.ws_bytes);
     if (w.bytes > a.ws_bytes) return dwn_set_error(-6, "readout_forward: workspace too small");
     const int M = a.B * a.T, Kg = a.Cin / a.groups, dt = a.dtype;
-    TRY(k_pack_weight_dual(a.w, w.wp, a.wt, a.groups, w.Rg, Kg, w.Rp, dt, s));   // both operand layouts, one read of the weight
+    TRY(k_pack_weight_dual(a.w, w.wp, a.wt, a.groups, w.Rg, Kg, w.Rp, w.ldp, w.ldt, dt, s));   // both operand layouts, one read of the weight
     LoadDesc x = ld_plain(a.x, a.Cin);
     const int kind = LD_PLAIN;
     if (a.drop_mask) {
@@ -764,7 +766,7 @@ int dwn_readout_forward(const dwn_readout_args* ap, int device, void* stream) {
         TRY(k_ew_apply(xm, LD_GATE, w.xd, a.Cin, M, a.Cin, dt, s));
         x = ld_plain(w.xd, a.Cin);
     }
-    GemmNN g = nn_base(x, kind, w.wp, Kg, nullptr, 0, M, w.Rg, Kg, a.groups);
+    GemmNN g = nn_base(x, kind, w.wp, w.ldp, nullptr, 0, M, w.Rg, Kg, a.groups);
     g.epi = EPI_READOUT; g.bias = a.bias; g.sp_beta = a.softplus_beta; g.out_nct = a.out; g.Tn = a.T; g.n_valid = a.n_out;
     PROF(DWN_FAM_READOUT_FWD, launch_gemm_nn(g, dt, s));
     return 0;
@@ -777,11 +779,11 @@ int dwn_readout_backward(const dwn_readout_args* ap, int device, void* stream) {
     if (w.bytes > a.ws_bytes) return dwn_set_error(-6, "readout_backward: workspace too small");
     const int M = a.B * a.T, Kg = a.Cin / a.groups, dt = a.dtype;
     const void* wt = a.wt;                       // per group W^T [Kg][Rp], zero padded: kept from the forward, or packed now
-    if (!wt) { TRY(k_pack_weight_dual(a.w, nullptr, w.wp, a.groups, w.Rg, Kg, w.Rp, dt, s)); wt = w.wp; }
+    if (!wt) { TRY(k_pack_weight_dual(a.w, nullptr, w.wp, a.groups, w.Rg, Kg, w.Rp, w.ldp, w.ldt, dt, s)); wt = w.wp; }
     TRY(k_readout_dz(a.dout, a.out, a.softplus_beta, a.B, a.T, a.n_out, w.Rg, w.Rp, a.groups, w.dz, a.dbias, dt, s));
     LoadDesc dz = ld_plain(w.dz, (i64)a.groups * w.Rp);
     {
-        GemmNN g = nn_base(dz, LD_PLAIN, wt, w.Rp, a.dx, a.Cin, M, Kg, w.Rp, a.groups);
+        GemmNN g = nn_base(dz, LD_PLAIN, wt, w.ldt, a.dx, a.Cin, M, Kg, w.Rp, a.groups);
         PROF(DWN_FAM_READOUT_BWD, launch_gemm_nn(g, dt, s));
     }
     LoadDesc x = ld_plain(a.x, a.Cin);

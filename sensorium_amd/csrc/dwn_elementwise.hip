@@ -1649,11 +1649,12 @@ int k_pack_weight(const float* src, void* dst, int groups, int R, int C, int tra
 // One pass over an fp32 weight [groups*R][C] for both operand layouts the readout needs (dwiseneuro.py:276-281):
 //   plain[groups*R][C]   (forward: B operand, K = C contiguous) and
 //   tr[g][C][Rp]         (data gradient: B operand, K = Rp contiguous; rows r >= R are zero)
+// with row strides ldp / ldt (elements)
 // 64 x 64 tiles: coalesced float4 reads, the transposed copy goes through LDS and leaves as 16-byte row segments.
 // (The per-element pack_weight_kernel above read the transposed layout with a stride of C floats between neighbouring lanes:
 // 53 us per 16 M-element readout weight and layout, twice per step.)
 template <typename T>
-__global__ __launch_bounds__(256) void pack_weight_dual_kernel(const float* src, T* plain, T* tr, int R, int C, int Rp) {
+__global__ __launch_bounds__(256) void pack_weight_dual_kernel(const float* src, T* plain, T* tr, int R, int C, int Rp, int ldp, int ldt) {
     constexpr int KC = TT<T>::KC;
     __shared__ float tile[64][65];
     const int tid = threadIdx.x;
@@ -1666,7 +1667,7 @@ __global__ __launch_bounds__(256) void pack_weight_dual_kernel(const float* src,
         if (r < R && c < C) {                             // C % 4 == 0 (checked by the launcher)
             v = *reinterpret_cast<const float4*>(src + ((i64)g * R + r) * C + c);
             if (plain) {
-                T* d = plain + ((i64)g * R + r) * C + c;
+                T* d = plain + ((i64)g * R + r) * ldp + c;
                 if constexpr (TT<T>::IS_BF16) {
                     uint2 o;
                     o.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
@@ -1691,16 +1692,17 @@ __global__ __launch_bounds__(256) void pack_weight_dual_kernel(const float* src,
         float v[KC];
 #pragma unroll
         for (int k = 0; k < KC; ++k) v[k] = tile[sg * KC + k][cl];
-        *reinterpret_cast<uint4*>(tr + ((i64)g * C + c) * Rp + r0 + sg * KC) = pack16<T>(v);
+        *reinterpret_cast<uint4*>(tr + ((i64)g * C + c) * ldt + r0 + sg * KC) = pack16<T>(v);
     }
 }
-int k_pack_weight_dual(const float* src, void* plain, void* tr, int groups, int R, int C, int Rp, int dtype, hipStream_t s) {
-    if (C % 4 || (tr && Rp % 64)) return dwn_set_error(-2, "pack_weight_dual: C % 4 == 0 and Rp % 64 == 0 required");
+int k_pack_weight_dual(const float* src, void* plain, void* tr, int groups, int R, int C, int Rp, int ldp, int ldt, int dtype,
+                       hipStream_t s) {
+    if (C % 4 || (tr && Rp % 64) || ldp % 8 || ldt % 8 || ldp < C || ldt < Rp) return dwn_set_error(-2, "pack_weight_dual: C % 4 == 0 and Rp % 64 == 0 required");
     const int rows = tr ? Rp : R;
     dim3 grid((C + 63) / 64, (rows + 63) / 64, groups);
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL((pack_weight_dual_kernel<bf16_t>), grid, dim3(256), 0, s, src, (bf16_t*)plain, (bf16_t*)tr, R, C, Rp),
-        hipLaunchKernelGGL((pack_weight_dual_kernel<float>), grid, dim3(256), 0, s, src, (float*)plain, (float*)tr, R, C, Rp));
+        hipLaunchKernelGGL((pack_weight_dual_kernel<bf16_t>), grid, dim3(256), 0, s, src, (bf16_t*)plain, (bf16_t*)tr, R, C, Rp, ldp, ldt),
+        hipLaunchKernelGGL((pack_weight_dual_kernel<float>), grid, dim3(256), 0, s, src, (float*)plain, (float*)tr, R, C, Rp, ldp, ldt));
     DWN_CHECK_LAUNCH();
     return 0;
 }

@@ -85,7 +85,8 @@ int k_adamw_ema(const TensorListEntry* list, int ntensors, int max_blocks, float
                 float grad_scale, hipStream_t s);
 int k_ema_lerp(const TensorListEntry* list, int ntensors, int max_blocks, float decay, float omd, hipStream_t s);
 int k_fill_f32(float* p, float v, int n, hipStream_t s);
-int k_pack_weight_dual(const float* src, void* plain, void* tr, int groups, int R, int C, int Rp, int dtype, hipStream_t s);
+int k_pack_weight_dual(const float* src, void* plain, void* tr, int groups, int R, int C, int Rp, int ldp, int ldt, int dtype,
+                       hipStream_t s);
 int k_pwl_bwd_reduce(const float* P, const float* gate, const float* W, int B, int K, int N, float* dW, float* dg,
                      hipStream_t s);
 int k_assemble_inputs(const dwn_clip_desc* descs, int B, int T, int H0, int W0, int H, int W, float pad, float* x,
