@@ -17,7 +17,11 @@ import torch  # noqa: F401,E402
 
 _HERE = Path(__file__).resolve().parent
 # DWN_LIB_PATH: development override (A/B runs of two builds of the same ABI on one box)
-LIB_PATH = Path(os.environ["DWN_LIB_PATH"]) if os.environ.get("DWN_LIB_PATH") else _HERE / "csrc" / "libdwiseneuro_hip.so"
+# DWN_DETERMINISTIC=1: the ordered-reduction build of the same sources (csrc/Makefile, dwn_common.h) — run-to-run bit-identical
+# results, several times slower; for re-run equality checks, not for training
+DETERMINISTIC = os.environ.get("DWN_DETERMINISTIC", "0") == "1"
+_LIB_NAME = "libdwiseneuro_hip_det.so" if DETERMINISTIC else "libdwiseneuro_hip.so"
+LIB_PATH = Path(os.environ["DWN_LIB_PATH"]) if os.environ.get("DWN_LIB_PATH") else _HERE / "csrc" / _LIB_NAME
 
 c_p = C.c_void_p
 c_i = C.c_int

@@ -156,6 +156,9 @@ static bool pwl_gated_weights(const dwn_block_args& a) {
 // three passes over a [Mout][Cmid] tensor at the price of zeroing / accumulating / reading B [Cout][Cmid] fp32 matrices,
 // so it is used when those are small next to one such pass.  DWN_PWL_BWD=old|new forces a path (tests).
 static bool pwl_bwd_per_sample(const dwn_block_args& a) {
+#ifdef DWN_DETERMINISTIC
+    return true;                 // the other path's GEMM epilogue adds to dg from several waves of a workgroup, inside its tile loop
+#endif
     static const char* force = getenv("DWN_PWL_BWD");
     if (force && force[0] == 'o') return false;
     if (force && force[0] == 'n') return true;
@@ -418,7 +421,9 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     }
     if (tr) TRY(bn_finalize(w.st2, a.Cmid, (double)Mout, a.bn2, a.Cmid, tr, a.momentum, a.eps, s));
     // temp_covn_dw (:105-111)
-    static const bool z3_off = getenv("DWN_EVAL_Z3_OFF") != nullptr;
+    // (deterministic build: the fused pass adds to the pooled sums from inside its main loop, several waves per word — the
+    // separate se_pool pass is used instead)
+    static const bool z3_off = getenv("DWN_EVAL_Z3_OFF") != nullptr DET_ONLY(|| true);
     const bool eval_z3 = !tr && !z3_off;
     {
         DwTemporalFwd d; memset(&d, 0, sizeof(d));

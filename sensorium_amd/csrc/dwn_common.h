@@ -308,6 +308,48 @@ template <int KIND, typename T> struct ColCoef {
     static constexpr bool two_tensors = (KIND == LD_AFFINE2 || KIND == LD_DY3);
 };
 
+// ---- deterministic build (-DDWN_DETERMINISTIC -> libdwiseneuro_hip_det.so, selected with DWN_DETERMINISTIC=1; SURVEY.md §5
+// "deterministic re-run equality tests").  The normal build leaves two things to arrival order: which WAVE of a workgroup adds
+// first to a shared LDS word, and which WORKGROUP adds first to a global word.  Here
+//   * every region of LDS float atomics is executed one wave after the other (DET_WAVES_BEGIN / _END: wave 0, barrier,
+//     wave 1, ...; lanes of one wave instruction that hit the same word are serialised by the LDS in lane order), and
+//   * a workgroup performs its global float atomics only while it holds the launch's ticket (DET_ENTER / DET_EXIT), handed
+//     on in linear workgroup-id order — workgroups are dispatched in that order, so the holder of an earlier ticket is always
+//     resident or finished.  A workgroup keeps the ticket from its first global atomic to its exit; kernels that flush
+//     inside their main loop therefore run one workgroup after the other.  Slow by design (a debugging build).
+// Every workgroup of a kernel that uses the ticket must pass it, whatever path it takes to its exit.
+#ifdef DWN_DETERMINISTIC
+static __device__ unsigned dwn_det_ticket_ = 0;          // one per translation unit; kernels of a stream run one at a time
+__device__ __forceinline__ unsigned det_wg_id_() { return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); }
+__device__ __forceinline__ void det_enter_() {
+    if (threadIdx.x == 0) {
+        const unsigned me = det_wg_id_();
+        while (__hip_atomic_load(&dwn_det_ticket_, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != me) __builtin_amdgcn_s_sleep(16);
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void det_exit_() {             // waits for the turn first: also the pass of a workgroup with nothing to add
+    det_enter_();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        unsigned next = det_wg_id_() + 1;
+        if (next == gridDim.x * gridDim.y * gridDim.z) next = 0;           // leave the ticket ready for the next launch
+        __hip_atomic_store(&dwn_det_ticket_, next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+#define DET_WAVES_BEGIN for (unsigned dw__ = 0; dw__ < (blockDim.x >> 6); ++dw__) { if ((threadIdx.x >> 6) == dw__) {
+#define DET_WAVES_END } __syncthreads(); }
+#define DET_ENTER() det_enter_()
+#define DET_EXIT() det_exit_()
+#define DET_ONLY(...) __VA_ARGS__
+#else
+#define DET_WAVES_BEGIN {
+#define DET_WAVES_END }
+#define DET_ENTER() ((void)0)
+#define DET_EXIT() ((void)0)
+#define DET_ONLY(...)
+#endif
+
 // ---- cross-workgroup statistics: double atomics into one of DWN_NREP replicas
 __device__ __forceinline__ void stat_add(double* base, int rep, int nchan, int which, int c, float v) {
     atomicAdd(base + ((i64)rep * 2 + which) * nchan + c, (double)v);

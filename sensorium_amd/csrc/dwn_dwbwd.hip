@@ -285,13 +285,16 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1_kernel(const D
             for (int q = 0; q < 4; ++q) v[k * 4 + q] = dwp[k][q];
         wk_fold4<9>(v, o, lane);
         const int r = lane >> 4;
+        DET_WAVES_BEGIN
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int vi = i + 9 * (r >> 1) + 18 * (r & 1);          // value index = tap*4 + q
             atomicAdd(&lw[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
         }
+        DET_WAVES_END
     }
     __syncthreads();
+    DET_ENTER();
     for (int i = tid; i < 9 * CS; i += NT) {
         const int k = i / CS, c = c0 + i % CS;
         if (c < a.C) atomicAdd(&a.dw[(i64)c * 9 + k], lw[i]);
@@ -304,17 +307,21 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1_kernel(const D
                       bi[2] * fmaf(-bm[2], sp0[1].x, sp1[1].x), bi[3] * fmaf(-bm[3], sp0[1].y, sp1[1].y)}, o[2];
         wk_fold4<2>(v, o, lane);
         const int r = lane >> 4;
+        DET_WAVES_BEGIN
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int vi = i + 2 * (r >> 1) + 4 * (r & 1);           // 0..3: Σdh1 of channel vi; 4..7: Σdh1·ŷ1 of channel vi-4
             atomicAdd(&lstat[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
         }
+        DET_WAVES_END
         __syncthreads();
+        DET_ENTER();
         if (tid < 2 * CS) {
             const int which = tid / CS, c = c0 + tid % CS;
             if (c < a.C) stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.C, which, c, lstat[tid]);
         }
     }
+    DET_EXIT();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -590,13 +597,16 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1c_kernel(const 
             for (int q = 0; q < 4; ++q) v[k * 4 + q] = dwp[k][q];
         wk_fold4<9>(v, o, lane);
         const int r = lane >> 4;
+        DET_WAVES_BEGIN
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int vi = i + 9 * (r >> 1) + 18 * (r & 1);          // value index = tap*4 + q
             atomicAdd(&lw[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
         }
+        DET_WAVES_END
     }
     __syncthreads();
+    DET_ENTER();
     for (int i = tid; i < 9 * CS; i += NT) {
         const int k = i / CS, c = c0 + i % CS;
         if (c < a.C) atomicAdd(&a.dw[(i64)c * 9 + k], lw[i]);
@@ -609,17 +619,21 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1c_kernel(const 
                       bi[2] * fmaf(-bm[2], sp0[1].x, sp1[1].x), bi[3] * fmaf(-bm[3], sp0[1].y, sp1[1].y)}, o[2];
         wk_fold4<2>(v, o, lane);
         const int r = lane >> 4;
+        DET_WAVES_BEGIN
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int vi = i + 2 * (r >> 1) + 4 * (r & 1);           // 0..3: Σdh1 of channel vi; 4..7: Σdh1·ŷ1 of channel vi-4
             atomicAdd(&lstat[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
         }
+        DET_WAVES_END
         __syncthreads();
+        DET_ENTER();
         if (tid < 2 * CS) {
             const int which = tid / CS, c = c0 + tid % CS;
             if (c < a.C) stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.C, which, c, lstat[tid]);
         }
     }
+    DET_EXIT();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -959,13 +973,16 @@ __global__ __launch_bounds__(256, 2) void dw_spatial_bwd_s1r_kernel(const DwSpat
             for (int q = 0; q < 4; ++q) v[k * 4 + q] = dwp[k][q];
         wk_fold4<9>(v, o, lane);
         const int r = lane >> 4;
+        DET_WAVES_BEGIN
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int vi = i + 9 * (r >> 1) + 18 * (r & 1);          // value index = tap*4 + q
             atomicAdd(&lw[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
         }
+        DET_WAVES_END
     }
     __syncthreads();
+    DET_ENTER();
     for (int i = tid; i < 9 * CS; i += NT) {
         const int k = i / CS, c = c0 + i % CS;
         if (c < a.C) atomicAdd(&a.dw[(i64)c * 9 + k], lw[i]);
@@ -978,17 +995,21 @@ __global__ __launch_bounds__(256, 2) void dw_spatial_bwd_s1r_kernel(const DwSpat
                       bi[2] * fmaf(-bm[2], sp0[1].x, sp1[1].x), bi[3] * fmaf(-bm[3], sp0[1].y, sp1[1].y)}, o[2];
         wk_fold4<2>(v, o, lane);
         const int r = lane >> 4;
+        DET_WAVES_BEGIN
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int vi = i + 2 * (r >> 1) + 4 * (r & 1);
             atomicAdd(&lstat[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
         }
+        DET_WAVES_END
         __syncthreads();
+        DET_ENTER();
         if (tid < 2 * CS) {
             const int which = tid / CS, c = c0 + tid % CS;
             if (c < a.C) stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.C, which, c, lstat[tid]);
         }
     }
+    DET_EXIT();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1169,13 +1190,16 @@ __global__ __launch_bounds__(256, WK_MINW2) void dw_spatial_bwd_s2_kernel(const 
             for (int q = 0; q < 4; ++q) v[k * 4 + q] = dwp[k][q];
         wk_fold4<9>(v, o, lane);
         const int r = lane >> 4;
+        DET_WAVES_BEGIN
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int vi = i + 9 * (r >> 1) + 18 * (r & 1);          // value index = tap*4 + q
             atomicAdd(&lw[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
         }
+        DET_WAVES_END
     }
     __syncthreads();
+    DET_ENTER();
     for (int i = tid; i < 9 * CS; i += NT) {
         const int k = i / CS, c = c0 + i % CS;
         if (c < a.C) atomicAdd(&a.dw[(i64)c * 9 + k], lw[i]);
@@ -1188,17 +1212,21 @@ __global__ __launch_bounds__(256, WK_MINW2) void dw_spatial_bwd_s2_kernel(const 
                       bi[2] * fmaf(-bm[2], sp0[1].x, sp1[1].x), bi[3] * fmaf(-bm[3], sp0[1].y, sp1[1].y)}, o[2];
         wk_fold4<2>(v, o, lane);
         const int r = lane >> 4;
+        DET_WAVES_BEGIN
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int vi = i + 2 * (r >> 1) + 4 * (r & 1);
             atomicAdd(&lstat[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
         }
+        DET_WAVES_END
         __syncthreads();
+        DET_ENTER();
         if (tid < 2 * CS) {
             const int which = tid / CS, c = c0 + tid % CS;
             if (c < a.C) stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.C, which, c, lstat[tid]);
         }
     }
+    DET_EXIT();
 }
 
 // ------------------------------------------------------------------------------------------------

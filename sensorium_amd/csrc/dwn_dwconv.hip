@@ -63,12 +63,15 @@ template <typename T>
 __device__ __forceinline__ void block_stats_flush(float* lstat, const float* s0, const float* s1, int cv, int c0, int C,
                                                  double* stats, int rep) {
     constexpr int CS = SL<T>::CS;
+    DET_WAVES_BEGIN
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         atomicAdd(&lstat[cv * 4 + i], s0[i]);
         atomicAdd(&lstat[CS + cv * 4 + i], s1[i]);
     }
+    DET_WAVES_END
     __syncthreads();
+    DET_ENTER();
     const int tid = threadIdx.x;
     if (tid < 2 * CS) {
         int which = tid / CS, c = c0 + tid % CS;
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(NT, 4) void dw_spatial_fwd_kernel(const DwSpatialFw
         __syncthreads();
     }
     if (a.stats) block_stats_flush<T>(lstat, st0, st1, cv, c0, a.C, a.stats, blockIdx.x % DWN_NREP);
+    DET_EXIT();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -441,6 +445,7 @@ __global__ __launch_bounds__(NT, 4) void dw_spatial_fwd_pair_kernel(const DwSpat
         const float s0[4] = {st0[0].x, st0[0].y, st0[1].x, st0[1].y}, s1[4] = {st1[0].x, st1[0].y, st1[1].x, st1[1].y};
         block_stats_flush<T>(lstat, s0, s1, cv, c0, a.C, a.stats, blockIdx.x % DWN_NREP);
     }
+    DET_EXIT();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -720,6 +725,7 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, (ST == 1 ? DWS_BWD_MINB1 : 3)) voi
     __syncthreads();
     for (int i = tid; i < KS * KS * CS; i += NT) lw[i] = 0.f;
     __syncthreads();
+    DET_WAVES_BEGIN
     if (chan_ok) {
 #pragma unroll
         for (int k = 0; k < KS * KS; ++k) {
@@ -729,13 +735,16 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, (ST == 1 ? DWS_BWD_MINB1 : 3)) voi
             atomicAdd(&lw[k * CS + cv * 4 + 3], dwp[k][1].y);
         }
     }
+    DET_WAVES_END
     __syncthreads();
+    DET_ENTER();
     for (int i = tid; i < KS * KS * CS; i += NT) {
         int k = i / CS, c = c0 + i % CS;
         if (c < a.C) atomicAdd(a.dw + (i64)c * (KS * KS) + k, lw[i]);
     }
     const float st0[4] = {sp0[0].x, sp0[0].y, sp0[1].x, sp0[1].y}, st1[4] = {sp1[0].x, sp1[0].y, sp1[1].x, sp1[1].y};
     if (a.stats) block_stats_flush<T>(lstat, st0, st1, cv, c0, a.C, a.stats, blockIdx.x % DWN_NREP);
+    DET_EXIT();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -847,6 +856,7 @@ __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFw
         }
     }
     if (a.stats) block_stats_flush<T>(lstat, st0, st1, cv, c0, a.C, a.stats, blockIdx.x % DWN_NREP);
+    DET_EXIT();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -968,17 +978,23 @@ __global__ __launch_bounds__(256, TB >= 8 ? 2 : 3) void dw_temporal_bwd_kernel(c
                 }
             }
         }
+    }
+    DET_WAVES_BEGIN
+    if (chan_ok) {
 #pragma unroll
         for (int k = 0; k < KT; ++k)
 #pragma unroll
             for (int i = 0; i < 4; ++i) atomicAdd(&lw[k * CS + cv * 4 + i], dwacc[k][i]);
     }
+    DET_WAVES_END
     __syncthreads();
+    DET_ENTER();
     for (int i = tid; i < KT * CS; i += 256) {
         int k = i / CS, c = c0 + i % CS;
         if (c < a.C) atomicAdd(a.dw + (i64)c * KT + k, lw[i]);
     }
     if (a.stats) block_stats_flush<T>(lstat, st0, st1, cv, c0, a.C, a.stats, blockIdx.x % DWN_NREP);
+    DET_EXIT();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1258,13 +1274,16 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, DWS_BWD_PAIR_MINW) void dw_spatial
     // weight gradient: reduce over the threads sharing a channel vector through LDS, then global fp32 atomics
     for (int i = tid; i < KS * KS * CS; i += NT) lw[i] = 0.f;
     __syncthreads();
+    DET_WAVES_BEGIN
     if (chan_ok) {
 #pragma unroll
         for (int k = 0; k < KS * KS; ++k)
 #pragma unroll
             for (int q = 0; q < 4; ++q) atomicAdd(&lw[k * CS + cv * 4 + q], dwp[k][q]);
     }
+    DET_WAVES_END
     __syncthreads();
+    DET_ENTER();
     for (int i = tid; i < KS * KS * CS; i += NT) {
         const int k = i / CS, c = c0 + i % CS;
         if (c < a.C) atomicAdd(&a.dw[(i64)c * (KS * KS) + k], lw[i]);
@@ -1273,6 +1292,7 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, DWS_BWD_PAIR_MINW) void dw_spatial
         const float s0[4] = {sp0[0].x, sp0[0].y, sp0[1].x, sp0[1].y}, s1[4] = {sp1[0].x, sp1[0].y, sp1[1].x, sp1[1].y};
         block_stats_flush<T>(lstat, s0, s1, cv, c0, a.C, a.stats, blockIdx.x % DWN_NREP);
     }
+    DET_EXIT();
 }
 
 template <typename T>
@@ -1457,17 +1477,23 @@ __global__ __launch_bounds__(256, DWT_RC_MINW) void dw_temporal_bwd_rc_kernel(co
                 }
             }
         }
+    }
+    DET_WAVES_BEGIN
+    if (chan_ok) {
 #pragma unroll
         for (int k = 0; k < KT; ++k)
 #pragma unroll
             for (int i = 0; i < 4; ++i) atomicAdd(&lw[k * CS + cv * 4 + i], dwacc[k][i]);
     }
+    DET_WAVES_END
     __syncthreads();
+    DET_ENTER();
     for (int i = tid; i < KT * CS; i += 256) {
         int k = i / CS, c = c0 + i % CS;
         if (c < a.C) atomicAdd(a.dw + (i64)c * KT + k, lw[i]);
     }
     if (a.stats) block_stats_flush<T>(lstat, st0, st1, cv, c0, a.C, a.stats, blockIdx.x % DWN_NREP);
+    DET_EXIT();
 }
 
 template <typename T>

@@ -331,14 +331,18 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_walk_kernel(const
             d2[k] = __uint_as_float(r.x) + __uint_as_float(r.y);
         }
         const int r = lane >> 4;                          // lane row r holds value index (r&1)*4 + (r>>1)*2 + {0,1}
+        DET_WAVES_BEGIN
 #pragma unroll
         for (int k = 0; k < 2; ++k) atomicAdd(&lstat[(r & 1) * CS + cv * 4 + (r >> 1) * 2 + k], d2[k]);
+        DET_WAVES_END
         __syncthreads();
+        DET_ENTER();
         if (tid < 2 * CS) {
             const int which = tid / CS, c = c0 + tid % CS;
             if (c < a.C) stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.C, which, c, lstat[tid]);
         }
     }
+    DET_EXIT();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -661,14 +665,18 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(cons
             d2[k] = __uint_as_float(r.x) + __uint_as_float(r.y);
         }
         const int r = lane >> 4;                          // lane row r holds value index (r&1)*4 + (r>>1)*2 + {0,1}
+        DET_WAVES_BEGIN
 #pragma unroll
         for (int k = 0; k < 2; ++k) atomicAdd(&lstat[(r & 1) * CS + cv * 4 + (r >> 1) * 2 + k], d2[k]);
+        DET_WAVES_END
         __syncthreads();
+        DET_ENTER();
         if (tid < 2 * CS) {
             const int which = tid / CS, c = c0 + tid % CS;
             if (c < a.C) stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.C, which, c, lstat[tid]);
         }
     }
+    DET_EXIT();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -25,6 +25,7 @@ __device__ __forceinline__ void slice_stats_flush(float* lstat, const float* s0,
     // xor-shuffles so that one lane per vector and wave touches LDS
     static_assert(NCV == 8, "wave pre-reduction below assumes 8 channel vectors per slice");
     const int tid = threadIdx.x;
+    DET_WAVES_BEGIN
 #pragma unroll
     for (int i = 0; i < KC; ++i) {
         float a = s0[i], b = s1[i];
@@ -35,7 +36,9 @@ __device__ __forceinline__ void slice_stats_flush(float* lstat, const float* s0,
             atomicAdd(&lstat[NCV * KC + cv * KC + i], b);
         }
     }
+    DET_WAVES_END
     __syncthreads();
+    DET_ENTER();
     if (tid < 2 * NCV * KC) {
         int which = tid / (NCV * KC), c = c0 + tid % (NCV * KC);
         if (c < C) stat_add(stats, rep, C, which, c, lstat[tid]);
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(LoadDesc d, i64 rows, int
             for (int i = 0; i < KC; ++i) { s0[i] += v[i]; s1[i] += v[i] * v[i]; }
         }
     slice_stats_flush<KC>(lstat, s0, s1, cv, c0, C, stats, blockIdx.x % DWN_NREP);
+    DET_EXIT();
 }
 
 template <typename T>
@@ -314,6 +318,7 @@ __global__ __launch_bounds__(256) void stem_xmom_kernel(const float* x, int B, i
         }
     }
     // wave reduction in double, then one LDS add per wave and value
+    DET_WAVES_BEGIN
 #pragma unroll
     for (int a_ = 0; a_ < STEM_MAXCIN; ++a_) {
         if (a_ >= Cin) break;
@@ -330,11 +335,14 @@ __global__ __launch_bounds__(256) void stem_xmom_kernel(const float* x, int B, i
             if ((tid & 63) == 0) atomicAdd(&lsum[STEM_MAXCIN + a_ * STEM_MAXCIN + b_], q);
         }
     }
+    DET_WAVES_END
     __syncthreads();
+    DET_ENTER();
     if (tid < STEM_NM) {
         const double v = lsum[tid];
         if (v != 0.0) atomicAdd(mom + (i64)(blockIdx.x % DWN_NREP) * STEM_NM + tid, v);
     }
+    DET_EXIT();
 }
 
 // one workgroup: replica reduce of the moments -> xmom, then per output channel the BatchNorm coefficients + running stats
@@ -494,6 +502,7 @@ __global__ __launch_bounds__(256) void stem_bwd_acc_kernel(const T* dout, const 
         }
     }
     // lanes l, l+8, ... of a wave share the channel vector: xor-shuffle them together, one LDS add per wave and value
+    DET_WAVES_BEGIN
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
         if (c < STEM_MAXCIN && c >= Cin) continue;
@@ -505,12 +514,15 @@ __global__ __launch_bounds__(256) void stem_bwd_acc_kernel(const T* dout, const 
             if ((tid & 63) < NCV) atomicAdd(&lacc[c * NCV * KC + cv * KC + i], v);
         }
     }
+    DET_WAVES_END
     __syncthreads();
+    DET_ENTER();
     for (int i = tid; i < NV * NCV * KC; i += 256) {
         const int c = i / (NCV * KC), o = c0 + i % (NCV * KC);
         if ((c == STEM_MAXCIN || c < Cin) && o < C0)
             atomicAdd(acc + ((i64)(blockIdx.x % DWN_NREP) * C0 + o) * NVG + (c == STEM_MAXCIN ? ::STEM_MAXCIN : c), (double)lacc[i]);
     }
+    DET_EXIT();
 }
 
 // one workgroup: dgamma, dbeta, dW from the accumulated sums (see the header of this section)
@@ -682,6 +694,7 @@ __global__ __launch_bounds__(STAT_NT) void shortcut_stats_kernel(LoadDesc xin, R
         }
     }
     slice_stats_flush<KC>(lstat, s0, s1, cv, c0, gm.Cin, stats, blockIdx.x % DWN_NREP);
+    DET_EXIT();
 }
 
 // out[m_out][c'] = d[b] * (s4*y4 + t4) + ssc*s + tsc,  s = (x+PE)[m_in][c' % Cin]
@@ -797,6 +810,7 @@ __global__ __launch_bounds__(STAT_NT) void residual_bwd_reduce_kernel(LoadDesc x
     slice_stats_flush<KC>(lstat, a0, a1, cv, c0, gm.Cout, stats4, blockIdx.x % DWN_NREP);
     __syncthreads();
     slice_stats_flush<KC>(lstat2, b0, b1, cv, c0, gm.Cout, statssc, blockIdx.x % DWN_NREP);
+    DET_EXIT();
 }
 
 // dy4[m][c'] = A1*(d*dout) + A2*y4 + A3
@@ -972,10 +986,14 @@ __global__ __launch_bounds__(256) void se_pool_kernel(LoadDesc z3, int C, int ro
             }
         }
     }
+    DET_WAVES_BEGIN
 #pragma unroll
     for (int i = 0; i < KC; ++i) atomicAdd(&lacc[cv * KC + i], acc[i]);
+    DET_WAVES_END
     __syncthreads();
+    DET_ENTER();
     if (tid < NCV * KC && c0 + tid < C) atomicAdd(pooled + (i64)b * C + c0 + tid, lacc[tid]);
+    DET_EXIT();
 }
 
 int k_se_pool(const LoadDesc& z3, int B, int C, int rows_per_sample, float* pooled, void* z3out, int dtype, hipStream_t s) {
@@ -1108,11 +1126,13 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_fast_kernel(const float* poole
                 acc[r] = fmaf(wr[(i64)rr * C + c], v, acc[r]);
             }
         }
+        DET_WAVES_BEGIN
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const float t = wave_sum(acc[r]);
             if (lane == 0 && r0 + r < R) atomicAdd(&hid[r0 + r], t);
         }
+        DET_WAVES_END
     }
     __syncthreads();
     if (tid < R) {
@@ -1186,11 +1206,13 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_fast_kernel(const float* dg, c
                 for (int r = 0; r < RB; ++r) acc[r] = fmaf(wrow[r0 + r < R ? r0 + r : R - 1], v, acc[r]);
             }
         }
+        DET_WAVES_BEGIN
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const float t = wave_sum(acc[r]);
             if (lane == 0 && r0 + r < R) atomicAdd(&dhp[r0 + r], t);
         }
+        DET_WAVES_END
     }
     __syncthreads();
     if (tid < R) {
@@ -1334,6 +1356,7 @@ __global__ __launch_bounds__(256) void bn3_bwd_reduce_kernel(LoadDesc d, const f
         }
     }
     slice_stats_flush<KC>(lstat, s0, s1, cv, c0, C, stats, blockIdx.x % DWN_NREP);
+    DET_EXIT();
 }
 int k_bn3_bwd_reduce(const LoadDesc& d, const float* coef3, i64 rows, int C, double* stats, void* dh_out, int dtype, hipStream_t s) {
     DISPATCH_T(dtype,
@@ -1362,6 +1385,7 @@ __global__ __launch_bounds__(256) void pwl_bwd_reduce_kernel(const float* __rest
         for (int j = 0; j < 4; ++j) { dgp[bb][j] = 0.f; gt[bb][j] = 0.f; }
     const bool vec = (N & 3) == 0 && n + 3 < N;         // whole 16-byte group inside the row (N % 4 == 0 keeps it aligned)
     const bool nok = n < N;
+    DET_ENTER();                 // dW receives this workgroup's sums from inside the k loop
     if (nok) {
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb)
@@ -1417,6 +1441,7 @@ __global__ __launch_bounds__(256) void pwl_bwd_reduce_kernel(const float* __rest
             dg[(i64)(b0 + bb) * N + nn] = t;
         }
     }
+    DET_EXIT();
 }
 int k_pwl_bwd_reduce(const float* P, const float* gate, const float* W, int B, int K, int N, float* dW, float* dg,
                      hipStream_t s) {
@@ -1770,6 +1795,7 @@ __global__ __launch_bounds__(256) void readout_dz_kernel(const float* dout, cons
         int np = n0 + nl;
         if (np < npad_total) dz[((i64)b * Tn + t) * npad_total + np] = from_f<T>(tile[nl * (Tn + 1) + t]);
     }
+    DET_ENTER();
     if (tid < 64) {
         int np = n0 + tid;
         int g = np / Rp, r = np % Rp;
@@ -1780,6 +1806,7 @@ __global__ __launch_bounds__(256) void readout_dz_kernel(const float* dout, cons
             atomicAdd(db + n, sum);
         }
     }
+    DET_EXIT();
 }
 int k_readout_dz(const float* dout, const float* out, float beta, int B, int Tn, int n_valid, int Rg, int Rp,
                  int groups, void* dz, float* db, int dtype, hipStream_t s) {
@@ -1807,7 +1834,9 @@ __global__ __launch_bounds__(256) void poisson_fwd_kernel(const float* pred, con
     __shared__ double part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
+    DET_ENTER();
     if (threadIdx.x == 0) atomicAdd(loss, part[0] + part[1] + part[2] + part[3]);
+    DET_EXIT();
 }
 __global__ __launch_bounds__(256) void poisson_bwd_kernel(const float* pred, const float* target, const float* w,
                                                           const float* gscale, i64 per_sample, i64 total, float eps,
@@ -2015,6 +2044,7 @@ __global__ __launch_bounds__(256) void pw_bwd_prep_kernel(const float* w1, const
             const int k = k0 + kl, n = n0 + nl;
             if (k < E && n < C) bp[n * ld + k] = from_f<T>(sA[kl][nl]);
         }
+        DET_EXIT();
         return;
     }
     bid -= nscale;
@@ -2058,6 +2088,7 @@ __global__ __launch_bounds__(256) void pw_bwd_prep_kernel(const float* w1, const
             for (int j = 0; j < 4; ++j) acc3[j] = fmaf(a3, b[j], acc3[j]);
         }
     }
+    DET_ENTER();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int cp = bx * 64 + ty * 4 + i;
@@ -2074,6 +2105,7 @@ __global__ __launch_bounds__(256) void pw_bwd_prep_kernel(const float* w1, const
             if (c < C) atomicAdd(r3 + c, acc3[j]);
         }
     }
+    DET_EXIT();
 }
 // (a "last block converts G" tail instead of this second launch was measured 4x slower than the whole chain it replaced:
 // an agent-scope release fence per block means an L2 write-back on this 8-XCD part)

@@ -141,7 +141,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     }
     const int mt_beg = (int)((i64)mr * ntm / nranges);
     const int mt_end = (int)((i64)(mr + 1) * ntm / nranges);
-    if (mt_beg >= mt_end) return;
+    if (mt_beg >= mt_end) { DET_EXIT(); return; }
+    // (deterministic build) the dg epilogue adds to global words from inside the tile loop: the workgroup holds the ticket throughout
+    if constexpr (EPI == EPI_DG) DET_ENTER();
     const int grp = blockIdx.y;
     const int n0 = nt * BN;
     const int acol0 = grp * g.K;
@@ -313,10 +315,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     auto flush_dg = [&]() {
         if (tid < BN) lred[tid] = 0.f;
         bar();
+        DET_WAVES_BEGIN
         if (ncol < g.N) {
 #pragma unroll
             for (int i = 0; i < KC; ++i) atomicAdd(&lred[ch * KC + i], dgp[i]);
         }
+        DET_WAVES_END
         bar();
         if (tid < BN && n0 + tid < g.N && dg_b >= 0) atomicAdd(g.dg + (i64)dg_b * g.dg_ld + n0 + tid, lred[tid]);
         bar();
@@ -590,6 +594,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
 #pragma unroll
                             for (int i = 0; i < KC; ++i) dgp[i] += v[i] * y[i];
                         } else {
+                            // (the deterministic build never takes the dg epilogue: dwn_api.hip routes conv_pwl's backward through
+                            // the per-sample products there — several waves add to one word here)
 #pragma unroll
                             for (int i = 0; i < KC; ++i) atomicAdd(g.dg + (i64)b * g.dg_ld + ncol + i, v[i] * y[i]);
                         }
@@ -645,6 +651,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
             }
             if (tid < 2 * BN) lred[tid] = 0.f;
             __syncthreads();
+            DET_WAVES_BEGIN
             if (ncol < g.N) {
 #pragma unroll
                 for (int i = 0; i < KC; ++i) {
@@ -652,7 +659,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                     atomicAdd(&lred[BN + ch * KC + i], st1[i]);
                 }
             }
+            DET_WAVES_END
             __syncthreads();
+            DET_ENTER();
             if (tid < 2 * BN) {
                 int col = tid % BN, which = tid / BN;
                 if (n0 + col < g.N)
@@ -660,6 +669,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
             }
         }
     }
+    DET_EXIT();
 }
 
 template <typename T, int ALD, int EPI, int BNv, int SINGLE>
@@ -965,7 +975,8 @@ __global__ __launch_bounds__(256, (TnOcc<PLD, QLD>::value)) void gemm_tn_kernel(
             __syncthreads();
         }
     }
-    if (mbeg >= mend) return;
+    if (mbeg >= mend) { DET_EXIT(); return; }
+    DET_ENTER();
     float* dw = g.dw + (i64)grp * g.R * g.lddw + dw_off;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -977,6 +988,7 @@ __global__ __launch_bounds__(256, (TnOcc<PLD, QLD>::value)) void gemm_tn_kernel(
                 int cc = c0 + wn * 64 + j * 16 + lr;
                 if (rr < g.R && cc < g.Cc) atomicAdd(dw + (i64)rr * g.lddw + cc, acc[i][j][r]);
             }
+    DET_EXIT();
 }
 
 template <typename T, int PLD, int QLD>
@@ -1205,6 +1217,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_fused_kernel(const bf16_t* __re
             }
     }
     // acc_dw[kc][j][r] = dW[e = kc*64 + wm*16 + 4*lg + r][c = wn*32 + j*16 + lr]
+    DET_ENTER();
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc)
 #pragma unroll
@@ -1212,6 +1225,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_fused_kernel(const bf16_t* __re
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 atomicAdd(dW + (size_t)(kc * 64 + wm * 16 + 4 * lg + r) * CIN + wn * 32 + j * 16 + lr, acc_dw[kc][j][r]);
+    DET_EXIT();
 }
 
 

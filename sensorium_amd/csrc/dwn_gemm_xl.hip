@@ -284,6 +284,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nn_xl_kernel(const XlArgs g) {
 
 // shapes this kernel takes over (DWN_NN_XL=0 never, =1 whenever the arguments allow it)
 bool gemm_nn_xl_eligible(const GemmNN& g, int dtype) {
+#ifdef DWN_DETERMINISTIC
+    return false;                                         // the deterministic build keeps to the kernels with ordered reductions
+#endif
     const char* e = getenv("DWN_NN_XL");                  // read per call: A/B inside one process
     if (e && e[0] == '0') return false;
     if (dtype != DWN_BF16 || g.a_kind != LD_PLAIN || g.epi != EPI_STORE || g.b_sample_stride || g.a2) return false;

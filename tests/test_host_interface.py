@@ -224,3 +224,22 @@ def test_pooled_drop_path_draws_follow_the_reference_rates():
     net.eval()
     net._draw_drop_paths(4, torch.device("cpu"))
     assert all(m.sample(4, torch.device("cpu")) is None for m in layers)
+
+
+def test_deterministic_build_of_the_library_loads_and_matches_the_abi():
+    """csrc/Makefile builds the ordered-reduction variant next to the product library (DWN_DETERMINISTIC=1 selects it):
+    same ABI version, same struct layouts, every symbol of include/dwn.h."""
+    import ctypes as C
+    from pathlib import Path
+    import sensorium_amd._lib as L
+    path = Path(L.__file__).resolve().parent / "csrc" / "libdwiseneuro_hip_det.so"
+    assert path.exists(), "run __graft_entry__.build()"
+    det = C.CDLL(str(path))
+    det.dwn_abi_version.restype = C.c_int
+    assert det.dwn_abi_version() == L.lib.dwn_abi_version()
+    det.dwn_sizeof.restype = C.c_size_t
+    det.dwn_sizeof.argtypes = [C.c_char_p]
+    for cname, struct in L._STRUCTS.items():
+        assert det.dwn_sizeof(cname.encode()) == C.sizeof(struct), cname
+    for name in L.SYMBOLS:
+        assert hasattr(det, name), name
