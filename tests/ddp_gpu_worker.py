@@ -12,7 +12,7 @@ import torch.distributed as dist
 
 def main():
     backend = sys.argv[1]
-    shard = len(sys.argv) > 2 and sys.argv[2] == "shard"      # reduce-scatter + sharded AdamW/EMA + all-gather for the readouts
+    shard = "shard" in sys.argv[2:]      # reduce-scatter + sharded AdamW/EMA + all-gather for the readouts
     share = backend == "gloo"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = 0 if share else int(os.environ["LOCAL_RANK"])
@@ -24,15 +24,23 @@ def main():
         dist.init_process_group("gloo")
     from sensorium_amd.argus_models import MouseModel
     from sensorium_amd.synthetic import make_batch
+    full = "full" in sys.argv[2:]                             # the metric architecture: buckets split at the real 12 MB cap
     kw = dict(readout_outputs=(24, 40), in_channels=5, core_features=(8, 8, 16), spatial_strides=(2, 1, 2), spatial_kernel=3,
               temporal_kernel=5, expansion_ratio=3, se_reduce_ratio=4, cortex_features=(32, 64), groups=2, softplus_beta=0.07,
               drop_rate=0.0, drop_path_rate=0.0)
+    shape = (4, 6, 12, 16)
+    if full:
+        kw = dict(readout_outputs=(1536, 2048), in_channels=5, core_features=(64, 64, 64, 64, 128, 128, 128, 256, 256),
+                  spatial_strides=(2, 1, 1, 1, 2, 1, 1, 2, 1), spatial_kernel=3, temporal_kernel=5, expansion_ratio=7,
+                  se_reduce_ratio=32, cortex_features=(1024, 2048, 4096), groups=2, softplus_beta=0.07, drop_rate=0.0,
+                  drop_path_rate=0.0)
+        shape = (2, 8, 36, 64)
     params = {"nn_module": ("dwiseneuro", kw), "loss": ("mice_poisson", {}), "optimizer": ("AdamW", {"lr": 1e-3, "weight_decay": 0.05}),
               "device": str(dev), "amp": False, "iter_size": 1, "ddp_shard_optimizer": shard}
     torch.manual_seed(100 + rank)                     # different init per rank: the rank-0 broadcast must fix it (EMA copy too)
     model = MouseModel(params)
     model.set_ema(0.9)
-    batch = make_batch(4, 6, 12, 16, (24, 40), seed=7 + rank, device=dev)
+    batch = make_batch(*shape, kw["readout_outputs"], seed=7 + rank, device=dev)
     model.get_optimizer()                             # builds GradBuckets: broadcast of parameters / buffers
     net = model.nn_module
     names = [n for n, _ in net.named_parameters()]
@@ -87,6 +95,9 @@ def main():
     # gradients are views of the flat buckets
     b0 = model.buckets.buckets[0]
     assert b0["params"][0].grad.data_ptr() == b0["flat"].data_ptr()
+    if full:
+        sizes = [b["flat"].numel() * 4 / 2 ** 20 for b in model.buckets.buckets]
+        assert len(sizes) >= 5 and max(s_ for s_, b in zip(sizes, model.buckets.buckets) if not b["optional"]) < 30, sizes
     if shard:
         sb = [b for b in model.buckets.buckets if b["sharded"]]
         assert len(sb) == 2, "one sharded bucket per readout"

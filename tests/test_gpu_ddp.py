@@ -51,3 +51,9 @@ def test_two_ranks_sharing_one_gpu_gloo_sharded_readout_optimizer():
     """ddp_shard_optimizer: reduce-scatter of the readout buckets, fused AdamW/EMA on the owned slice, all-gather of the
     parameters — same parameters / EMA as torch.optim.AdamW on the averaged gradient, identical on both ranks."""
     _run("gloo", "shard")
+
+
+def test_two_ranks_sharing_one_gpu_gloo_metric_architecture():
+    """The same checks on the benchmarked architecture (nine blocks, expansion 7, 1024-2048-4096 cortex, two readouts) at B=2:
+    ~25 M parameters in several buckets split at the 12 MB cap, the real kernels' gradients written into the bucket slices."""
+    _run("gloo", "full")
