@@ -20,6 +20,10 @@
 #include "dwn_internal.h"
 #include <type_traits>
 
+#ifndef NN_DMA_NST
+#define NN_DMA_NST 3                 // stages of the LDS-DMA ring of gemm_nn_kernel<..., 3>
+#endif
+
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     constexpr int NJ = BN / 32;                        // 16-column sub-tiles per wave (2x2 waves)
     constexpr int A_CH = BM * 8 / 256;
     constexpr int B_CH = BN * 8 / 256;
-    constexpr int CROW = BN * (int)sizeof(T) + 16;     // epilogue staging row stride (bytes)
+    constexpr int CROW = BN * (int)sizeof(T) + ((SINGLE == 3 && NN_DMA_NST >= 4) ? 0 : 16);     // epilogue staging row stride (bytes)
     constexpr int CROWS = TT<T>::IS_BF16 ? 128 : 32;   // rows staged per epilogue pass (bf16: whole tile, one pass)
     constexpr int NPASS = BM / CROWS;
     constexpr int CPR = BN / KC;                       // 16-byte chunks per output row
@@ -100,16 +104,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     // and under the epilogue, with no staging registers.  One workgroup per CU (131 KB).  For the shapes whose k-loop is a
     // serial chain of HBM round trips: few M-tiles per workgroup and a long K (blocks 7-8, cortex, readouts).
     constexpr bool DMA = SINGLE == 3;
-    constexpr int NST = 3;
+    // NN_DMA_NST = 4: three k-tiles in flight instead of two (96 KB per CU).  The epilogue staging then ALIASES the ring stage
+    // the tile's last MFMAs have just released (the next load into it is issued at the next tile's first k-step, after the
+    // epilogue's closing barrier); it is exactly one stage when its rows carry no padding, so the bank stagger of the
+    // column-strided accumulator writes comes from an XOR swizzle of the 16-byte chunk index with the row instead.
+    constexpr int NST = DMA ? NN_DMA_NST : 3;
+    constexpr bool SC_ALIAS = DMA && NST >= 4;
     constexpr int SA_BYTES = NKT * BM * ROWB, SB_BYTES = NKT * BN * ROWB, SC_BYTES = CROWS * CROW;
     constexpr int STG_BYTES = SA_BYTES + SB_BYTES;
     constexpr bool ALIAS_C = (NKT == 2 && BN == 128);
     constexpr int R0_BYTES = ALIAS_C ? (SA_BYTES > SC_BYTES ? SA_BYTES : SC_BYTES) : SA_BYTES;
-    constexpr int SMEM_BYTES = DMA ? NST * STG_BYTES + SC_BYTES : R0_BYTES + SB_BYTES + (ALIAS_C ? 0 : SC_BYTES);
+    static_assert(!SC_ALIAS || SC_BYTES <= STG_BYTES, "the aliased epilogue staging must fit one ring stage");
+    constexpr int SMEM_BYTES = DMA ? NST * STG_BYTES + (SC_ALIAS ? 0 : SC_BYTES) : R0_BYTES + SB_BYTES + (ALIAS_C ? 0 : SC_BYTES);
     __shared__ __attribute__((aligned(16))) unsigned char smem_nn[SMEM_BYTES];
     unsigned char* const sA = smem_nn;
     unsigned char* const sB = smem_nn + (DMA ? SA_BYTES : R0_BYTES);
-    unsigned char* const sC = DMA ? smem_nn + NST * STG_BYTES : (ALIAS_C ? smem_nn : smem_nn + R0_BYTES + SB_BYTES);
+    unsigned char* sC = DMA ? smem_nn + (SC_ALIAS ? 0 : NST * STG_BYTES) : (ALIAS_C ? smem_nn : smem_nn + R0_BYTES + SB_BYTES);
+    // byte offset of (row r, byte b of the row) in the staging tile
+    auto sc_off = [&](int r, int b) -> int {
+        if constexpr (SC_ALIAS) return r * CROW + ((((b >> 4) ^ (r & (CPR < 16 ? CPR - 1 : 15))) << 4) | (b & 15));
+        else return r * CROW + b;
+    };
     __shared__ float lred[2 * BN];
 
     const int tid = threadIdx.x;
@@ -398,13 +413,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
             for (int kt = 0; kt < nk; ++kt) {
                 // this wave's loads of the consumed k-tile have landed once at most the next k-tile's are outstanding
                 // (loads retire in order; the epilogue's younger stores only make the wait stricter)
-                if (n_issued - n_done > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + BN / 32) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (NST >= 4) {
+                    if (n_issued - n_done > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (4 + BN / 32)) : "memory");
+                    else if (n_issued - n_done > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + BN / 32) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else {
+                    if (n_issued - n_done > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + BN / 32) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 nn_lds_barrier();                               // every wave's part landed; everyone is past the previous MFMAs
                 dma_issue();                                    // k-tile +2 into the stage the previous MFMAs just released
                 mma_tile(cs_st * STG_BYTES);
                 ++n_done;
                 cs_st = cs_st == NST - 1 ? 0 : cs_st + 1;
+            }
+            if constexpr (SC_ALIAS) {
+                // the stage just consumed is free until the next tile's first k-step issues into it
+                sC = smem_nn + (cs_st == 0 ? NST - 1 : cs_st - 1) * STG_BYTES;
+                nn_lds_barrier();                               // every wave is done reading that stage
             }
         } else if constexpr (single) {
             if constexpr (HN) load_a((mt + 1) * BM, 0);         // in flight under the MFMAs and the epilogue
@@ -492,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
 #pragma unroll
                             for (int j = 0; j < NJ; ++j) {
                                 const int col = wn * (BN / 2) + j * 16 + lg * 4;
-                                unsigned char* dst = sC + (trow - prow0) * CROW + col * (int)sizeof(T);
+                                unsigned char* dst = sC + sc_off(trow - prow0, col * (int)sizeof(T));
                                 if (EPI == EPI_STORE_CAT && n0 + col < g.N) {
                                     const float4 bv = *reinterpret_cast<const float4*>(g.bias + ccol0 + n0 + col);
                                     acc[i][j][0] += bv.x; acc[i][j][1] += bv.y; acc[i][j][2] += bv.z; acc[i][j][3] += bv.w;
@@ -516,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                     for (int it = 0; it < CROWS * CPR / 256; ++it) {
                         const int row = tid / CPR + it * (256 / CPR);
                         const int m = mp + row;
-                        const uint4 raw = *reinterpret_cast<const uint4*>(sC + row * CROW + ch_e * 16);
+                        const uint4 raw = *reinterpret_cast<const uint4*>(sC + sc_off(row, ch_e * 16));
                         float v[KC];
                         unpack16<T>(raw, v);
                         if constexpr (EPI == EPI_DH3) {
@@ -552,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                     const int row = tid / CPR + it * (256 / CPR);
                     const int m = mp + row;
                     if (m >= g.M || ncol >= g.N) continue;
-                    const uint4 raw = *reinterpret_cast<const uint4*>(sC + row * CROW + ch * 16);
+                    const uint4 raw = *reinterpret_cast<const uint4*>(sC + sc_off(row, ch * 16));
                     float v[KC];
                     unpack16<T>(raw, v);
                     if constexpr (EPI == EPI_DH3) {
@@ -622,7 +648,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
             __syncthreads();
         }
     };
-    if constexpr (DMA) { dma_issue(); dma_issue(); }
+    if constexpr (DMA) {
+#pragma unroll
+        for (int q = 0; q < NST - 1; ++q) dma_issue();
+    }
     else if constexpr (!single) { load_a(mt_beg * BM, 0); load_b(0, mt_beg * BM); }
     for (int mt = mt_beg; mt < mt_end; ++mt) {
         const int m0_ = mt * BM;
