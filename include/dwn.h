@@ -327,6 +327,9 @@ int dwn_block_forward(const dwn_block_args* a, int device, void* stream);
 int dwn_block_backward(const dwn_block_args* a, int device, void* stream);
 /* 1 when dwn_block_backward(a) with a->defer_pw_wgrad = 1 would leave the conv_pw weight gradient to the call below */
 int dwn_block_pw_wgrad_deferred(const dwn_block_args* a);
+/* bit 0: dwn_block_forward writes y1; bit 1: it writes y3 (eval mode skips them where the stencil rebuilds y1 / the temporal
+ * pass emits z3 directly: the caller may leave those pointers NULL) */
+int dwn_block_forward_writes(const dwn_block_args* a);
 /* dW1 += dy1^T a0 (dwiseneuro.py:91 backward) from the buffers / workspace a finished dwn_block_backward(a) left behind */
 int dwn_block_backward_pw_wgrad(const dwn_block_args* a, int device, void* stream);
 int dwn_pool_forward(const dwn_pool_args* a, int device, void* stream);

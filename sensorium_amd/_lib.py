@@ -199,6 +199,7 @@ SYMBOLS = {
     "dwn_block_forward": (c_i, [_P(BlockArgs), c_i, c_p]),
     "dwn_block_backward": (c_i, [_P(BlockArgs), c_i, c_p]),
     "dwn_block_pw_wgrad_deferred": (c_i, [_P(BlockArgs)]),
+    "dwn_block_forward_writes": (c_i, [_P(BlockArgs)]),
     "dwn_block_backward_pw_wgrad": (c_i, [_P(BlockArgs), c_i, c_p]),
     "dwn_pool_forward": (c_i, [_P(PoolArgs), c_i, c_p]),
     "dwn_pool_backward": (c_i, [_P(PoolArgs), c_i, c_p]),

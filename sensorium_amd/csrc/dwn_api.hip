@@ -600,6 +600,16 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     return 0;
 }
 
+// Which of the intermediates dwn_block_forward will write for these arguments: bit 0 = y1, bit 1 = y3.  Training writes
+// both; the eval-mode forward skips y1 where the stencil rebuilds it (block_fwd_rc) and y3 where the temporal pass emits z3
+// directly — the caller need not allocate what is not written (and may pass NULL for it).
+int dwn_block_forward_writes(const dwn_block_args* ap) {
+    const dwn_block_args& a = *ap;
+    if (a.training) return 3;
+    static const bool z3_off = getenv("DWN_EVAL_Z3_OFF") != nullptr DET_ONLY(|| true);
+    return (block_fwd_rc(a) ? 0 : 1) | (z3_off ? 2 : 0);
+}
+
 int dwn_block_pw_wgrad_deferred(const dwn_block_args* ap) {
     const dwn_block_args& a = *ap;
     const i64 Min = (i64)a.B * a.T * a.Hin * a.Win;

@@ -276,9 +276,7 @@ class BlockFn(torch.autograd.Function):
             _check_bn(bn)
         training = bns[0].training
         f32 = dict(dtype=torch.float32, device=dev)
-        y1 = torch.empty(B, T, Hin, Win, Cmid, dtype=dtype, device=dev)
         y2 = torch.empty(B, T, Hout, Wout, Cmid, dtype=dtype, device=dev)
-        y3 = torch.empty_like(y2)
         z3 = torch.empty_like(y2)
         a0 = None if x_has_pe else torch.empty_like(x)
         y4 = torch.empty(B, T, Hout, Wout, Cout, dtype=dtype, device=dev)
@@ -289,7 +287,11 @@ class BlockFn(torch.autograd.Function):
                      gate=torch.empty(B, Cmid, **f32))
         a = _block_args(blk, geom, x, dtype, training, coefs, saved, drop_scale, x_has_pe, a0)
         a.out = out.data_ptr()
-        a.y1 = y1.data_ptr(); a.y2 = y2.data_ptr(); a.y3 = y3.data_ptr(); a.y4 = y4.data_ptr()
+        # eval: y1 is not written where the stencil rebuilds it, y3 not where the temporal pass emits z3 directly
+        writes = 3 if training else L.lib.dwn_block_forward_writes(C.byref(a))
+        y1 = torch.empty(B, T, Hin, Win, Cmid, dtype=dtype, device=dev) if writes & 1 else None
+        y3 = torch.empty_like(y2) if writes & 2 else None
+        a.y1 = _ptr(y1); a.y2 = y2.data_ptr(); a.y3 = _ptr(y3); a.y4 = y4.data_ptr()
         a.z3 = z3.data_ptr()
         if out_pe is not None:   # next block's positional encoding, folded into this block's residual pass
             a.out_pe_t, a.out_pe_h, a.out_pe_w = (t.data_ptr() for t in out_pe)
@@ -302,6 +304,8 @@ class BlockFn(torch.autograd.Function):
             blk._captured = dict(y1=y1, y2=y2, y3=y3, y4=y4, z3=z3, coefs=coefs, **saved)
         ctx.has_drop = drop_scale is not None
         # the block input *including* its positional encoding is what backward needs
+        if not training:              # no backward through eval-mode BatchNorm: nothing to keep
+            return out
         tensors = [x if x_has_pe else a0, y1, y2, y3, y4, *coefs, saved["pmean"], saved["hidpre"], saved["gate"], z3]
         if drop_scale is not None:
             tensors.append(drop_scale)
