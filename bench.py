@@ -493,12 +493,14 @@ def main():
             torch.cuda.empty_cache()
             sys.path.insert(0, str(ROOT / "tools"))
             from bench_predict import ensemble_bench
-            inf = {"workload": "7-fold ensemble, one 300-frame trial at 64x64, window 16 step 2, 32 windows per forward, all "
-                               "folds in one captured hipGraph per window batch, blend on the device",
+            inf = {"workload": "7-fold ensemble, one 300-frame trial at 64x64, window 16 step 2 (270 windows), 90 windows per "
+                               "forward (three exact batches; the reference runs one window per forward, predictors.py:46-54 — "
+                               "the batch size does not change the result), all folds in one captured hipGraph per window batch, "
+                               "blend on the device",
                    "hbm_frac_is": "bytes the eval-mode pass structure executes (tools/bench_predict.py::eval_executed_bytes) "
                                   "/ time / 8 TB/s"}
             for dt_ in ("bf16", "fp32"):
-                inf[dt_] = ensemble_bench(dtype=dt_, device=dev)
+                inf[dt_] = ensemble_bench(dtype=dt_, device=dev, windows=90)
             ptraf = ROOT / "profiles" / "r3_predict_pmc.json"
             if ptraf.exists():
                 try:

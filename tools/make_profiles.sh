@@ -17,8 +17,8 @@ python3 tools/pmc_traffic.py $out/pmc_f $out/pmc_w $out/${tag}_pmc_traffic.json 
 python3 tools/per_block.py $out/trace/t_kernel_trace.csv $out/pmc_f $out/pmc_w $out/${tag}_per_block.json $out/${tag}_dws_per_block.json > $out/per_block.txt 2>&1
 # inference leg (BASELINE.json configs[4]): PMC traffic of one 7-fold trial, bf16 and fp32
 for dt in bf16 fp32; do
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/ppmc_f_$dt -o p -- python3 tools/bench_predict.py --pmc-trial --dtype $dt > $out/ppmc_f_$dt.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/ppmc_w_$dt -o p -- python3 tools/bench_predict.py --pmc-trial --dtype $dt > $out/ppmc_w_$dt.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/ppmc_f_$dt -o p -- python3 tools/bench_predict.py --pmc-trial --windows 90 --dtype $dt > $out/ppmc_f_$dt.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/ppmc_w_$dt -o p -- python3 tools/bench_predict.py --pmc-trial --windows 90 --dtype $dt > $out/ppmc_w_$dt.log 2>&1
 done
 python3 tools/predict_pmc.py bf16 $out/ppmc_f_bf16 $out/ppmc_w_bf16 fp32 $out/ppmc_f_fp32 $out/ppmc_w_fp32 $out/${tag}_predict_pmc.json > $out/predict_pmc.txt 2>&1
 cp $out/${tag}_predict_pmc.json profiles/${tag}_predict_pmc.json
