@@ -1170,6 +1170,79 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_fast_kernel(const float* poole
     }
 }
 
+// Round-3 forward: the squeeze layer by ROWS.  Wave w owns hidden units w, w+4, ... (RP/4 of them, all unrolled) and walks
+// the channels with 16-byte loads (lane -> 4 consecutive channels, 256 channels per wave step): a quarter of the load
+// instructions of the thread-per-channel form above, every one of them independent, one xor-shuffle sum per owned unit and NO
+// LDS atomics (a hidden unit has exactly one owner wave — nothing to order in the deterministic build either).
+// Requires C % 4 == 0 (16-byte rows of `wr`).
+template <int RP>
+__global__ __launch_bounds__(256) void se_mlp_fwd_rows_kernel(const float* pooled_sum, float inv_s, const float* wr,
+                                                              const float* br, const float* we, const float* be, int C,
+                                                              int R, float* pmean, float* hid_pre, float* gate) {
+    constexpr int RPW = RP / 4;
+    __shared__ float hid[RP];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = gridDim.y, part = blockIdx.y;
+    const int C4 = C >> 2;                                  // float4 per row
+    float acc[RPW];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) acc[q] = 0.f;
+    const float4* ps4 = reinterpret_cast<const float4*>(pooled_sum + (i64)b * C);
+    float4* pm4 = reinterpret_cast<float4*>(pmean + (i64)b * C);
+    for (int c4 = lane; c4 < C4; c4 += 64) {
+        float4 v = ps4[c4];
+        v.x *= inv_s; v.y *= inv_s; v.z *= inv_s; v.w *= inv_s;
+        if (part == 0 && wave == 0) pm4[c4] = v;
+        float4 w[RPW];
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int r = wave + 4 * q;
+            w[q] = reinterpret_cast<const float4*>(wr + (i64)(r < R ? r : R - 1) * C)[c4];
+        }
+#pragma unroll
+        for (int q = 0; q < RPW; ++q)
+            acc[q] = fmaf(w[q].x, v.x, fmaf(w[q].y, v.y, fmaf(w[q].z, v.z, fmaf(w[q].w, v.w, acc[q]))));
+    }
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const float t = wave_sum(acc[q]);
+        const int r = wave + 4 * q;
+        if (lane == 0 && r < R) {
+            const float h = t + br[r];
+            if (part == 0) hid_pre[(i64)b * R + r] = h;
+            hid[r] = siluf_(h);
+        }
+    }
+    __syncthreads();
+    const int per = (C + split - 1) / split;
+    const int c_end = (part + 1) * per < C ? (part + 1) * per : C;
+    for (int c = part * per + tid; c < c_end; c += 256) {
+        float a = be[c];
+        const float* wrow = we + (i64)c * R;
+#pragma unroll 1
+        for (int r0 = 0; r0 < RP; r0 += 16) {
+            if (r0 >= R) break;
+            float wv[16];
+            if ((R & 3) == 0) {
+                const float4* w4 = reinterpret_cast<const float4*>(wrow);
+                const int nq = R >> 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int qi = (r0 >> 2) + q;
+                    const float4 t = w4[qi < nq ? qi : nq - 1];
+                    wv[4 * q] = t.x; wv[4 * q + 1] = t.y; wv[4 * q + 2] = t.z; wv[4 * q + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) wv[r] = wrow[r0 + r < R ? r0 + r : R - 1];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a = fmaf(wv[r], r0 + r < R ? hid[r0 + r] : 0.f, a);
+        }
+        gate[(i64)b * C + c] = sigmoidf_(a);
+    }
+}
+
 template <int RP>
 __global__ __launch_bounds__(256) void se_mlp_bwd_fast_kernel(const float* dg, const float* gate, const float* hid_pre,
                                                               const float* wr, const float* we, int C, int R,
@@ -1238,6 +1311,108 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_fast_kernel(const float* dg, c
     }
 }
 
+// Folding wave reduction: every lane holds N partial sums (N a power of two <= 64); afterwards lane l holds the wave total
+// of value l % N.  At distance d a lane keeps the half of its live values whose index bit matches its own lane bit and
+// adds the partner's copy of them: N - 1 + (plain steps) shuffles instead of 6 N for N separate butterfly sums.
+template <int N, int LIVE, int D> struct WaveFold {
+    static __device__ __forceinline__ void run(float (&v)[N], int lane) {
+        if constexpr (D > 0) {
+            if constexpr (LIVE > D) {
+                constexpr int H = LIVE / 2;
+                const bool up = (lane & D) != 0;
+#pragma unroll
+                for (int i = 0; i < H; ++i) {
+                    const float send = up ? v[i] : v[i + H];
+                    const float keep = up ? v[i + H] : v[i];
+                    v[i] = keep + __shfl_xor(send, D);
+                }
+                WaveFold<N, H, D / 2>::run(v, lane);
+            } else {
+#pragma unroll
+                for (int i = 0; i < LIVE; ++i) v[i] += __shfl_xor(v[i], D);
+                WaveFold<N, LIVE, D / 2>::run(v, lane);
+            }
+        }
+    }
+};
+template <int N>
+__device__ __forceinline__ float wave_fold(float (&v)[N], int lane) {
+    WaveFold<N, N, 32>::run(v, lane);
+    return v[0];
+}
+
+// Round-3 backward data path: all RP partial sums of the excite layer's transpose product in one pass (16-/8-byte loads of the
+// `we` rows), one folding reduction per wave, the four wave totals combined through LDS slots — no LDS atomics (nothing to
+// order in the deterministic build).  Requires R even.
+template <int RP, int VW>
+__global__ __launch_bounds__(256) void se_mlp_bwd_fold_kernel(const float* dg, const float* gate, const float* hid_pre,
+                                                              const float* wr, const float* we, int C, int R,
+                                                              float inv_s, float* dgp_out, float* dhp_out, float* dps) {
+    __shared__ float part4[4][RP];
+    __shared__ float dhp[RP];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = gridDim.y, part = blockIdx.y;
+    float acc[RP];
+#pragma unroll
+    for (int r = 0; r < RP; ++r) acc[r] = 0.f;
+    for (int c = tid; c < C; c += 256) {
+        const float g = gate[(i64)b * C + c];
+        const float v = dg[(i64)b * C + c] * g * (1.f - g);
+        if (part == 0) dgp_out[(i64)b * C + c] = v;
+        const float* wrow = we + (i64)c * R;
+        if constexpr (VW == 4) {
+            const float4* w4 = reinterpret_cast<const float4*>(wrow);
+            const int nq = R >> 2;
+            float4 t[RP / 4];
+#pragma unroll
+            for (int q = 0; q < RP / 4; ++q) t[q] = w4[q < nq ? q : nq - 1];
+#pragma unroll
+            for (int q = 0; q < RP / 4; ++q) {
+                acc[4 * q] = fmaf(t[q].x, v, acc[4 * q]); acc[4 * q + 1] = fmaf(t[q].y, v, acc[4 * q + 1]);
+                acc[4 * q + 2] = fmaf(t[q].z, v, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(t[q].w, v, acc[4 * q + 3]);
+            }
+        } else {
+            const float2* w2 = reinterpret_cast<const float2*>(wrow);
+            const int nq = R >> 1;
+            float2 t[RP / 2];
+#pragma unroll
+            for (int q = 0; q < RP / 2; ++q) t[q] = w2[q < nq ? q : nq - 1];
+#pragma unroll
+            for (int q = 0; q < RP / 2; ++q) {
+                acc[2 * q] = fmaf(t[q].x, v, acc[2 * q]); acc[2 * q + 1] = fmaf(t[q].y, v, acc[2 * q + 1]);
+            }
+        }
+    }
+    const float tot = wave_fold<RP>(acc, lane);              // lane l: this wave's total of unit l % RP (units >= R: ignored)
+    if (lane < RP) part4[wave][lane] = tot;
+    __syncthreads();
+    if (tid < RP) {
+        const float sum = (part4[0][tid] + part4[1][tid]) + (part4[2][tid] + part4[3][tid]);
+        float v = 0.f;
+        if (tid < R) {
+            v = sum * silu_gradf_(hid_pre[(i64)b * R + tid]);
+            if (part == 0) dhp_out[(i64)b * R + tid] = v;
+        }
+        dhp[tid] = v;
+    }
+    __syncthreads();
+    const int per = (C + split - 1) / split;
+    const int c_end = (part + 1) * per < C ? (part + 1) * per : C;
+    for (int c = part * per + tid; c < c_end; c += 256) {
+        float a = 0.f;
+#pragma unroll 1
+        for (int r0 = 0; r0 < RP; r0 += 16) {
+            if (r0 >= R) break;
+            float wv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wv[r] = wr[(i64)(r0 + r < R ? r0 + r : R - 1) * C + c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a = fmaf(wv[r], r0 + r < R ? dhp[r0 + r] : 0.f, a);
+        }
+        dps[(i64)b * C + c] = a * inv_s;
+    }
+}
+
 // parameter grads of the SE MLP.  grid.x = ceil(C/256), grid.y = R: thread (c, r) reduces over the batch.
 __global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const float* dgp, const float* dhp, const float* pmean,
                                                            const float* hid_pre, int B, int C, int R, float* dwr,
@@ -1266,6 +1441,21 @@ __global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const float* dgp, con
 
 int k_se_mlp_fwd(const float* pooled_sum, float inv_s, const float* wr, const float* br, const float* we,
                  const float* be, int B, int C, int R, float* pmean, float* hid_pre, float* gate, hipStream_t s) {
+    const char* v2 = getenv("DWN_SE_ROWS");                  // "0": the thread-per-channel kernels (A/B)
+    if (!(v2 && v2[0] == '0') && (C & 3) == 0 && R <= SE_RT &&
+        !(((size_t)pooled_sum | (size_t)wr | (size_t)pmean) & 15)) {
+        if (R <= 16)
+            hipLaunchKernelGGL(se_mlp_fwd_rows_kernel<16>, dim3(B, 8), dim3(256), 0, s, pooled_sum, inv_s, wr, br, we, be, C, R,
+                               pmean, hid_pre, gate);
+        else if (R <= 32)
+            hipLaunchKernelGGL(se_mlp_fwd_rows_kernel<32>, dim3(B, 8), dim3(256), 0, s, pooled_sum, inv_s, wr, br, we, be, C, R,
+                               pmean, hid_pre, gate);
+        else
+            hipLaunchKernelGGL(se_mlp_fwd_rows_kernel<SE_RT>, dim3(B, 8), dim3(256), 0, s, pooled_sum, inv_s, wr, br, we, be, C,
+                               R, pmean, hid_pre, gate);
+        DWN_CHECK_LAUNCH();
+        return 0;
+    }
     if (R <= 16)
         hipLaunchKernelGGL(se_mlp_fwd_fast_kernel<16>, dim3(B, 8), dim3(256), 0, s, pooled_sum, inv_s, wr, br, we, be, C, R,
                            pmean, hid_pre, gate);
@@ -1284,6 +1474,21 @@ int k_se_mlp_fwd(const float* pooled_sum, float inv_s, const float* wr, const fl
 int k_se_mlp_bwd(const float* dg, const float* gate, const float* hid_pre, const float* pmean, const float* wr,
                  const float* we, int B, int C, int R, float inv_s, float* dgp, float* dhp, float* dps, float* dwr,
                  float* dbr, float* dwe, float* dbe, hipStream_t s) {
+    const char* v2 = getenv("DWN_SE_ROWS");                  // "0": the thread-per-channel kernels with LDS atomics (A/B)
+    if (!(v2 && v2[0] == '0') && (R & 1) == 0 && R <= SE_RT && !((size_t)we & 15)) {
+#define SE_BWD_FOLD(RP_) do { \
+        if ((R & 3) == 0) hipLaunchKernelGGL((se_mlp_bwd_fold_kernel<RP_, 4>), dim3(B, 8), dim3(256), 0, s, dg, gate, hid_pre, wr, we, C, R, inv_s, dgp, dhp, dps); \
+        else hipLaunchKernelGGL((se_mlp_bwd_fold_kernel<RP_, 2>), dim3(B, 8), dim3(256), 0, s, dg, gate, hid_pre, wr, we, C, R, inv_s, dgp, dhp, dps); } while (0)
+        if (R <= 16) SE_BWD_FOLD(16);
+        else if (R <= 32) SE_BWD_FOLD(32);
+        else SE_BWD_FOLD(SE_RT);
+#undef SE_BWD_FOLD
+        DWN_CHECK_LAUNCH();
+        hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 255) / 256, R), dim3(256), 0, s, dgp, dhp, pmean, hid_pre, B, C, R,
+                           dwr, dbr, dwe, dbe);
+        DWN_CHECK_LAUNCH();
+        return 0;
+    }
     if (R <= 16)
         hipLaunchKernelGGL(se_mlp_bwd_fast_kernel<16>, dim3(B, 8), dim3(256), 0, s, dg, gate, hid_pre, wr, we, C, R, inv_s, dgp,
                            dhp, dps);
