@@ -3,7 +3,8 @@
   * forward / loss / gradient-norm errors of the bf16 run against the reference's digest (tests/golden/full_width_digest.npz),
   * per-parameter gradient cosine similarity bf16 vs fp32 (worst per block) and run-to-run gradient noise of each mode,
   * a 30-step training trajectory (AdamW + EMA, seeded synthetic batch) in both modes: loss curves, prediction correlation.
-Writes profiles/r2_bf16_parity.json; tests/test_gpu_bf16_depth.py asserts bounds derived from these measurements."""
+Writes profiles/r2_bf16_parity.json; tests/test_gpu_bf16_depth.py asserts bounds derived from these measurements.
+Lives under tests/ because it drives the CPU oracle (test infrastructure): run as `python tests/bf16_parity_report.py` on a GPU box."""
 import json
 import math
 import sys

@@ -1,6 +1,6 @@
 """bf16 storage (the benchmarked dtype) at FULL width and depth — expansion 7, nine blocks, 7863 neurons — against the
 reference's digest and against the fp32 HIP path (which is pinned to the reference at 1e-3).  Bounds are ~3x the errors
-measured by tools/bf16_parity.py (profiles/r2_bf16_parity.json): loss 5e-5, gradient norm 2e-3, worst gradient cosine 0.983,
+measured by tests/bf16_parity_report.py (profiles/r2_bf16_parity.json): loss 5e-5, gradient norm 2e-3, worst gradient cosine 0.983,
 30-step loss gap 6e-4 of the loss drop, |corr difference| 4e-4."""
 import math
 
@@ -69,7 +69,7 @@ def test_bf16_full_width_digest_and_gradient_directions(golden_dir):
 @pytest.mark.parametrize("bf16,bound", [(False, 1e-4), (True, 0.25)])
 def test_run_to_run_gradient_noise_is_bounded(bf16, bound):
     """The weight gradients are accumulated with fp32 atomics (order varies run to run): the noise on every gradient that is
-    not analytically zero stays below `bound` of its norm (measured by tools/bf16_parity.py: fp32 1.1e-5; bf16 8e-2, on the
+    not analytically zero stays below `bound` of its norm (measured by tests/bf16_parity_report.py: fp32 1.1e-5; bf16 8e-2, on the
     tiny SE-bias gradients — the large weight gradients are two orders of magnitude quieter)."""
     model = _model()
     x, t, w, _ = _batch()
