@@ -199,7 +199,10 @@ class MouseModel(Model):
             self.buckets.gather_params()          # awaited by the readouts' forward pre-hook: hidden behind the next core forward
         if self.model_ema is not None:
             # the fused AdamW kernel has already lerped the parameter copies iff it is bound to THIS ModelEma
-            self.model_ema.update(self.nn_module, skip_parameters=self.optimizer.folds_ema_of(self.model_ema))
+            folded = self.optimizer.folds_ema_of(self.model_ema)
+            if not folded and self.buckets is not None and self.buckets.shard:
+                self.buckets.wait_params()        # the lerp below reads every parameter: the all-gather must have landed
+            self.model_ema.update(self.nn_module, skip_parameters=folded)
         return {"prediction": self.prediction_transform(deep_detach(prediction)), "target": deep_detach(target),
                 "loss": loss_value}
 
