@@ -77,7 +77,10 @@ typedef struct dwn_gemm_nn_args {
     void* c; long long ldc;
     int M, N, K;
     int groups;
-    double* stats; int stat_rep_stride_unused; int stat_nchan;
+    double* stats;
+    int f32_split;      /* dtype f32 only: nonzero = products as bf16 hi/lo splits on the bf16 matrix cores (hi*hi + hi*lo + lo*hi, fp32
+                         * accumulate; ~1e-5 relative) instead of the fp32 MFMA — the eval-mode forward sets it, training does not */
+    int stat_nchan;
     int epi;
     const float* bias; float sp_beta; float* out_nct; int Tn; int n_valid;
     /* DWN_EPI_DG: y3 = the activated project-conv input z3 = SiLU(BN3(y3)) [M][N] (materialised by the forward);

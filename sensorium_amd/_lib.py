@@ -49,7 +49,7 @@ class LoadDesc(C.Structure):
 class GemmNNArgs(C.Structure):
     _fields_ = [("a", LoadDesc), ("a_kind", c_i), ("b", c_p), ("ldb", c_ll), ("c", c_p), ("ldc", c_ll),
                 ("M", c_i), ("N", c_i), ("K", c_i), ("groups", c_i), ("stats", c_p),
-                ("stat_rep_stride_unused", c_i), ("stat_nchan", c_i), ("epi", c_i), ("bias", c_p),
+                ("f32_split", c_i), ("stat_nchan", c_i), ("epi", c_i), ("bias", c_p),
                 ("sp_beta", c_f), ("out_nct", c_p), ("Tn", c_i), ("n_valid", c_i), ("y3", c_p), ("ldy3", c_ll),
                 ("s3", c_p), ("t3", c_p), ("dg", c_p), ("dg_ld", c_i), ("rows_per_sample", c_i),
                 ("a2", c_p), ("a2_ld", c_ll), ("K1", c_i), ("b_sample_stride", c_ll), ("b_rows_per_sample", c_i),

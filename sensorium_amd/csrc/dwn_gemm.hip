@@ -23,6 +23,14 @@
 #ifndef NN_DMA_NST
 #define NN_DMA_NST 3                 // stages of the LDS-DMA ring of gemm_nn_kernel<..., 3>
 #endif
+// fp32 products of gemm_nn on the bf16 matrix cores: every operand element is split into hi = bf16(x) and lo = bf16(x - hi) when
+// it is staged into LDS, and a product is hi*hi + hi*lo + lo*hi accumulated in fp32 (three v_mfma_f32_16x16x32_bf16 per 32-deep
+// k-tile and 16x16 block instead of eight v_mfma_f32_16x16x4_f32: a sixth of the matrix-core time; the dropped lo*lo term and the
+// 16-17 significant bits of hi + lo leave a relative error of ~1e-5 per product, far inside the 1e-3 bar of the fp32 path).
+// 0 = the native fp32 MFMA.
+#ifndef NN_F32_X3
+#define NN_F32_X3 1
+#endif
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -70,6 +78,18 @@ static __device__ __forceinline__ void nn_lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// bf16x3 staging of four fp32 k-values (16-byte chunk kc of a 32-deep tile row): hi halves to logical chunk kc/2 (bytes 8*(kc&1)..),
+// lo halves to logical chunk 4 + kc/2; logical chunks are XOR-swizzled with the row like the plain layout
+__device__ __forceinline__ void x3_store(unsigned char* rowp, int row, int kc, const uint4& v) {
+    const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
+    const unsigned h01 = pk_bf16(f0, f1), h23 = pk_bf16(f2, f3);
+    const float r0 = f0 - __uint_as_float(h01 << 16), r1 = f1 - __uint_as_float(h01 & 0xffff0000u);
+    const float r2 = f2 - __uint_as_float(h23 << 16), r3 = f3 - __uint_as_float(h23 & 0xffff0000u);
+    const int ch = kc >> 1, off = (kc & 1) * 8;
+    *reinterpret_cast<uint2*>(rowp + ((ch ^ (row & 7)) << 4) + off) = make_uint2(h01, h23);
+    *reinterpret_cast<uint2*>(rowp + (((4 + ch) ^ (row & 7)) << 4) + off) = make_uint2(pk_bf16(r0, r1), pk_bf16(r2, r3));
+}
+
 // ------------------------------------------------------------------------------------------------
 // NN — persistent: a workgroup owns one N-tile and a contiguous range of M-tiles.
 //   * K <= one k-tile (the point-wise expand convs, K = 64 bf16): the weight tile is loaded once and stays
@@ -82,12 +102,13 @@ static __device__ __forceinline__ void nn_lds_barrier() {
 //     flushed once per workgroup — per-tile global atomics on the same few hundred addresses serialise at
 //     the memory side (MI355X_MICROARCH.md § Global float atomics, "contention").
 // ------------------------------------------------------------------------------------------------
-template <typename T, int ALD, int EPI, int BN, int SINGLE>
+template <typename T, int ALD, int EPI, int BN, int SINGLE, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     constexpr int KC = TT<T>::KC;
     constexpr int BM = 128;
     constexpr int ROWB = 128;                          // bytes per tile row per k-step
     constexpr int BK = ROWB / (int)sizeof(T);          // 64 bf16 / 32 f32
+    constexpr bool X3 = !TT<T>::IS_BF16 && SPLIT;
     constexpr int NJ = BN / 32;                        // 16-column sub-tiles per wave (2x2 waves)
     constexpr int A_CH = BM * 8 / 256;
     constexpr int B_CH = BN * 8 / 256;
@@ -250,7 +271,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                 if constexpr (decltype(cf)::two_tensors) v = ok ? cf.apply(g.a, (unsigned)m, rp[kt * A_CH + i], rq[kt * A_CH + i]) : make_uint4(0, 0, 0, 0);
                 else v = ok ? cf.apply(g.a, (unsigned)m, rp[kt * A_CH + i], make_uint4(0, 0, 0, 0)) : make_uint4(0, 0, 0, 0);
             }
-            *reinterpret_cast<uint4*>(sA + kt * (BM * ROWB) + row * ROWB + ((kc ^ (row & 7)) << 4)) = v;
+            if constexpr (X3) x3_store(sA + kt * (BM * ROWB) + row * ROWB, row, kc, v);
+            else *reinterpret_cast<uint4*>(sA + kt * (BM * ROWB) + row * ROWB + ((kc ^ (row & 7)) << 4)) = v;
         }
         }
     };
@@ -262,7 +284,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                 int c = tid + 256 * i;
                 int row = c >> 3, kc = c & 7;
                 const bool ok = (n0 + row) < g.N && (ldb_k0 + kt * BK + kc * KC) < g.K;
-                *reinterpret_cast<uint4*>(sB + kt * (BN * ROWB) + row * ROWB + ((kc ^ (row & 7)) << 4)) =
+                if constexpr (X3) x3_store(sB + kt * (BN * ROWB) + row * ROWB, row, kc, ok ? rb[kt * B_CH + i] : make_uint4(0, 0, 0, 0));
+                else *reinterpret_cast<uint4*>(sB + kt * (BN * ROWB) + row * ROWB + ((kc ^ (row & 7)) << 4)) =
                     ok ? rb[kt * B_CH + i] : make_uint4(0, 0, 0, 0);
             }
     };
@@ -273,6 +296,37 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     f32x4_t acc[4][NJ];
 
     auto mma_tile = [&](const int stage_off = 0) {
+        if constexpr (X3) {
+            // one 32-deep k-tile per NKT: hi fragments in 16-byte chunks 0-3 of a row (8 consecutive k each), lo in chunks 4-7
+#pragma unroll
+            for (int kb = 0; kb < NKT; ++kb) {
+                uint4 ah[4], al[4], bh[NJ], bl[NJ];
+                const unsigned char* tA = sA + stage_off + kb * (BM * ROWB);
+                const unsigned char* tB = sB + stage_off + kb * (BN * ROWB);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = wm * 64 + i * 16 + lr;
+                    ah[i] = *reinterpret_cast<const uint4*>(tA + row * ROWB + ((lg ^ (row & 7)) << 4));
+                    al[i] = *reinterpret_cast<const uint4*>(tA + row * ROWB + (((4 + lg) ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int row = wn * (BN / 2) + j * 16 + lr;
+                    bh[j] = *reinterpret_cast<const uint4*>(tB + row * ROWB + ((lg ^ (row & 7)) << 4));
+                    bl[j] = *reinterpret_cast<const uint4*>(tB + row * ROWB + (((4 + lg) ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        // small terms first
+                        Mma<bf16_t>::run(bl[j], ah[i], acc[i][j]);
+                        Mma<bf16_t>::run(bh[j], al[i], acc[i][j]);
+                        Mma<bf16_t>::run(bh[j], ah[i], acc[i][j]);
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int kb = 0; kb < 2 * NKT; ++kb) {
             uint4 af[4], bfr[NJ];
@@ -719,6 +773,17 @@ static int launch_nn_k(const GemmNN& g, hipStream_t s) {
     while (nranges > 1 && (nranges * ntn) % 8 != 0) --nranges;
     if ((nranges * ntn) % 8 != 0) nranges = 8;
     dim3 grid(nranges * ntn, g.groups);
+    if constexpr (!TT<T>::IS_BF16 && NN_F32_X3 != 0) {
+        // fp32 products on the bf16 matrix cores (see NN_F32_X3): asked for per call (the eval-mode forward does), DWN_F32_SPLIT=0 never,
+        // =2 always (A/B)
+        const char* e = getenv("DWN_F32_SPLIT");
+        const bool split = e ? (e[0] == '2' || (e[0] != '0' && g.f32_split)) : g.f32_split != 0;
+        if (split) {
+            hipLaunchKernelGGL((gemm_nn_kernel<T, ALD, EPI, BNv, SINGLE, true>), grid, dim3(256), 0, s, g);
+            DWN_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((gemm_nn_kernel<T, ALD, EPI, BNv, SINGLE>), grid, dim3(256), 0, s, g);
     DWN_CHECK_LAUNCH();
     return 0;

@@ -46,8 +46,8 @@ def test_tiny_model_eval_matches_reference(golden_dir, dtype):
         assert preds[m].shape == z[f"pred_{m}"].shape and preds[m].dtype == torch.float32
         e = rel(preds[m], torch.from_numpy(z[f"pred_{m}"]))
         assert e < (1e-3 if dtype == torch.float32 else 3e-2), (m, e)
-    # two launches differ in the last bits (fp32 atomics in the SE pooling sums): same value to rounding
-    assert rel(p1, preds[1]) < 1e-6
+    # two launches differ in the last bits (fp32 atomics in the SE pooling sums): same value to rounding (0.3-1.1e-6 observed)
+    assert rel(p1, preds[1]) < 5e-6
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
