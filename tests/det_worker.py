@@ -75,5 +75,41 @@ def run(kind: str):
           f"differing={differing} max_rel={worst:.3e} worst={worst_name}", flush=True)
 
 
+def run_predict():
+    """Sliding-window prediction of one trial by a two-model ensemble (src/predictors.py:36-55), twice: bit-identical?"""
+    from sensorium_amd import _lib as L
+    from sensorium_amd.argus_models import MouseModel
+    from sensorium_amd.predictors import EnsemblePredictor
+    kw = dict(readout_outputs=(96,), in_channels=5, core_features=(64, 64, 128), spatial_strides=(2, 1, 2), spatial_kernel=3,
+              temporal_kernel=5, expansion_ratio=7, se_reduce_ratio=32, cortex_features=(256, 512), groups=2, softplus_beta=0.07,
+              drop_rate=0.0, drop_path_rate=0.0)
+    outs = []
+    for bf16 in (True, False):
+        models = []
+        for k in range(2):
+            torch.manual_seed(50 + k)
+            m = MouseModel({"nn_module": ("dwiseneuro", kw), "loss": ("mice_poisson", {}), "optimizer": ("AdamW", {"lr": 1e-3}),
+                            "device": "cuda:0", "amp": False, "iter_size": 1})
+            if bf16:
+                m.nn_module.compute_dtype = torch.bfloat16
+            models.append(m)
+        g = torch.Generator().manual_seed(1)
+        inputs = torch.zeros(5, 48, 64, 64)
+        inputs[0] = torch.randint(0, 256, (48, 64, 64), generator=g).float()
+        inputs[1:] = torch.rand(4, 48, 1, 1, generator=g) * 50
+        ens = EnsemblePredictor(models, frame_stack_size=16, frame_stack_step=2, windows_per_batch=6, use_graph=False)
+        outs.append([torch.from_numpy(ens.predict_trial(inputs, 0)) for _ in range(2)])
+    differing = sum(int(not torch.equal(a, b)) for a, b in outs)
+    worst = max(float((a - b).abs().max() / (a.abs().max() + 1e-30)) for a, b in outs)
+    finite = all(bool(torch.isfinite(a).all()) for a, _ in outs)
+    print(f"DET_STEP0 max_rel_l2={worst:.3e}", flush=True)
+    print(f"DET_WORKER deterministic={int(L.DETERMINISTIC)} lib={L.LIB_PATH.name} tensors={len(outs)} identical={int(differing == 0 and finite)} "
+          f"differing={differing} max_rel={worst:.3e} worst=prediction", flush=True)
+
+
 if __name__ == "__main__":
-    run(sys.argv[1] if len(sys.argv) > 1 else "tiny")
+    kind = sys.argv[1] if len(sys.argv) > 1 else "tiny"
+    if kind == "predict":
+        run_predict()
+    else:
+        run(kind)

@@ -36,6 +36,14 @@ def test_deterministic_build_repeats_training_steps_bit_for_bit(kind):
     assert r["identical"] == 1, f"{r['differing']} of {r['tensors']} tensors differ between two runs (worst {r['worst']}: {r['max_rel']:.2e})"
 
 
+def test_deterministic_build_repeats_ensemble_predictions_bit_for_bit():
+    """Inference (src/predictors.py:36-55 through EnsemblePredictor, eval-mode kernels: the y1-rebuilding stencil, fused
+    temporal pass off in this build, fp32 split products): two predictions of one trial, bf16 and fp32, identical."""
+    r = _run("predict", True)
+    assert r["det"] == 1 and r["tensors"] == 2
+    assert r["identical"] == 1, f"{r['differing']} of 2 predictions differ between two runs ({r['max_rel']:.2e})"
+
+
 @pytest.mark.parametrize("kind,bound", [("metric_f32", 1e-4), ("metric", 0.2)])
 def test_normal_build_run_to_run_noise_is_small(kind, bound):
     """Not bit-identical by design (float atomics add in arrival order).  First-step predictions / loss / gradients, relative
