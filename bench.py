@@ -257,6 +257,8 @@ def main():
                     "on xGMI, fp32 master buckets)")
     ap.add_argument("--ddp-shard", action="store_true", help="readout buckets: reduce-scatter -> AdamW/EMA on the owned 1/N slice "
                     "-> all-gather of the parameters (hidden behind the next core forward) instead of all-reduce + full optimizer")
+    ap.add_argument("--arena-gb", type=float, default=0.0, help="reserve ONE device segment of this size before the first step (allocated "
+                    "and handed straight back to torch's caching allocator, which then carves every activation out of it)")
     ap.add_argument("--dry-run", action="store_true", help="testing only: launcher + rendezvous + timing plumbing, no GPU work")
     args = ap.parse_args()
 
@@ -325,6 +327,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.arena_gb > 0:
+        arena = torch.empty(int(args.arena_gb * (1 << 30)), dtype=torch.uint8, device=dev)
+        del arena
     for _ in range(args.warmup):
         model.train_step(next_batch(), sync_loss=False)
     fam_names = L.FAMILIES

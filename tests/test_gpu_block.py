@@ -60,6 +60,14 @@ CASES = [
     (64, 64, 2, 7, 32, 2, 3, 9, 16),
     # a plane too wide for either register geometry of the y1-rebuilding eval stencil (LDS fits): eval must fall back
     (64, 64, 1, 7, 32, 1, 2, 4, 130),
+    # the 256-channel blocks (7 and 8 of the benchmarked model: Cin = 256, E = 1792).  The small pair checks the arithmetic at that
+    # width; the large pair has the row counts / rows-per-sample at which the library takes the paths only those blocks run
+    # (T*Hout*Wout = 1280 < 2048: bf16 conv_pwl backward through the materialised du + bn3_bwd_reduce; M_in >= 8192:
+    # gemm_nn_xl for conv_pw; the K-concatenated conv_pw data gradient at K = 1792 + 256)
+    (256, 256, 2, 7, 32, 1, 2, 9, 16),
+    (256, 256, 1, 7, 32, 2, 2, 5, 8),
+    (256, 256, 2, 7, 32, 2, 32, 9, 16),
+    (256, 256, 1, 7, 32, 7, 32, 5, 8),
 ]
 
 
@@ -131,7 +139,7 @@ def test_block_train_forward_backward(case, dtype, drop):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case_id", [1, 3, 4, 9, 10, 12, 14])
+@pytest.mark.parametrize("case_id", [1, 3, 4, 9, 10, 12, 14, 15, 16, 17, 18])
 def test_block_eval_forward(dtype, case_id):
     """Eval-mode forward.  The cases with 64 / 128 input channels take, in bf16, the y1-recomputing stencil
     (dwn_dw_spatial_fwd_rc: conv_pw never runs as its own pass) — except case 14, whose 130-pixel rows fit neither register

@@ -1,0 +1,154 @@
+"""Full-width parity against digests of the REAL reference (oracle/make_golden_fullwidth.py):
+
+* the reference training shape R of configs/true_batch_001.py:5-8 (64x64 frame, 16 frames, expansion 7): loss, predictions,
+  the gradient norm of every parameter, BatchNorm running statistics after the step — fp32 at 1e-3 / 5e-3, bf16 with stated bounds;
+* BASELINE.json configs[4] at real width: three full-width fold models, one 46-frame 64x64 trial = 16 windows, through
+  ``EnsemblePredictor(use_graph=True)`` and through single ``Predictor``s, against the reference's own loop
+  (src/predictors.py:36-55, scripts/predict.py:44-50) — fp32 at 1e-3, bf16 with a stated bound.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dwiseneuro_oracle as orc  # noqa: E402
+from tests.gpu_helpers import analytically_zero_grad, dev, rel, synth_inputs  # noqa: E402
+
+STRIDES = (2, 1, 1, 1, 2, 1, 1, 2, 1)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_reference_training_shape_digest(golden_dir, bf16):
+    from sensorium_amd import DwiseNeuro, MicePoissonLoss
+    z = np.load(golden_dir / "r_shape_digest.npz")
+    sd = orc.make_state_dict(readout_outputs=(7863,), expansion_ratio=7, seed=13)
+    model = DwiseNeuro(readout_outputs=(7863,), expansion_ratio=7, drop_rate=0.0, drop_path_rate=0.0)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev()).train()
+    rng = np.random.default_rng(20231125)
+    x, targets, weights = synth_inputs(rng, 2, 16, 64, 64, (7863,))
+    assert float(x.astype(np.float64).sum()) == float(z["input_checksum"])          # same generator, same draws
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        preds = model(torch.from_numpy(x).to(dev()))
+        loss = MicePoissonLoss()(preds, ([torch.from_numpy(targets[0]).to(dev())], torch.from_numpy(weights).to(dev())))
+    loss.backward()
+    torch.cuda.synchronize()
+    p = preds[0].detach().float()
+    # bounds: fp32 = the north-star 1e-3 (5e-3 on gradient norms, as for the B=2, T=8 digest); bf16 storage = stated separately
+    t_loss, t_pred, t_samp, t_gtot, t_g, t_bn = (2e-4, 2e-3, 2e-2, 2e-2, 1e-1, 2e-2) if bf16 else (1e-3, 1e-3, 1e-3, 5e-3, 5e-3, 1e-3)
+    assert abs(float(loss) - float(z["loss"])) <= t_loss * abs(float(z["loss"]))
+    assert abs(float(p.mean()) - float(z["pred_mean"])) <= t_pred * abs(float(z["pred_mean"]))
+    assert abs(float(p.double().norm()) - float(z["pred_l2"])) <= t_pred * float(z["pred_l2"])
+    idx = z["sample_idx"]
+    got = p.cpu().numpy()[idx[:, 0], idx[:, 1], idx[:, 2]]
+    assert rel(torch.from_numpy(got), torch.from_numpy(z["sample_val"])) <= t_samp
+    named = dict(model.named_parameters())
+    assert list(named) == [str(k) for k in z["grad_names"]]
+    gn = np.array([float(v.grad.double().norm()) for v in named.values()])
+    tot = math.sqrt(float((gn ** 2).sum()))
+    assert abs(tot - float(z["grad_total_norm"])) <= t_gtot * float(z["grad_total_norm"])
+    for k, mine, ref in zip(named, gn, z["grad_norms"]):
+        if analytically_zero_grad(k):
+            continue                                              # summation noise on both sides
+        assert abs(mine - ref) <= t_g * ref + 1e-4 * float(z["grad_total_norm"]), (k, mine, ref)
+    after = model.state_dict()
+    for k, ref in zip(z["bn_names"], z["bn_l2"]):
+        mine = float(after[str(k)].double().norm())
+        assert abs(mine - ref) <= t_bn * ref + 1e-3 * t_bn * math.sqrt(after[str(k)].numel()), (k, mine, float(ref))
+
+
+def _trial(rng, length):
+    """oracle/make_golden_fullwidth.py::make_trial restated (that script imports the reference and cannot run here)."""
+    video = rng.integers(0, 256, size=(36, 64, length)).astype(np.uint8)
+    behavior = np.clip(rng.normal(size=(2, length)) * np.array([[10.0], [5.0]]) + np.array([[30.0], [5.0]]), 0, None).astype(np.float32)
+    pupil = (rng.normal(size=(2, length)) * 20 + np.array([[100.0], [70.0]])).astype(np.float32)
+    return video, behavior, pupil
+
+
+def _calibrated_state_dict(seed, readouts, window):
+    """Seeded weights + randomised BatchNorm affines; running statistics := the statistics of the trial's first window (one
+    train-mode pass with momentum 1) — computed by the oracle here, by the reference in the generator, which checks the two agree."""
+    sd = orc.make_state_dict(readout_outputs=readouts, expansion_ratio=7, seed=seed, randomize_bn=True)
+    keep = orc.BN_MOMENTUM
+    orc.BN_MOMENTUM = 1.0
+    try:
+        stats = {}
+        with torch.no_grad():
+            orc.forward(sd, window, strides=STRIDES, readout_outputs=readouts, index=1, training=True, new_stats=stats)
+    finally:
+        orc.BN_MOMENTUM = keep
+    sd = dict(sd)
+    sd.update({k: v.to(sd[k].dtype) for k, v in stats.items()})
+    return sd
+
+
+@pytest.fixture(scope="module")
+def fold_setup(golden_dir):
+    from sensorium_amd.inputs import get_inputs_processor
+    z = np.load(golden_dir / "full_width_ensemble.npz")
+    rng = np.random.default_rng(20231126)
+    video, behavior, pupil = _trial(rng, int(z["length"]))
+    assert int(video.astype(np.int64).sum()) == int(z["video_checksum"])
+    proc = get_inputs_processor("stack_inputs", {"size": (64, 64), "pad_fill_value": 0})
+    inputs = proc(video, behavior, pupil)
+    assert abs(float(inputs.double().norm()) - float(z["inputs_l2"])) <= 1e-6 * float(z["inputs_l2"])
+    size, step = int(z["size"]), int(z["step"])
+    window0 = inputs[:, 0:(size - 1) * step + 1:step].unsqueeze(0)
+    readouts = tuple(int(v) for v in z["readouts"])
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    sds = [_calibrated_state_dict(int(s), readouts, window0) for s in z["seeds"]]
+    return z, (video, behavior, pupil), inputs, readouts, sds, proc
+
+
+def _models(sds, readouts, amp):
+    from sensorium_amd.argus_models import MouseModel
+    models = []
+    for sd in sds:
+        params = {"nn_module": ("dwiseneuro", dict(readout_outputs=readouts, expansion_ratio=7)), "loss": ("mice_poisson", {}),
+                  "optimizer": ("AdamW", {"lr": 1e-3}), "device": "cuda:0", "amp": amp, "iter_size": 1,
+                  "inputs_processor": ("stack_inputs", {"size": (64, 64), "pad_fill_value": 0}),
+                  "frame_stack": {"size": 16, "step": 2, "position": "last"}}
+        m = MouseModel(params)
+        m.nn_module.load_state_dict(sd, strict=True)
+        models.append(m)
+    return models
+
+
+def _check(out, z, prefix, k, bound, centred):
+    ref_l2 = float(z[f"{prefix}_l2"][k] if k is not None else z[f"{prefix}_l2"])
+    ref_mean = float(z[f"{prefix}_mean"][k] if k is not None else z[f"{prefix}_mean"])
+    ref_s = z[f"{prefix}_sample"][k] if k is not None else z[f"{prefix}_sample"]
+    idx = z["sample_idx"]
+    assert abs(float(np.linalg.norm(out.astype(np.float64))) - ref_l2) <= bound * ref_l2, (prefix, k)
+    assert abs(float(out.astype(np.float64).mean()) - ref_mean) <= bound * abs(ref_mean), (prefix, k)
+    got = out[idx[:, 0], idx[:, 1]].astype(np.float64)
+    e = float(np.linalg.norm(got - ref_s) / np.linalg.norm(ref_s))
+    assert e <= bound, (prefix, k, e)
+    # the responses sit on a pedestal of softplus(0)/beta = 9.9 with a spread of ~0.5: the same error against the part that varies
+    ec = float(np.linalg.norm(got - ref_s) / np.linalg.norm(ref_s - ref_s.mean()))
+    assert ec <= centred, (prefix, k, ec)
+
+
+@pytest.mark.parametrize("amp,bound,centred", [(False, 1e-3, 5e-3), (True, 3e-2, 0.3)])
+def test_full_width_fold_ensemble_matches_reference(fold_setup, amp, bound, centred):
+    """Three full-width folds x 16 windows in one captured graph (fp32 = the reference's prediction precision,
+    src/argus_models.py:89-99; bf16 = the fast path, bound 3e-2 relative L2 on 4096 sampled elements)."""
+    from sensorium_amd.predictors import EnsemblePredictor, Predictor
+    z, (video, behavior, pupil), inputs, readouts, sds, proc = fold_setup
+    models = _models(sds, readouts, amp)
+    ens = EnsemblePredictor(models, blend_weights="ones", frame_stack_size=16, frame_stack_step=2, windows_per_batch=16, use_graph=True)
+    ens.inputs_processor = proc
+    out = ens.predict_trial(video, behavior, pupil, 1)
+    assert out.shape == (readouts[1], int(z["length"])) and np.isfinite(out).all()
+    _check(out, z, "ensemble", None, bound, centred)
+    fm = out.astype(np.float64).mean(0)
+    assert np.abs(fm - z["ensemble_frame_mean"]).max() <= bound * np.abs(z["ensemble_frame_mean"]).max()
+    nl2 = np.linalg.norm(out.astype(np.float64), axis=1)[::16]
+    assert np.abs(nl2 - z["ensemble_neuron_l2"]).max() <= 2 * bound * np.abs(z["ensemble_neuron_l2"]).max()
+    # every fold on its own (the reference's one-predictor-after-the-other order), eager and with 5 windows per forward
+    for k, m in enumerate(models):
+        one = Predictor(m, blend_weights="ones", frame_stack_size=16, frame_stack_step=2, windows_per_batch=5).predict_trial(inputs, 1)
+        _check(one, z, "per_model", k, bound, centred)
