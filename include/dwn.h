@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DWN_ABI_VERSION 3
+#define DWN_ABI_VERSION 4
 #define DWN_F32 0
 #define DWN_BF16 1
 #define DWN_NREP 32 /* replicas of every cross-workgroup statistics buffer: double[DWN_NREP][2][C] */
@@ -100,7 +100,15 @@ typedef struct dwn_gemm_nn_args {
      * `stats` is set, accumulates sum(dh3) and sum(dh3 * (y3 - coef3[2][n]) * coef3[3][n]) — the two BatchNorm-backward
      * sums.  coef3 is the [4][coef3_ld] table scale, shift, mean, invstd. */
     const float* gate3; const float* dps3; const float* coef3; int coef3_ld;
+    /* kernel variant: DWN_NN_AUTO = chosen by shape; DWN_NN_XL128 / DWN_NN_XL256 = the 256-row LDS-DMA kernel with 128- / 256-column
+     * tiles wherever its argument constraints hold (bf16, plain loader, store epilogue); DWN_NN_TILE128 = never that kernel (the
+     * tests compare the two bit for bit) */
+    int variant;
 } dwn_gemm_nn_args;
+#define DWN_NN_AUTO 0
+#define DWN_NN_XL128 1
+#define DWN_NN_XL256 2
+#define DWN_NN_TILE128 3   /* never the 256-row kernel: the 128-row persistent kernel (what the tests compare it with) */
 
 /* dW[R][Cc] += sum_m load(P)[m][r] * load(Q)[m][c]   (fp32 atomics; dW must be zeroed by the caller) */
 typedef struct dwn_gemm_tn_args {
@@ -124,7 +132,9 @@ typedef struct dwn_dw_spatial_fwd_args {
     void* out;
     int planes, Hin, Win, Hout, Wout, C, stride, ks;
     double* stats;
-    int rows_band;      /* <= 0: chosen by the library */
+    int rows_band;      /* output rows per chunk / band; <= 0: chosen by the library */
+    int impl;           /* 0: the library's choice (chained row-walk kernels where they apply); 1: the pair / generic kernels, the
+                         * second implementation the tests compare bit for bit */
 } dwn_dw_spatial_fwd_args;
 
 typedef struct dwn_dw_spatial_bwd_args {
@@ -136,6 +146,7 @@ typedef struct dwn_dw_spatial_bwd_args {
     int planes, Hin, Win, Hout, Wout, C, stride, ks;
     double* stats;
     int rows_band;
+    int impl;           /* as in dwn_dw_spatial_fwd_args */
 } dwn_dw_spatial_bwd_args;
 
 /* depth-wise (k,1,1) conv along T, pad k/2 — dwiseneuro.py:105-109 */
@@ -148,8 +159,9 @@ typedef struct dwn_dw_temporal_fwd_args {
     /* eval-mode epilogue (BatchNorm-3 coefficients are known before the pass): with z_scale != NULL the kernel stores
      * z3 = SiLU(z_scale * y3 + z_shift) instead of y3 (y3 rounded to the storage type first, as a stored y3 would read back)
      * and, with pooled != NULL, adds the per-(sample, channel) sums of the stored z3 into pooled [B][C] (zeroed by the
-     * caller) — the SqueezeExcite pooling pass (dwiseneuro.py:38-39) without a separate read of y3. */
-    const float* z_scale; const float* z_shift; float* pooled;
+     * caller) — the SqueezeExcite pooling pass (dwiseneuro.py:38-39) without a separate read of y3.  The sums are 64-bit
+     * fixed point in units of 2^-32 (sum = pooled * 2^-32): integer adds make them independent of the arrival order. */
+    const float* z_scale; const float* z_shift; long long* pooled;
 } dwn_dw_temporal_fwd_args;
 
 typedef struct dwn_dw_temporal_bwd_args {
@@ -213,12 +225,10 @@ typedef struct dwn_block_args {
     void *dy4, *da0;                         /* scratch [M_out][Cout], [M_in][Cin] */
     float *dw_pw, *dw_dws, *dw_dwt, *dw_pwl, *dse_wr, *dse_br, *dse_we, *dse_be;   /* overwritten (16-byte aligned) */
     void* ws; size_t ws_bytes;
-    /* backward: 1 = leave out the conv_pw weight gradient where it is a launch of its own (blocks whose conv_pw backward
-     * is not the fused data + weight kernel: dwn_block_pw_wgrad_deferred() says which); the caller then runs
-     * dwn_block_backward_pw_wgrad() with the SAME arguments and workspace — typically on a second stream, after an event
-     * recorded behind dwn_block_backward: nothing on the data-gradient chain waits for it (dw_pw is cleared by
-     * dwn_block_backward either way) */
-    int defer_pw_wgrad;
+    /* backward, conv_pwl: 0 = the library chooses by shape between (1) per-sample products dy4_b^T z3_b + a GEMM that
+     * recomputes du in its epilogue and (2) the materialised du = dy4 . W2 with a separate reduction pass; 1 / 2 force one
+     * (the parity tests run both implementations against the oracle) */
+    int pwl_bwd;
 } dwn_block_args;
 
 /* AdaptiveAvgPool3d((None,1,1)) — dwiseneuro.py:374,400 */
@@ -328,13 +338,9 @@ int dwn_stem_backward(const dwn_stem_args* a, int device, void* stream);
 size_t dwn_block_workspace_bytes(const dwn_block_args* a, int backward);
 int dwn_block_forward(const dwn_block_args* a, int device, void* stream);
 int dwn_block_backward(const dwn_block_args* a, int device, void* stream);
-/* 1 when dwn_block_backward(a) with a->defer_pw_wgrad = 1 would leave the conv_pw weight gradient to the call below */
-int dwn_block_pw_wgrad_deferred(const dwn_block_args* a);
 /* bit 0: dwn_block_forward writes y1; bit 1: it writes y3 (eval mode skips them where the stencil rebuilds y1 / the temporal
  * pass emits z3 directly: the caller may leave those pointers NULL) */
 int dwn_block_forward_writes(const dwn_block_args* a);
-/* dW1 += dy1^T a0 (dwiseneuro.py:91 backward) from the buffers / workspace a finished dwn_block_backward(a) left behind */
-int dwn_block_backward_pw_wgrad(const dwn_block_args* a, int device, void* stream);
 int dwn_pool_forward(const dwn_pool_args* a, int device, void* stream);
 int dwn_pool_backward(const dwn_pool_args* a, int device, void* stream);
 size_t dwn_cortex_workspace_bytes(const dwn_cortex_args* a, int backward);

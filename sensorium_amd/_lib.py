@@ -34,6 +34,7 @@ DWN_F32, DWN_BF16 = 0, 1
 DWN_NREP = 32
 LD_PLAIN, LD_PE, LD_BNACT, LD_AFFINE2, LD_DY3, LD_GATE = 0, 1, 2, 3, 4, 5
 EPI_STORE, EPI_READOUT, EPI_DG, EPI_STORE_CAT, EPI_DH3 = 0, 1, 2, 3, 4
+NN_AUTO, NN_XL128, NN_XL256, NN_TILE128 = 0, 1, 2, 3
 FAMILIES = ("pw_fwd", "dws_fwd", "dwt_fwd", "se_pool", "pwl_fwd", "resid_fwd", "resid_bwd", "pwl_dgrad", "pwl_wgrad",
             "bn3_reduce", "dwt_bwd", "dws_bwd", "pw_dgrad", "pw_wgrad", "cortex_fwd", "cortex_bwd", "readout_fwd",
             "readout_bwd")
@@ -53,7 +54,7 @@ class GemmNNArgs(C.Structure):
                 ("sp_beta", c_f), ("out_nct", c_p), ("Tn", c_i), ("n_valid", c_i), ("y3", c_p), ("ldy3", c_ll),
                 ("s3", c_p), ("t3", c_p), ("dg", c_p), ("dg_ld", c_i), ("rows_per_sample", c_i),
                 ("a2", c_p), ("a2_ld", c_ll), ("K1", c_i), ("b_sample_stride", c_ll), ("b_rows_per_sample", c_i),
-                ("gate3", c_p), ("dps3", c_p), ("coef3", c_p), ("coef3_ld", c_i)]
+                ("gate3", c_p), ("dps3", c_p), ("coef3", c_p), ("coef3_ld", c_i), ("variant", c_i)]
 
 
 class GemmTNArgs(C.Structure):
@@ -66,13 +67,13 @@ class GemmTNArgs(C.Structure):
 class DwSpatialFwdArgs(C.Structure):
     _fields_ = [("inp", LoadDesc), ("w", c_p), ("out", c_p), ("planes", c_i), ("Hin", c_i), ("Win", c_i),
                 ("Hout", c_i), ("Wout", c_i), ("C", c_i), ("stride", c_i), ("ks", c_i), ("stats", c_p),
-                ("rows_band", c_i)]
+                ("rows_band", c_i), ("impl", c_i)]
 
 
 class DwSpatialBwdArgs(C.Structure):
     _fields_ = [("dy", LoadDesc), ("y1", LoadDesc), ("w", c_p), ("dh1", c_p), ("dw", c_p), ("planes", c_i),
                 ("Hin", c_i), ("Win", c_i), ("Hout", c_i), ("Wout", c_i), ("C", c_i), ("stride", c_i),
-                ("ks", c_i), ("stats", c_p), ("rows_band", c_i)]
+                ("ks", c_i), ("stats", c_p), ("rows_band", c_i), ("impl", c_i)]
 
 
 class DwTemporalFwdArgs(C.Structure):
@@ -115,7 +116,7 @@ class BlockArgs(C.Structure):
                 ("dout", c_p), ("dx", c_p), ("buf_a", c_p), ("buf_b", c_p), ("dy4", c_p), ("da0", c_p),
                 ("dw_pw", c_p), ("dw_dws", c_p), ("dw_dwt", c_p), ("dw_pwl", c_p), ("dse_wr", c_p),
                 ("dse_br", c_p), ("dse_we", c_p), ("dse_be", c_p),
-                ("ws", c_p), ("ws_bytes", c_sz), ("defer_pw_wgrad", c_i)]
+                ("ws", c_p), ("ws_bytes", c_sz), ("pwl_bwd", c_i)]
 
 
 class PoolArgs(C.Structure):
@@ -198,9 +199,7 @@ SYMBOLS = {
     "dwn_block_workspace_bytes": (c_sz, [_P(BlockArgs), c_i]),
     "dwn_block_forward": (c_i, [_P(BlockArgs), c_i, c_p]),
     "dwn_block_backward": (c_i, [_P(BlockArgs), c_i, c_p]),
-    "dwn_block_pw_wgrad_deferred": (c_i, [_P(BlockArgs)]),
     "dwn_block_forward_writes": (c_i, [_P(BlockArgs)]),
-    "dwn_block_backward_pw_wgrad": (c_i, [_P(BlockArgs), c_i, c_p]),
     "dwn_pool_forward": (c_i, [_P(PoolArgs), c_i, c_p]),
     "dwn_pool_backward": (c_i, [_P(PoolArgs), c_i, c_p]),
     "dwn_cortex_workspace_bytes": (c_sz, [_P(CortexArgs), c_i]),
@@ -240,7 +239,7 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.dwn_abi_version() != 3:
+    if lib.dwn_abi_version() != 4:
         raise ImportError("libdwiseneuro_hip.so ABI version mismatch")
     for cname, struct in _STRUCTS.items():
         n = lib.dwn_sizeof(cname.encode())

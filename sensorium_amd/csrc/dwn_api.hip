@@ -136,7 +136,7 @@ struct BlockWs {
     void *wpw, *wpwl;            // forward: W1 [Cmid][Cin], W2 [Cout][Cmid] in T; backward: W1^T [Cin][Cmid], W2^T [Cmid][Cout]
     float *wdws, *wdwt;          // tap-major depth-wise weights
     double *st1, *st2, *st3, *st4, *stsc;
-    float* pooled;               // forward: SE pooled sums; backward: dg
+    long long* pooled;           // forward: SE pooled sums (64-bit fixed point, pool_fix); backward: the same slot holds dg (float)
     float *abc1, *abc2, *abc3, *abc4, *abcsc, *ident3;
     float *dgp, *dhp, *dps;
     void* bp; float* r3; float* gacc;                      // conv_pw data-gradient folding (see dwn_elementwise.hip)
@@ -154,14 +154,14 @@ static bool pwl_gated_weights(const dwn_block_args& a) {
 }
 // conv_pwl backward through per-sample products (k_pwl_bwd_reduce) + the recompute-du GEMM epilogue (EPI_DH3): saves
 // three passes over a [Mout][Cmid] tensor at the price of zeroing / accumulating / reading B [Cout][Cmid] fp32 matrices,
-// so it is used when those are small next to one such pass.  DWN_PWL_BWD=old|new forces a path (tests).
+// so it is used when those are small next to one such pass.  dwn_block_args.pwl_bwd = 1 | 2 forces a path (the parity
+// tests run both).
 static bool pwl_bwd_per_sample(const dwn_block_args& a) {
 #ifdef DWN_DETERMINISTIC
     return true;                 // the other path's GEMM epilogue adds to dg from several waves of a workgroup, inside its tile loop
 #endif
-    static const char* force = getenv("DWN_PWL_BWD");
-    if (force && force[0] == 'o') return false;
-    if (force && force[0] == 'n') return true;
+    if (a.pwl_bwd == 2) return false;
+    if (a.pwl_bwd == 1) return true;
     const double pb = 4.0 * a.B * a.Cout * a.Cmid * sizeof(float);
     const double pass = (double)a.B * a.T * a.Hout * a.Wout * a.Cmid * tsize(a.dtype);
     return pb <= pass;
@@ -189,7 +189,7 @@ BlockWs carve_block(const dwn_block_args& a, int backward, void* base, size_t ca
     w.st3 = c.take<double>(nstat(a.Cmid));
     w.st4 = c.take<double>(nstat(a.Cout));
     w.stsc = c.take<double>(nstat(backward ? a.Cout : a.Cin));
-    w.pooled = c.take<float>((size_t)a.B * a.Cmid);
+    w.pooled = c.take<long long>((size_t)a.B * a.Cmid);
     size_t z1 = c.off;
     if (backward) {
         w.abc1 = c.take<float>(3 * (size_t)a.Cmid);
@@ -422,10 +422,7 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     }
     if (tr) TRY(bn_finalize(w.st2, a.Cmid, (double)Mout, a.bn2, a.Cmid, tr, a.momentum, a.eps, s));
     // temp_covn_dw (:105-111)
-    // (deterministic build: the fused pass adds to the pooled sums from inside its main loop, several waves per word — the
-    // separate se_pool pass is used instead)
-    static const bool z3_off = getenv("DWN_EVAL_Z3_OFF") != nullptr DET_ONLY(|| true);
-    const bool eval_z3 = !tr && !z3_off;
+    const bool eval_z3 = !tr;       // eval: z3 and the SE pooling sums come straight from the temporal pass (integer sums: any order)
     {
         DwTemporalFwd d; memset(&d, 0, sizeof(d));
         d.in = ld_bnact(a.y2, a.Cmid, a.bn2.coef, a.Cmid, 1, nullptr, 0, 1);
@@ -482,7 +479,7 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     const int dt = a.dtype;
     const i64 Min = (i64)a.B * a.T * a.Hin * a.Win, Mout = (i64)a.B * a.T * a.Hout * a.Wout;
     const int S_out = a.T * a.Hout * a.Wout;
-    float* dg = w.pooled;
+    float* dg = reinterpret_cast<float*>(w.pooled);
     {   // one launch: zero the statistics arena, W2^T [Cmid][Cout], tap-major depth-wise weights, identity affine
         PrepArgs pa;
         bool ok = pa.zero(w.zero_beg, ((size_t)(w.zero_end - w.zero_beg) + 15) & ~(size_t)15);
@@ -558,9 +555,8 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     // temporal dw backward
     {
         DwTemporalBwd d; memset(&d, 0, sizeof(d));
-        static const bool rc_off = getenv("DWN_DWT_NORECOMP") != nullptr;
         d.dy = ld_affine2(du, a.y3, a.Cmid, w.abc3, a.Cmid);
-        d.dy_kind = rc_off ? LD_AFFINE2 : LD_PLAIN;     // LD_PLAIN: y3 is recomputed from y2 inside the kernel
+        d.dy_kind = LD_PLAIN;                           // y3 is recomputed from y2 inside the kernel (one E-wide pass less)
         d.y2 = ld_ycoef(a.y2, a.Cmid, a.bn2.coef, a.Cmid);
         d.w = w.wdwt; d.dh2 = a.buf_b; d.dw = a.dw_dwt; d.B = a.B; d.T = a.T; d.HW = a.Hout * a.Wout; d.C = a.Cmid;
         d.kt = a.kt; d.stats = w.st2;
@@ -591,7 +587,7 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
             g.epi = EPI_STORE_CAT; g.a2 = xin.p; g.a2_ld = a.Cin; g.K1 = a.Cmid; g.bias = w.r3;
             PROF(DWN_FAM_PW_DGRAD, launch_gemm_nn(g, dt, s));
         }
-        if (!a.defer_pw_wgrad) {   // weight gradient: dW1 = dy1^T a0 with the BatchNorm-backward affine applied while loading (dh1, y1)
+        {   // weight gradient: dW1 = dy1^T a0 with the BatchNorm-backward affine applied while loading (dh1, y1)
             LoadDesc dy1 = ld_affine2(dh1, a.y1, a.Cmid, w.abc1, a.Cmid);
             GemmTN g = tn_base(dy1, LD_AFFINE2, xin, LD_PLAIN, (int)Min, a.Cmid, a.Cin, a.dw_pw, a.Cin, 1);
             PROF(DWN_FAM_PW_WGRAD, launch_gemm_tn(g, dt, s));
@@ -607,31 +603,7 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
 int dwn_block_forward_writes(const dwn_block_args* ap) {
     const dwn_block_args& a = *ap;
     if (a.training) return 3;
-    static const bool z3_off = getenv("DWN_EVAL_Z3_OFF") != nullptr DET_ONLY(|| true);
-    return (block_fwd_rc(a) ? 0 : 1) | (z3_off ? 2 : 0);
-}
-
-int dwn_block_pw_wgrad_deferred(const dwn_block_args* ap) {
-    const dwn_block_args& a = *ap;
-    const i64 Min = (i64)a.B * a.T * a.Hin * a.Win;
-    return (a.defer_pw_wgrad && !dwn_pw_bwd_fused_supported(a.dtype, Min, a.Cmid, a.Cin)) ? 1 : 0;
-}
-// The conv_pw weight gradient on its own (see dwn_block_args.defer_pw_wgrad): reads dh1 (buf_a), y1, the block input and
-// the BatchNorm-1 backward coefficients dwn_block_backward left in the workspace.
-int dwn_block_backward_pw_wgrad(const dwn_block_args* ap, int device, void* stream) {
-    ENTER(device);
-    const dwn_block_args& a = *ap;
-    hipStream_t s = (hipStream_t)stream;
-    TRY(check_block(a));
-    if (!dwn_block_pw_wgrad_deferred(ap)) return dwn_set_error(-2, "block_backward_pw_wgrad: nothing was deferred for these arguments");
-    BlockWs w = carve_block(a, 1, a.ws, a.ws_bytes);
-    if (w.bytes > a.ws_bytes) return dwn_set_error(-6, "block_backward_pw_wgrad: workspace too small");
-    const i64 Min = (i64)a.B * a.T * a.Hin * a.Win;
-    LoadDesc xin = ld_plain(a.x_has_pe ? a.x : a.a0, a.Cin);
-    LoadDesc dy1 = ld_affine2(a.buf_a, a.y1, a.Cmid, w.abc1, a.Cmid);
-    GemmTN g = tn_base(dy1, LD_AFFINE2, xin, LD_PLAIN, (int)Min, a.Cmid, a.Cin, a.dw_pw, a.Cin, 1);
-    PROF(DWN_FAM_PW_WGRAD, launch_gemm_tn(g, a.dtype, s));
-    return 0;
+    return block_fwd_rc(a) ? 0 : 1;
 }
 
 // ------------------------------------------------------------------------------------------------ pool
@@ -746,8 +718,7 @@ ReadoutWs carve_readout(const dwn_readout_args& a, int backward, void* base, siz
     w.Rg = w.Npad / a.groups;
     w.Rp = (w.Rg + 63) / 64 * 64;      // the data-gradient product contracts over Rp: whole k-tiles (LDS-DMA variant)
     const int Kg = a.Cin / a.groups;
-    static const int pad = getenv("DWN_RO_PAD") ? atoi(getenv("DWN_RO_PAD")) : 0;      // tuning: operand row padding (elements)
-    w.ldp = Kg + pad; w.ldt = w.Rp + pad;
+    w.ldp = Kg; w.ldt = w.Rp;          // (row padding of 8 / 64 / 72 elements measured: no effect, so none)
     w.wp = c.take<char>(backward ? (a.wt ? 0 : (size_t)a.groups * Kg * w.ldt * ts) : (size_t)w.Npad * w.ldp * ts);
     if (backward) w.dz = c.take<char>((size_t)M * a.groups * w.Rp * ts);
     if (a.drop_mask) w.xd = c.take<char>((size_t)M * a.Cin * ts);      // x * dropout mask, materialised once
@@ -855,8 +826,7 @@ int dwn_ema_lerp_multi(const dwn_tensor_entry* list, int ntensors, int max_block
 }
 
 int dwn_pw_bwd_fused_supported(int dtype, long long M, int E, int Cin) {
-    static const bool off = getenv("DWN_PW_FUSED_OFF") != nullptr;
-    return (!off && pw_bwd_fused_supported(dtype, M, E, Cin)) ? 1 : 0;
+    return pw_bwd_fused_supported(dtype, M, E, Cin) ? 1 : 0;
 }
 int dwn_pw_bwd_fused(const dwn_pw_bwd_args* a, int dtype, int device, void* stream) {
     ENTER(device);

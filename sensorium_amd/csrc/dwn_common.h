@@ -122,6 +122,12 @@ struct RasterIdx {
 // v_exp_f32 + v_rcp_f32 (1 ulp each): an IEEE fp32 division would cost ~10 VALU instructions per element
 __device__ __forceinline__ float sigmoidf_(float h) { return __builtin_amdgcn_rcpf(1.0f + __expf(-h)); }
 __device__ __forceinline__ float siluf_(float h) { return h * sigmoidf_(h); }
+// SqueezeExcite pooling sums are accumulated as 64-bit fixed point in units of 2^-32: integer addition is associative, so the
+// sums do not depend on the order in which lanes, waves and workgroups add (fp32 atomics made the gate — and through bf16
+// roundings every later activation — differ from run to run).  A float of magnitude >= 2^-8 converts exactly; smaller ones
+// lose bits below 2^-32, the same bits in every run.  |sum| < 2^31.
+__device__ __forceinline__ long long pool_fix(float v) { return (long long)(v * 4294967296.0f); }
+__device__ __forceinline__ float pool_unfix(long long s) { return (float)((double)s * (1.0 / 4294967296.0)); }
 // d silu(h) / dh
 __device__ __forceinline__ float silu_gradf_(float h) {
     float s = sigmoidf_(h);

@@ -133,202 +133,9 @@ __device__ __forceinline__ void wk_stage(const DwSpatialBwd& a, unsigned* tile, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// stride 1.  LPW = pixel pairs per plane row (Win == 2*LPW in {32, 16, 8}); NG = 16/LPW planes side by side in one tile.
-// ------------------------------------------------------------------------------------------------
-template <int LPW>
-__global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1_kernel(const DwSpatialBwd a, const int R, const int rows_qmax) {
-    typedef bf16_t T;
-    constexpr int NT = 256, CS = 64, NG = 16 / LPW, Wqp = LPW + 1;
-    __shared__ float lstat[2 * CS];
-    __shared__ __attribute__((aligned(16))) unsigned lwp[3 * 4 * CS];        // packed weights [dy][combo][channel]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int cv = tid & 15, pl = tid >> 4;
-    const int grp = pl / LPW, jj = pl % LPW;
-    const int c0 = blockIdx.y * CS;
-    const int chan = c0 + cv * 4;
-    const bool chan_ok = chan < a.C;
-    const int chs = chan_ok ? chan : 0;
-    if (tid < 2 * CS) lstat[tid] = 0.f;
-    for (int i = tid; i < 3 * CS; i += NT) {
-        const int dy = i / CS, cc = i % CS, c = c0 + cc;
-        float w0 = 0.f, w1 = 0.f, w2 = 0.f;
-        if (c < a.C) { w0 = a.w[(i64)(dy * 3 + 0) * a.C + c]; w1 = a.w[(i64)(dy * 3 + 1) * a.C + c]; w2 = a.w[(i64)(dy * 3 + 2) * a.C + c]; }
-        lwp[(dy * 4 + 0) * CS + cc] = pk_bf16(w2, w1);
-        lwp[(dy * 4 + 1) * CS + cc] = pk_bf16(w0, 0.f);
-        lwp[(dy * 4 + 2) * CS + cc] = pk_bf16(0.f, w2);
-        lwp[(dy * 4 + 3) * CS + cc] = pk_bf16(w1, w0);
-    }
-    __syncthreads();
-
-    float dwp[9][4];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { dwp[k][0] = dwp[k][1] = dwp[k][2] = dwp[k][3] = 0.f; }
-    float bs[4], bt[4];
-    ldc4(a.y1.v1 + chs, bs); ldc4(a.y1.v2 + chs, bt);
-    const wk_f2_t bs2[2] = {wk_f2_t{bs[0], bs[1]}, wk_f2_t{bs[2], bs[3]}}, bt2[2] = {wk_f2_t{bt[0], bt[1]}, wk_f2_t{bt[2], bt[3]}};
-    // the second BatchNorm-backward sum is accumulated as sum(dh1 * y1) and centred once at the end:
-    // sum(dh1 * yhat) = invstd * (sum(dh1 * y1) - mean * sum(dh1))   (two coefficient vectors less in the loop)
-    wk_f2_t sp0[2] = {wk_f2_t{0.f, 0.f}, wk_f2_t{0.f, 0.f}}, sp1[2] = {wk_f2_t{0.f, 0.f}, wk_f2_t{0.f, 0.f}};
-
-    const int Win = a.Win, Hin = a.Hin;             // stride 1: Hout == Hin, Wout == Win == 2*LPW
-    const int nbands = (Hin + R - 1) / R;
-    const int ngroups = (a.planes + NG - 1) / NG;
-    const int ntiles = ngroups * nbands;
-    T* dhp = reinterpret_cast<T*>(a.dh1);
-    const T* y1p = reinterpret_cast<const T*>(a.y1.p);
-    unsigned* tile = reinterpret_cast<unsigned*>(wk_smem);        // [NG][rows_qmax][Wqp][64] dwords
-    const int rowdw = Wqp * CS;
-    unsigned* tcol = tile + (grp * rows_qmax * Wqp + jj) * CS + cv * 4;      // this thread's pair column, tile row 0
-    const unsigned y1row = (unsigned)Win * (unsigned)a.y1.ld, dhrow = (unsigned)Win * (unsigned)a.C;
-
-    for (int tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
-        const int pg = tile_id / nbands, band = tile_id - pg * nbands;
-        const int plane = pg * NG + grp;
-        const bool pvalid = plane < a.planes && chan_ok;
-        const int psafe = plane < a.planes ? plane : 0;
-        const int hi0 = band * R;
-        const int nri = (Hin - hi0 < R) ? Hin - hi0 : R;
-        const int ho_lo = hi0 - 1;
-        const int rows_q = nri + 2;
-        // ---------------- stage dL/dy2 (BatchNorm-backward affine), x-pair-packed, zero halo
-        wk_stage<LPW>(a, tile, grp, jj, cv, chs, psafe, pvalid, ho_lo, rows_q, rows_qmax);
-        __syncthreads();
-        // ---------------- walk down the rows of this thread's pixel-pair column
-        if (pvalid) {
-            const i64 prow = (i64)plane * Hin * Win;
-            const T* y10 = y1p + prow * a.y1.ld + chs + (unsigned)(hi0 * Win + 2 * jj) * (unsigned)a.y1.ld;
-            T* dh0 = dhp + prow * a.C + chan + (unsigned)(hi0 * Win + 2 * jj) * (unsigned)a.C;
-            uint4 gw[3][2];                              // gradient-tile rows iy, iy+1, iy+2 (pairs jj, jj+1)
-            gw[0][0] = *reinterpret_cast<const uint4*>(tcol); gw[0][1] = *reinterpret_cast<const uint4*>(tcol + CS);
-            gw[1][0] = *reinterpret_cast<const uint4*>(tcol + rowdw); gw[1][1] = *reinterpret_cast<const uint4*>(tcol + rowdw + CS);
-            uint2 ryn[2] = {wk_ld8(y10), wk_ld8(y10 + a.y1.ld)};
-            auto row_step = [&](const int iy, uint4 (&g0)[2], uint4 (&g1)[2], uint4 (&g2)[2]) {
-                // g0, g1, g2: tile rows iy, iy+1, iy+2; g2 is loaded here
-                g2[0] = *reinterpret_cast<const uint4*>(tcol + (iy + 2) * rowdw);
-                g2[1] = *reinterpret_cast<const uint4*>(tcol + (iy + 2) * rowdw + CS);
-                const uint2 ry[2] = {ryn[0], ryn[1]};
-                if (iy + 1 < nri) {                      // next row's y1 in flight under this row's math
-                    const T* yn = y10 + (unsigned)(iy + 1) * y1row;
-                    ryn[0] = wk_ld8(yn); ryn[1] = wk_ld8(yn + a.y1.ld);
-                }
-                wk_f2_t y[2][2], z1[2][2], dsl[2][2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    wk_unpack(ry[h], y[h][0], y[h][1]);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const wk_f2_t hh = y[h][q] * bs2[q] + bt2[q];
-                        const wk_f2_t sg = wk_f2_t{sigmoidf_(hh.x), sigmoidf_(hh.y)};
-                        z1[h][q] = hh * sg;
-                        dsl[h][q] = sg * (1.0f + hh * (1.0f - sg));
-                    }
-                }
-                const unsigned Z[4] = {pk_bf16(z1[0][0].x, z1[1][0].x), pk_bf16(z1[0][0].y, z1[1][0].y),
-                                       pk_bf16(z1[0][1].x, z1[1][1].x), pk_bf16(z1[0][1].y, z1[1][1].y)};
-                float dz0[4] = {0.f, 0.f, 0.f, 0.f}, dz1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    __builtin_amdgcn_sched_barrier(0);        // one stencil row's weight vectors live at a time (registers)
-                    // tile row iy + (2 - dy): output row ho = hi + 1 - dy
-                    const uint4 G0 = dy == 0 ? g2[0] : dy == 1 ? g1[0] : g0[0];
-                    const uint4 G1 = dy == 0 ? g2[1] : dy == 1 ? g1[1] : g0[1];
-                    const uint4 Wa = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 0) * CS + cv * 4]);
-                    const uint4 Wb = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 1) * CS + cv * 4]);
-                    const uint4 Wc = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 2) * CS + cv * 4]);
-                    const uint4 Wd = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 3) * CS + cv * 4]);
-                    const unsigned ga[4] = {G0.x, G0.y, G0.z, G0.w}, gb[4] = {G1.x, G1.y, G1.z, G1.w};
-                    const unsigned wa[4] = {Wa.x, Wa.y, Wa.z, Wa.w}, wb[4] = {Wb.x, Wb.y, Wb.z, Wb.w};
-                    const unsigned wc[4] = {Wc.x, Wc.y, Wc.z, Wc.w}, wd[4] = {Wd.x, Wd.y, Wd.z, Wd.w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        dz0[q] = wk_dot2(ga[q], wa[q], dz0[q]);
-                        dz0[q] = wk_dot2(gb[q], wb[q], dz0[q]);
-                        dz1[q] = wk_dot2(ga[q], wc[q], dz1[q]);
-                        dz1[q] = wk_dot2(gb[q], wd[q], dz1[q]);
-                        const unsigned gm = __builtin_amdgcn_alignbit(gb[q], ga[q], 16);      // (G0.hi, G1.lo)
-                        dwp[dy * 3 + 2][q] = wk_dot2(Z[q], ga[q], dwp[dy * 3 + 2][q]);
-                        dwp[dy * 3 + 1][q] = wk_dot2(Z[q], gm, dwp[dy * 3 + 1][q]);
-                        dwp[dy * 3 + 0][q] = wk_dot2(Z[q], gb[q], dwp[dy * 3 + 0][q]);
-                    }
-                }
-                T* dst = dh0 + (unsigned)iy * dhrow;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float* dz = h == 0 ? dz0 : dz1;
-                    const wk_f2_t d0 = wk_f2_t{dz[0], dz[1]} * dsl[h][0], d1 = wk_f2_t{dz[2], dz[3]} * dsl[h][1];
-                    const uint2 packed = make_uint2(pk_bf16(d0.x, d0.y), pk_bf16(d1.x, d1.y));
-                    *reinterpret_cast<uint2*>(dst + h * a.C) = packed;
-                    wk_f2_t r0, r1;
-                    wk_unpack(packed, r0, r1);                    // statistics of the values as stored
-                    sp0[0] += r0; sp0[1] += r1;
-                    sp1[0] += r0 * y[h][0];
-                    sp1[1] += r1 * y[h][1];
-                }
-            };
-            for (int iy0 = 0; iy0 < nri; iy0 += 3) {
-                row_step(iy0, gw[0], gw[1], gw[2]);
-                if (iy0 + 1 < nri) row_step(iy0 + 1, gw[1], gw[2], gw[0]);
-                if (iy0 + 2 < nri) row_step(iy0 + 2, gw[2], gw[0], gw[1]);
-            }
-        }
-        __syncthreads();
-    }
-    // ---------------- weight gradient: fold the wave's four pixel lanes (36 values -> 9 per lane), then LDS / global atomics
-    float* lw = reinterpret_cast<float*>(wk_smem);               // [9][64], the gradient tile is dead
-    for (int i = tid; i < 9 * CS; i += NT) lw[i] = 0.f;
-    __syncthreads();
-    {
-        float v[36], o[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[k * 4 + q] = dwp[k][q];
-        wk_fold4<9>(v, o, lane);
-        const int r = lane >> 4;
-        DET_WAVES_BEGIN
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int vi = i + 9 * (r >> 1) + 18 * (r & 1);          // value index = tap*4 + q
-            atomicAdd(&lw[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
-        }
-        DET_WAVES_END
-    }
-    __syncthreads();
-    DET_ENTER();
-    for (int i = tid; i < 9 * CS; i += NT) {
-        const int k = i / CS, c = c0 + i % CS;
-        if (c < a.C) atomicAdd(&a.dw[(i64)c * 9 + k], lw[i]);
-    }
-    if (a.stats) {
-        float bm[4], bi[4];
-        ldc4(a.y1.v3 + chs, bm); ldc4(a.y1.v4 + chs, bi);
-        float v[8] = {sp0[0].x, sp0[0].y, sp0[1].x, sp0[1].y,
-                      bi[0] * fmaf(-bm[0], sp0[0].x, sp1[0].x), bi[1] * fmaf(-bm[1], sp0[0].y, sp1[0].y),
-                      bi[2] * fmaf(-bm[2], sp0[1].x, sp1[1].x), bi[3] * fmaf(-bm[3], sp0[1].y, sp1[1].y)}, o[2];
-        wk_fold4<2>(v, o, lane);
-        const int r = lane >> 4;
-        DET_WAVES_BEGIN
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int vi = i + 2 * (r >> 1) + 4 * (r & 1);           // 0..3: Σdh1 of channel vi; 4..7: Σdh1·ŷ1 of channel vi-4
-            atomicAdd(&lstat[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
-        }
-        DET_WAVES_END
-        __syncthreads();
-        DET_ENTER();
-        if (tid < 2 * CS) {
-            const int which = tid / CS, c = c0 + tid % CS;
-            if (c < a.C) stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.C, which, c, lstat[tid]);
-        }
-    }
-    DET_EXIT();
-}
-
-// ------------------------------------------------------------------------------------------------
-// stride 1, CHAINED bands (round 3).  Same arithmetic and dot2 order as dw_spatial_bwd_s1_kernel (dh1 bit-identical), other
-// schedule.  What the round-2 kernel's profile said: per 9-row tile a workgroup made ~14 DEPENDENT memory round trips (three
-// 4-row staging batches, the halo column, then one y1 row per row step prefetched a single step ahead) and both VALU
-// (~40 %) and HBM (3.3-4.6 TB/s) idled on latency; bands re-read two halo rows of (dh2, y2) each.  Here:
+// stride 1, CHAINED rows.  LPW = pixel pairs per plane row (Win == 2*LPW in {32, 16, 8}); NG = 16/LPW planes side by side in one
+// tile.  dh1 is bit-identical to the pair kernel's (same dot2 order).  A banded version of this kernel made ~14 DEPENDENT memory
+// round trips per 9-row tile and idled on latency; here:
 //   * a workgroup walks a WHOLE plane group top to bottom in chunks of RB rows and keeps the gradient tile as a RING of
 //     RB + 2 row slots: the two halo rows a chunk needs are the previous chunk's last rows, still in LDS -> no halo re-read;
 //   * the chunk's y1 rows arrive by LDS-DMA (global_load_lds_dwordx4, no registers), issued BEFORE the staging loads so both
@@ -336,7 +143,7 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1_kernel(const D
 //     group row), placed 0,2,1,3,4,6,5,7 inside the block so that the two pixel lanes of a 32-lane group hit different
 //     bank halves;
 //   * staging fetches the chunk's RB rows (+ the halo column) in ONE batch.
-// One dependent round trip per RB rows instead of ~14 per 9.
+// One dependent round trip per RB rows.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wk_glds16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
@@ -637,382 +444,6 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1c_kernel(const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// stride 1, chained, y2 RECOMPUTED (round 3): the gradient tile needs dL/dy2 = A1*dh2 + A2*y2 + A3 and the round-2 / chained
-// kernels read y2 for it — a fourth E-wide tensor next to dh2, y1 (in) and dh1 (out).  This kernel rebuilds
-// y2 = round_bf16(S z1) from the activated y1 rows it has to hold anyway:
-//   per chunk of RB rows:  A) z1 = SiLU(BN1(y1)) of the newly arrived y1 rows -> Z ring (aligned pixel pairs; a thread
-//                             converts the two pixels it later walks, out of its own wave's LDS-DMA block)
-//                          B) y2 rows by the forward stencil on the Z ring (v_dot2c, 4 per pixel pair, row and channel), rounded
-//                             to bf16 as the stored y2 was; gradient tile row = A1*dh2 + A2*y2 + A3 -> G ring (x-pair-packed)
-//                          C) the row walk of dw_spatial_bwd_s1c_kernel (dz taps, SiLU', dh1, dW, BatchNorm-1 backward sums)
-// HBM traffic = dh2 + y1 in, dh1 out: the algorithmic three tensors, no halo re-reads.  All global reads of chunk k+1 (y1 by
-// LDS-DMA, dh2 into registers) are issued during chunk k.  The extra VALU work (a second sigmoid per element, 6 dot2 per
-// element) is why it runs two workgroups per CU with all loads software-pipelined instead of three.
-// y2 is rebuilt with the taps paired as (2j-2, 2j-1 | 2j, 2j+1) where the forward kernel pairs (2j-1, 2j | 2j+1, 2j+2): the
-// fp32 sums can differ in the last bit, which flips the bf16 rounding of ~1e-4 of the y2 values by one ulp (tests say so).
-// ------------------------------------------------------------------------------------------------
-template <int LPW, int RB>
-__global__ __launch_bounds__(256, 2) void dw_spatial_bwd_s1r_kernel(const DwSpatialBwd a) {
-    typedef bf16_t T;
-    constexpr int NT = 256, CS = 64, NG = 16 / LPW, Wqp = LPW + 1, W = 2 * LPW;
-    constexpr int NY = 2 * RB + 2, NZ = RB + 2, NGR = RB + 2;
-    constexpr int growdw = Wqp * CS;                                        // dwords between G-ring rows of one plane
-    constexpr unsigned Y_BYTES = (unsigned)NY * 4096u, Z_BYTES = (unsigned)NZ * 4096u;
-    static_assert(RB <= LPW, "one halo-column row per thread and chunk");
-    __shared__ float lstat[2 * CS];
-    __shared__ __attribute__((aligned(16))) unsigned lwp[3 * 4 * CS];        // backward taps  [dy][combo][channel]
-    __shared__ __attribute__((aligned(16))) unsigned lwf[3 * 4 * CS];        // forward taps   [dy][combo][channel]
-    __shared__ __attribute__((aligned(16))) float lcoef[5 * CS];             // bn1 scale, shift; BatchNorm-2 backward A1, A2, A3
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cv = tid & 15, pl = tid >> 4;
-    const int grp = pl / LPW, jj = pl % LPW;
-    const int c0 = blockIdx.y * CS;
-    const int chan = c0 + cv * 4;
-    const bool chan_ok = chan < a.C;
-    const int chs = chan_ok ? chan : 0;
-    if (tid < 2 * CS) lstat[tid] = 0.f;
-    for (int i = tid; i < 5 * CS; i += NT) {
-        const int which = i / CS, c = c0 + i % CS;
-        const float* src = which == 0 ? a.y1.v1 : which == 1 ? a.y1.v2 : which == 2 ? a.dy.v1 : which == 3 ? a.dy.v2 : a.dy.v3;
-        lcoef[i] = c < a.C ? src[c] : 0.f;
-    }
-    for (int i = tid; i < 3 * CS; i += NT) {
-        const int dy = i / CS, cc = i % CS, c = c0 + cc;
-        float w0 = 0.f, w1 = 0.f, w2 = 0.f;
-        if (c < a.C) { w0 = a.w[(i64)(dy * 3 + 0) * a.C + c]; w1 = a.w[(i64)(dy * 3 + 1) * a.C + c]; w2 = a.w[(i64)(dy * 3 + 2) * a.C + c]; }
-        lwp[(dy * 4 + 0) * CS + cc] = pk_bf16(w2, w1);
-        lwp[(dy * 4 + 1) * CS + cc] = pk_bf16(w0, 0.f);
-        lwp[(dy * 4 + 2) * CS + cc] = pk_bf16(0.f, w2);
-        lwp[(dy * 4 + 3) * CS + cc] = pk_bf16(w1, w0);
-        // forward: pixel 2j-1 = L.(w0,w1) + C.(w2,0), pixel 2j = L.(0,w0) + C.(w1,w2) with L = z(2j-2, 2j-1), C = z(2j, 2j+1)
-        lwf[(dy * 4 + 0) * CS + cc] = pk_bf16(w0, w1);
-        lwf[(dy * 4 + 1) * CS + cc] = pk_bf16(w2, 0.f);
-        lwf[(dy * 4 + 2) * CS + cc] = pk_bf16(0.f, w0);
-        lwf[(dy * 4 + 3) * CS + cc] = pk_bf16(w1, w2);
-    }
-    __syncthreads();
-
-    float dwp[9][4];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { dwp[k][0] = dwp[k][1] = dwp[k][2] = dwp[k][3] = 0.f; }
-    wk_f2_t sp0[2] = {wk_f2_t{0.f, 0.f}, wk_f2_t{0.f, 0.f}}, sp1[2] = {wk_f2_t{0.f, 0.f}, wk_f2_t{0.f, 0.f}};
-
-    const int Hin = a.Hin;                          // stride 1: Hout == Hin, Wout == Win == W
-    const int ngroups = (a.planes + NG - 1) / NG;
-    const int nchunks = (Hin + RB) / RB;            // chunks cover gradient rows 0 .. Hin (row Hin = the zero row below the plane)
-    T* dhp = reinterpret_cast<T*>(a.dh1);
-    const T* y1p = reinterpret_cast<const T*>(a.y1.p);
-    unsigned char* ybase = wk_smem;                                              // Y ring: raw y1 rows, LDS-DMA layout
-    unsigned char* zbase = wk_smem + Y_BYTES;                                    // Z ring: [slot][pl][cv] 16 B = 4 ch x (z(2jj), z(2jj+1))
-    unsigned* gtile = reinterpret_cast<unsigned*>(wk_smem + Y_BYTES + Z_BYTES);  // G ring: [NG][NGR][Wqp][64] dwords
-    unsigned* gcol = gtile + (grp * NGR * Wqp + jj) * CS + cv * 4;
-    unsigned* glast = gtile + (grp * NGR * Wqp + LPW) * CS + cv * 4;
-    unsigned char* zown = zbase + pl * 256 + cv * 16;
-    const unsigned y1row = (unsigned)W * (unsigned)a.y1.ld, dhrow = (unsigned)W * (unsigned)a.C;
-    const unsigned dyrow = (unsigned)W * (unsigned)a.dy.ld;
-    // y1 by LDS-DMA: lane -> (pixel slot, 16-byte channel chunk) of this wave's 1 KB block of a group row (see s1c kernel)
-    const int dslot = lane >> 3, c16 = lane & 7;
-    const int dq = (dslot & 4) | ((dslot & 1) << 1) | ((dslot >> 1) & 1);
-    const int dp = wave * 8 + dq;
-    const int dgrp = dp / W, dx = dp % W;
-    const int dce = (c0 + c16 * 8 < a.C) ? c0 + c16 * 8 : c0;
-    const unsigned lds_y = (unsigned)(size_t)wk_smem + (unsigned)wave * 1024u;
-    const int jq = pl & 3;
-    const unsigned char* yld = ybase + wave * 1024 + (((jq & 1) + ((jq >> 1) << 2)) * 128) + cv * 8;
-    const unsigned cmask = (jj > 0 ? 0x0000ffffu : 0u) | 0xffff0000u;          // pair jj = (wo = 2jj-1, wo = 2jj)
-    const unsigned lmask = jj > 0 ? 0xffffffffu : 0u;                          // left neighbour pair exists
-    const unsigned colhi = (unsigned)(2 * jj) * (unsigned)a.dy.ld;
-    const unsigned lodelta = jj > 0 ? (unsigned)a.dy.ld : 0u;
-    const unsigned collast = (unsigned)(W - 1) * (unsigned)a.dy.ld;
-
-    for (int pg = blockIdx.x; pg < ngroups; pg += gridDim.x) {
-        const int plane = pg * NG + grp;
-        const bool pvalid = plane < a.planes && chan_ok;
-        const int psafe = plane < a.planes ? plane : 0;
-        const T* dp0 = reinterpret_cast<const T*>(a.dy.p) + (i64)psafe * Hin * W * a.dy.ld + chs;
-        const int dplane = pg * NG + dgrp < a.planes ? pg * NG + dgrp : 0;
-        const T* ysrc0 = y1p + ((i64)dplane * Hin * W + dx) * a.y1.ld + dce;
-        T* dh0 = dhp + (i64)psafe * Hin * W * a.C + chan + (unsigned)(2 * jj) * (unsigned)a.C;
-        auto issue_y = [&](const int row0, const int nrows) {          // rows row0 .. row0+nrows-1 (clamped) -> Y slots row % NY
-            for (int i = 0; i < nrows; ++i) {
-                const int row = row0 + i;
-                const int rc = row < Hin ? row : Hin - 1;
-                wk_glds16(ysrc0 + (unsigned)rc * y1row, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_y + (unsigned)(row % NY) * 4096u)));
-            }
-        };
-        uint2 rp[RB][2], ep;                                            // dh2 of the chunk being staged next
-        auto issue_dh2 = [&](const int s0) {
-#pragma unroll
-            for (int u = 0; u < RB; ++u) {
-                const int ho = s0 + u;
-                const unsigned off = (pvalid && ho < Hin) ? (unsigned)ho * dyrow + colhi : lodelta;
-                rp[u][1] = wk_ld8(dp0 + off);
-                rp[u][0] = wk_ld8(dp0 + off - lodelta);
-            }
-            const int he = s0 + jj;
-            ep = wk_ld8(dp0 + ((pvalid && jj < RB && he < Hin) ? (unsigned)he * dyrow + collast : 0u));
-        };
-        auto touch_dh2 = [&]() {                                        // the compiler's vmcnt wait for these loads goes HERE
-#pragma unroll
-            for (int u = 0; u < RB; ++u) asm volatile("" : "+v"(rp[u][0].x), "+v"(rp[u][0].y), "+v"(rp[u][1].x), "+v"(rp[u][1].y));
-            asm volatile("" : "+v"(ep.x), "+v"(ep.y));
-        };
-        // SiLU(BN1(y1)) of rows r0 .. r0+n-1 of this thread's two pixels -> Z ring (zeros outside the plane)
-        auto stage_a = [&](const int r0, const int n) {
-            const float4 s4 = *reinterpret_cast<const float4*>(&lcoef[cv * 4]), t4 = *reinterpret_cast<const float4*>(&lcoef[CS + cv * 4]);
-            const wk_f2_t bs2[2] = {wk_f2_t{s4.x, s4.y}, wk_f2_t{s4.z, s4.w}}, bt2[2] = {wk_f2_t{t4.x, t4.y}, wk_f2_t{t4.z, t4.w}};
-            for (int i = 0; i < n; ++i) {
-                const int row = r0 + i;
-                uint4 o = make_uint4(0, 0, 0, 0);
-                if (pvalid && row < Hin) {
-                    const unsigned char* yr = yld + (row % NY) * 4096;
-                    const uint2 ry[2] = {*reinterpret_cast<const uint2*>(yr), *reinterpret_cast<const uint2*>(yr + 256)};
-                    wk_f2_t z[2][2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        wk_f2_t y0, y1v;
-                        wk_unpack(ry[h], y0, y1v);
-                        const wk_f2_t h0 = y0 * bs2[0] + bt2[0], h1 = y1v * bs2[1] + bt2[1];
-                        z[h][0] = h0 * wk_f2_t{sigmoidf_(h0.x), sigmoidf_(h0.y)};
-                        z[h][1] = h1 * wk_f2_t{sigmoidf_(h1.x), sigmoidf_(h1.y)};
-                    }
-                    o = make_uint4(pk_bf16(z[0][0].x, z[1][0].x), pk_bf16(z[0][0].y, z[1][0].y), pk_bf16(z[0][1].x, z[1][1].x), pk_bf16(z[0][1].y, z[1][1].y));
-                }
-                *reinterpret_cast<uint4*>(zown + ((row + 1) % NZ) * 4096) = o;
-            }
-        };
-        // ---------------- plane-group prologue: zero rows -1 of both rings, y1 row 0 -> Z, first chunk's loads in flight
-        *reinterpret_cast<uint4*>(zown) = make_uint4(0, 0, 0, 0);                        // Z slot of row -1
-        *reinterpret_cast<uint4*>(gcol) = make_uint4(0, 0, 0, 0);                        // G slot of row -1
-        if (jj == 0) *reinterpret_cast<uint4*>(glast) = make_uint4(0, 0, 0, 0);
-        issue_y(0, 1);
-        issue_y(1, RB);
-        issue_dh2(0);
-        wk_wait_vm0();
-        touch_dh2();
-        stage_a(0, 1);
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            const int s = chunk * RB;
-            if (chunk > 0) { wk_wait_vm0(); touch_dh2(); }          // this chunk's y1 rows (DMA) and dh2 (registers) have landed
-            stage_a(s + 1, RB);
-            wk_lds_barrier();
-            if (chunk + 1 < nchunks) issue_y(s + RB + 1, RB);       // next chunk's y1 rows: in flight under B and the walk
-            // ---------------- B: gradient rows s .. s+RB-1 = A1*dh2 + A2*round(S z1) + A3, x-pair-packed -> G ring
-            {
-                const float4 c1 = *reinterpret_cast<const float4*>(&lcoef[2 * CS + cv * 4]);
-                const float4 c2 = *reinterpret_cast<const float4*>(&lcoef[3 * CS + cv * 4]);
-                const float4 c3 = *reinterpret_cast<const float4*>(&lcoef[4 * CS + cv * 4]);
-                const float a1[4] = {c1.x, c1.y, c1.z, c1.w}, a2[4] = {c2.x, c2.y, c2.z, c2.w}, a3[4] = {c3.x, c3.y, c3.z, c3.w};
-                const unsigned char* zl = jj > 0 ? zown - 256 : zown;             // pair jj-1 (masked away when jj == 0)
-                uint4 ZL[3], ZC[3];
-                auto ldz = [&](const int row, uint4& l, uint4& c) {
-                    const int off = ((row + 1) % NZ) * 4096;
-                    l = *reinterpret_cast<const uint4*>(zl + off);
-                    c = *reinterpret_cast<const uint4*>(zown + off);
-                    l.x &= lmask; l.y &= lmask; l.z &= lmask; l.w &= lmask;
-                };
-                ldz(s - 1, ZL[0], ZC[0]);
-                ldz(s, ZL[1], ZC[1]);
-#pragma unroll
-                for (int u = 0; u < RB; ++u) {
-                    const int ho = s + u;
-                    uint4& l0 = ZL[u % 3]; uint4& q0 = ZC[u % 3];
-                    uint4& l1 = ZL[(u + 1) % 3]; uint4& q1 = ZC[(u + 1) % 3];
-                    uint4& l2 = ZL[(u + 2) % 3]; uint4& q2 = ZC[(u + 2) % 3];
-                    ldz(ho + 1, l2, q2);
-                    float ylo[4] = {0.f, 0.f, 0.f, 0.f}, yhi[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const uint4 L4 = dy == 0 ? l0 : dy == 1 ? l1 : l2;
-                        const uint4 C4 = dy == 0 ? q0 : dy == 1 ? q1 : q2;
-                        const uint4 Fa = *reinterpret_cast<const uint4*>(&lwf[(dy * 4 + 0) * CS + cv * 4]);
-                        const uint4 Fb = *reinterpret_cast<const uint4*>(&lwf[(dy * 4 + 1) * CS + cv * 4]);
-                        const uint4 Fc = *reinterpret_cast<const uint4*>(&lwf[(dy * 4 + 2) * CS + cv * 4]);
-                        const uint4 Fd = *reinterpret_cast<const uint4*>(&lwf[(dy * 4 + 3) * CS + cv * 4]);
-                        const unsigned zl4[4] = {L4.x, L4.y, L4.z, L4.w}, zc4[4] = {C4.x, C4.y, C4.z, C4.w};
-                        const unsigned fa[4] = {Fa.x, Fa.y, Fa.z, Fa.w}, fb[4] = {Fb.x, Fb.y, Fb.z, Fb.w};
-                        const unsigned fc[4] = {Fc.x, Fc.y, Fc.z, Fc.w}, fd[4] = {Fd.x, Fd.y, Fd.z, Fd.w};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            ylo[q] = wk_dot2(zl4[q], fa[q], ylo[q]);
-                            ylo[q] = wk_dot2(zc4[q], fb[q], ylo[q]);
-                            yhi[q] = wk_dot2(zl4[q], fc[q], yhi[q]);
-                            yhi[q] = wk_dot2(zc4[q], fd[q], yhi[q]);
-                        }
-                    }
-                    wk_f2_t dlo0, dlo1, dhi0, dhi1;
-                    wk_unpack(rp[u][0], dlo0, dlo1);
-                    wk_unpack(rp[u][1], dhi0, dhi1);
-                    const float dl[4] = {dlo0.x, dlo0.y, dlo1.x, dlo1.y}, dh_[4] = {dhi0.x, dhi0.y, dhi1.x, dhi1.y};
-                    unsigned o[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const unsigned y2p = pk_bf16(ylo[q], yhi[q]);                          // y2 as it was stored
-                        const float y2l = __uint_as_float(y2p << 16), y2h = __uint_as_float(y2p & 0xffff0000u);
-                        const float gl = a1[q] * dl[q] + (a2[q] * y2l + a3[q]);
-                        const float gh = a1[q] * dh_[q] + (a2[q] * y2h + a3[q]);
-                        o[q] = pk_bf16(gl, gh) & ((pvalid && ho < Hin) ? cmask : 0u);
-                    }
-                    *reinterpret_cast<uint4*>(gcol + ((ho + 1) % NGR) * growdw) = make_uint4(o[0], o[1], o[2], o[3]);
-                }
-                // halo pair column (wo = W-1 | outside): row s + jj, from pair LPW-1 of the Z ring
-                if (jj < RB) {
-                    const int ho = s + jj;
-                    const unsigned char* ze = zbase + (grp * LPW + LPW - 1) * 256 + cv * 16;
-                    float ye[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const uint4 Z4 = *reinterpret_cast<const uint4*>(ze + ((ho + dy) % NZ) * 4096);     // row ho + dy - 1
-                        const uint4 Fa = *reinterpret_cast<const uint4*>(&lwf[(dy * 4 + 0) * CS + cv * 4]);
-                        const unsigned z4[4] = {Z4.x, Z4.y, Z4.z, Z4.w}, fa[4] = {Fa.x, Fa.y, Fa.z, Fa.w};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) ye[q] = wk_dot2(z4[q], fa[q], ye[q]);
-                    }
-                    wk_f2_t d0, d1;
-                    wk_unpack(ep, d0, d1);
-                    const float de[4] = {d0.x, d0.y, d1.x, d1.y};
-                    unsigned o[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float y2e = __uint_as_float(pk_bf16(ye[q], 0.f) << 16);
-                        const float ge = a1[q] * de[q] + (a2[q] * y2e + a3[q]);
-                        o[q] = pk_bf16(ge, 0.f) & ((pvalid && ho < Hin) ? 0x0000ffffu : 0u);
-                    }
-                    *reinterpret_cast<uint4*>(glast + ((ho + 1) % NGR) * growdw) = make_uint4(o[0], o[1], o[2], o[3]);
-                }
-            }
-            if (chunk + 1 < nchunks) issue_dh2(s + RB);             // next chunk's dh2: in flight under the walk
-            wk_lds_barrier();
-            // ---------------- C: walk rows s-1 .. s+RB-2 of this thread's pixel-pair column
-            const int r_lo = s > 0 ? s - 1 : 0;
-            const int r_hi = s + RB - 1 < Hin ? s + RB - 1 : Hin;          // exclusive
-            if (pvalid && r_lo < r_hi) {
-                const float4 s4 = *reinterpret_cast<const float4*>(&lcoef[cv * 4]), t4 = *reinterpret_cast<const float4*>(&lcoef[CS + cv * 4]);
-                const wk_f2_t bs2[2] = {wk_f2_t{s4.x, s4.y}, wk_f2_t{s4.z, s4.w}}, bt2[2] = {wk_f2_t{t4.x, t4.y}, wk_f2_t{t4.z, t4.w}};
-                uint4 gw[3][2];
-                gw[0][0] = *reinterpret_cast<const uint4*>(gcol + ((r_lo) % NGR) * growdw); gw[0][1] = *reinterpret_cast<const uint4*>(gcol + ((r_lo) % NGR) * growdw + CS);
-                gw[1][0] = *reinterpret_cast<const uint4*>(gcol + ((r_lo + 1) % NGR) * growdw); gw[1][1] = *reinterpret_cast<const uint4*>(gcol + ((r_lo + 1) % NGR) * growdw + CS);
-                auto row_step = [&](const int r, uint4 (&g0)[2], uint4 (&g1)[2], uint4 (&g2)[2]) {
-                    g2[0] = *reinterpret_cast<const uint4*>(gcol + ((r + 2) % NGR) * growdw);
-                    g2[1] = *reinterpret_cast<const uint4*>(gcol + ((r + 2) % NGR) * growdw + CS);
-                    const unsigned char* yr = yld + (r % NY) * 4096;
-                    const uint2 ry[2] = {*reinterpret_cast<const uint2*>(yr), *reinterpret_cast<const uint2*>(yr + 256)};
-                    wk_f2_t y[2][2], z1[2][2], dsl[2][2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        wk_unpack(ry[h], y[h][0], y[h][1]);
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const wk_f2_t hh = y[h][q] * bs2[q] + bt2[q];
-                            const wk_f2_t sg = wk_f2_t{sigmoidf_(hh.x), sigmoidf_(hh.y)};
-                            z1[h][q] = hh * sg;
-                            dsl[h][q] = sg * (1.0f + hh * (1.0f - sg));
-                        }
-                    }
-                    const unsigned Z[4] = {pk_bf16(z1[0][0].x, z1[1][0].x), pk_bf16(z1[0][0].y, z1[1][0].y),
-                                           pk_bf16(z1[0][1].x, z1[1][1].x), pk_bf16(z1[0][1].y, z1[1][1].y)};
-                    float dz0[4] = {0.f, 0.f, 0.f, 0.f}, dz1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        const uint4 G0 = dy == 0 ? g2[0] : dy == 1 ? g1[0] : g0[0];
-                        const uint4 G1 = dy == 0 ? g2[1] : dy == 1 ? g1[1] : g0[1];
-                        const uint4 Wa = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 0) * CS + cv * 4]);
-                        const uint4 Wb = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 1) * CS + cv * 4]);
-                        const uint4 Wc = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 2) * CS + cv * 4]);
-                        const uint4 Wd = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 3) * CS + cv * 4]);
-                        const unsigned ga[4] = {G0.x, G0.y, G0.z, G0.w}, gb[4] = {G1.x, G1.y, G1.z, G1.w};
-                        const unsigned wa[4] = {Wa.x, Wa.y, Wa.z, Wa.w}, wb[4] = {Wb.x, Wb.y, Wb.z, Wb.w};
-                        const unsigned wc[4] = {Wc.x, Wc.y, Wc.z, Wc.w}, wd[4] = {Wd.x, Wd.y, Wd.z, Wd.w};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            dz0[q] = wk_dot2(ga[q], wa[q], dz0[q]);
-                            dz0[q] = wk_dot2(gb[q], wb[q], dz0[q]);
-                            dz1[q] = wk_dot2(ga[q], wc[q], dz1[q]);
-                            dz1[q] = wk_dot2(gb[q], wd[q], dz1[q]);
-                            const unsigned gm = __builtin_amdgcn_alignbit(gb[q], ga[q], 16);      // (G0.hi, G1.lo)
-                            dwp[dy * 3 + 2][q] = wk_dot2(Z[q], ga[q], dwp[dy * 3 + 2][q]);
-                            dwp[dy * 3 + 1][q] = wk_dot2(Z[q], gm, dwp[dy * 3 + 1][q]);
-                            dwp[dy * 3 + 0][q] = wk_dot2(Z[q], gb[q], dwp[dy * 3 + 0][q]);
-                        }
-                    }
-                    T* dst = dh0 + (unsigned)r * dhrow;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const float* dz = h == 0 ? dz0 : dz1;
-                        const wk_f2_t d0 = wk_f2_t{dz[0], dz[1]} * dsl[h][0], d1 = wk_f2_t{dz[2], dz[3]} * dsl[h][1];
-                        const uint2 packed = make_uint2(pk_bf16(d0.x, d0.y), pk_bf16(d1.x, d1.y));
-                        *reinterpret_cast<uint2*>(dst + h * a.C) = packed;
-                        wk_f2_t r0, r1;
-                        wk_unpack(packed, r0, r1);                    // statistics of the values as stored
-                        sp0[0] += r0; sp0[1] += r1;
-                        sp1[0] += r0 * y[h][0];
-                        sp1[1] += r1 * y[h][1];
-                    }
-                };
-                for (int r = r_lo; r < r_hi; r += 3) {
-                    row_step(r, gw[0], gw[1], gw[2]);
-                    if (r + 1 < r_hi) row_step(r + 1, gw[1], gw[2], gw[0]);
-                    if (r + 2 < r_hi) row_step(r + 2, gw[2], gw[0], gw[1]);
-                }
-            }
-        }
-        wk_wait_vm0();                              // (nothing of this plane group is in flight when the rings are re-used)
-        wk_lds_barrier();
-    }
-    // ---------------- weight gradient: fold the wave's four pixel lanes (36 values -> 9 per lane), then LDS / global atomics
-    float* lw = reinterpret_cast<float*>(wk_smem);               // [9][64], the rings are dead
-    for (int i = tid; i < 9 * CS; i += NT) lw[i] = 0.f;
-    __syncthreads();
-    {
-        float v[36], o[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[k * 4 + q] = dwp[k][q];
-        wk_fold4<9>(v, o, lane);
-        const int r = lane >> 4;
-        DET_WAVES_BEGIN
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int vi = i + 9 * (r >> 1) + 18 * (r & 1);          // value index = tap*4 + q
-            atomicAdd(&lw[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
-        }
-        DET_WAVES_END
-    }
-    __syncthreads();
-    DET_ENTER();
-    for (int i = tid; i < 9 * CS; i += NT) {
-        const int k = i / CS, c = c0 + i % CS;
-        if (c < a.C) atomicAdd(&a.dw[(i64)c * 9 + k], lw[i]);
-    }
-    if (a.stats) {
-        float bm[4], bi[4];
-        ldc4(a.y1.v3 + chs, bm); ldc4(a.y1.v4 + chs, bi);
-        float v[8] = {sp0[0].x, sp0[0].y, sp0[1].x, sp0[1].y,
-                      bi[0] * fmaf(-bm[0], sp0[0].x, sp1[0].x), bi[1] * fmaf(-bm[1], sp0[0].y, sp1[0].y),
-                      bi[2] * fmaf(-bm[2], sp0[1].x, sp1[1].x), bi[3] * fmaf(-bm[3], sp0[1].y, sp1[1].y)}, o[2];
-        wk_fold4<2>(v, o, lane);
-        const int r = lane >> 4;
-        DET_WAVES_BEGIN
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int vi = i + 2 * (r >> 1) + 4 * (r & 1);
-            atomicAdd(&lstat[(vi >> 2) * CS + cv * 4 + (vi & 3)], o[i]);
-        }
-        DET_WAVES_END
-        __syncthreads();
-        DET_ENTER();
-        if (tid < 2 * CS) {
-            const int which = tid / CS, c = c0 + tid % CS;
-            if (c < a.C) stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.C, which, c, lstat[tid]);
-        }
-    }
-    DET_EXIT();
-}
-
-// ------------------------------------------------------------------------------------------------
 // stride 2.  A thread owns one QUAD of input pixels (columns 4m .. 4m+3) of an input row and walks down the rows.
 // With the output-column pairs Gq[k] = (g[wo = 2k-1], g[wo = 2k]) and M = (g[wo = 2m], g[wo = 2m+1]) = align(Gq[m], Gq[m+1]),
 // a tap row (dy, output row ho) contributes
@@ -1237,8 +668,7 @@ __global__ __launch_bounds__(256, WK_MINW2) void dw_spatial_bwd_s2_kernel(const 
 #endif
 
 bool dw_spatial_bwd_walk_supported(const DwSpatialBwd& a, int dtype) {
-    const char* off = getenv("DWN_DWS_WALK_OFF");          // read per call: lets one process A/B the two implementations
-    if ((off && off[0] == '1') || dtype != DWN_BF16 || a.ks != 3 || a.C % 8) return false;
+    if (a.impl == 1 || dtype != DWN_BF16 || a.ks != 3 || a.C % 8) return false;      // impl 1: the pair / generic kernels (tests)
     if (a.stride == 1) {
         if (a.Win != 32 && a.Win != 16 && a.Win != 8) return false;
         if (a.Hout != a.Hin || a.Wout != a.Win) return false;
@@ -1252,38 +682,6 @@ bool dw_spatial_bwd_walk_supported(const DwSpatialBwd& a, int dtype) {
         return true;
     }
     return false;
-}
-
-template <int LPW>
-static int launch_s1(const DwSpatialBwd& a, hipStream_t s) {
-    constexpr int NG = 16 / LPW, Wqp = LPW + 1;
-    const size_t rowb = (size_t)NG * Wqp * 256;
-    int R = a.rows_band;
-    if (R <= 0) {
-        R = 1;
-        while (R < a.Hin && (size_t)(R + 1 + 2) * rowb <= (size_t)WK_LDS_BUDGET) ++R;
-        const int nb = (a.Hin + R - 1) / R;
-        R = (a.Hin + nb - 1) / nb;                    // even split: no ragged last band
-    }
-    if (R > a.Hin) R = a.Hin;
-    const int rows_qmax = R + 2;
-    size_t lds = (size_t)rows_qmax * rowb;
-    if (lds < 9 * 64 * sizeof(float)) lds = 9 * 64 * sizeof(float);
-    if (lds > 150 * 1024) return dwn_set_error(-5, "dw_spatial_bwd: rows_band too large for the LDS tile");
-    auto kern = dw_spatial_bwd_s1_kernel<LPW>;
-    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        (void)hipGetLastError();
-    int bpc = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kern, 256, lds) != hipSuccess || bpc < 1) { (void)hipGetLastError(); bpc = 2; }
-    const int slices = (a.C + 63) / 64;
-    const int nbands = (a.Hin + R - 1) / R;
-    const i64 work = (i64)((a.planes + NG - 1) / NG) * nbands;
-    i64 gx = (256 * bpc) / slices;
-    if (gx < 1) gx = 1;
-    if (gx > work) gx = work;
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, slices), dim3(256), lds, s, a, R, rows_qmax);
-    DWN_CHECK_LAUNCH();
-    return 0;
 }
 
 template <int LPW>
@@ -1337,40 +735,11 @@ static int launch_s1c(const DwSpatialBwd& a, hipStream_t s) {
     DWN_CHECK_LAUNCH();
     return 0;
 }
-template <int LPW, int RB>
-static int launch_s1r(const DwSpatialBwd& a, hipStream_t s) {
-    constexpr int NG = 16 / LPW, Wqp = LPW + 1;
-    const size_t lds = (size_t)(2 * RB + 2) * 4096 + (size_t)(RB + 2) * 4096 + (size_t)NG * (RB + 2) * Wqp * 256;
-    auto kern = dw_spatial_bwd_s1r_kernel<LPW, RB>;
-    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        (void)hipGetLastError();
-    int bpc = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kern, 256, lds) != hipSuccess || bpc < 1) { (void)hipGetLastError(); bpc = 2; }
-    const int slices = (a.C + 63) / 64;
-    const i64 work = (a.planes + NG - 1) / NG;
-    i64 gx = (256 * bpc) / slices;
-    if (gx < 1) gx = 1;
-    if (gx > work) gx = work;
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, slices), dim3(256), lds, s, a);
-    DWN_CHECK_LAUNCH();
-    return 0;
-}
-template <int LPW>
-static int launch_s1r_rb(const DwSpatialBwd& a, hipStream_t s) {
-    const char* e = getenv("DWN_DWS_Y2RC_RB");
-    const int rb = a.rows_band > 0 ? a.rows_band : (e ? atoi(e) : 2);
-    if (rb <= 1) return launch_s1r<LPW, 1>(a, s);
-    if (rb <= 2) return launch_s1r<LPW, 2>(a, s);
-    if (rb <= 3) return launch_s1r<LPW, 3>(a, s);
-    return launch_s1r<LPW, 4>(a, s);
-}
-
-// chained stride-1 kernel: rows per chunk from a.rows_band / DWN_DWS_CHAIN_RB (4 = three workgroups per CU)
+// chained stride-1 kernel: rows per chunk = a.rows_band, or the measured best at the metric shapes (tools/bwd_chain_check.py):
+// 4 rows per chunk at 18x32 planes (three workgroups per CU), 2 at 9x16 and 5x8
 template <int LPW>
 static int launch_s1c_rb(const DwSpatialBwd& a, hipStream_t s) {
-    const char* e = getenv("DWN_DWS_CHAIN_RB");
-    // measured best at the metric shapes (tools/bwd_chain_check.py): 4 rows per chunk at 18x32 planes, 2 at 9x16 and 5x8
-    int rb = a.rows_band > 0 ? a.rows_band : (e ? atoi(e) : (LPW == 16 ? 4 : 2));
+    const int rb = a.rows_band > 0 ? a.rows_band : (LPW == 16 ? 4 : 2);
     if (rb <= 2) return launch_s1c<LPW, 2>(a, s);
     if (rb <= 4) return launch_s1c<LPW, 4>(a, s);
     if (rb <= 6) return launch_s1c<LPW, 6>(a, s);
@@ -1378,22 +747,10 @@ static int launch_s1c_rb(const DwSpatialBwd& a, hipStream_t s) {
 }
 
 int launch_dw_spatial_bwd_walk(const DwSpatialBwd& a, hipStream_t s) {
-    const char* ch = getenv("DWN_DWS_CHAIN");            // read per call: A/B inside one process
-    const char* rc = getenv("DWN_DWS_Y2RC");              // "1": the y2-rebuilding kernel (a.dy.q is not read)
-    if (a.stride == 1 && rc && rc[0] == '1') {
-        if (a.Win == 32) return launch_s1r_rb<16>(a, s);
-        if (a.Win == 16) return launch_s1r_rb<8>(a, s);
-        return launch_s1r_rb<4>(a, s);
-    }
-    if (a.stride == 1 && !(ch && ch[0] == '0')) {
+    if (a.stride == 1) {
         if (a.Win == 32) return launch_s1c_rb<16>(a, s);
         if (a.Win == 16) return launch_s1c_rb<8>(a, s);
         return launch_s1c_rb<4>(a, s);
-    }
-    if (a.stride == 1) {
-        if (a.Win == 32) return launch_s1<16>(a, s);
-        if (a.Win == 16) return launch_s1<8>(a, s);
-        return launch_s1<4>(a, s);
     }
     if (a.stride == 2) {
         if (a.Win == 64) return launch_s2<16>(a, s);

@@ -837,7 +837,8 @@ __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFw
                     // then fold them with xor-shuffles and let the first NCV lanes add 4 channels each
                     const int b0 = __builtin_amdgcn_readfirstlane((int)b);
                     const bool uniform = __popcll(__ballot(1)) == 64 && __all((int)b == b0);
-                    float* dst = a.pooled + b * a.C + chan;
+                    // 64-bit fixed-point sums (pool_fix): whatever the arrival order, the same total
+                    unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.pooled) + b * a.C + chan;
                     if (uniform) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
@@ -845,11 +846,11 @@ __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFw
                             for (int o = NCV; o < 64; o <<= 1) ps[i] += __shfl_xor(ps[i], o);
                         if ((tid & 63) < NCV) {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) atomicAdd(dst + i, ps[i]);
+                            for (int i = 0; i < 4; ++i) atomicAdd(dst + i, (unsigned long long)pool_fix(ps[i]));
                         }
                     } else {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) atomicAdd(dst + i, ps[i]);
+                        for (int i = 0; i < 4; ++i) atomicAdd(dst + i, (unsigned long long)pool_fix(ps[i]));
                     }
                 }
             }
@@ -1012,8 +1013,7 @@ static int resident_grid_x(K kernel, size_t dyn_lds, int slices, i64 work, int t
     }
     int bpc = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kernel, threads, dyn_lds) != hipSuccess || bpc < 1) bpc = 2;
-    static const int mode = getenv("DWN_GRID_MODE") ? atoi(getenv("DWN_GRID_MODE")) : 0;   // tuning knob (microbench)
-    int gx = (256 * bpc * (mode > 0 ? mode : 1)) / slices;     // 256 CUs
+    int gx = (256 * bpc) / slices;     // 256 CUs
     if (gx < 1) gx = 1;
     return grid_cap(work, gx);
 }
@@ -1025,8 +1025,7 @@ static int spatial_fwd_t(DwSpatialFwd a, hipStream_t s) {
     if (a.C % 8) return dwn_set_error(-2, "dw_spatial: C must be a multiple of 8");
     const int Wp = a.Win + 2;
     // bf16, stride 1/2: x-pair-packed tile (dot2 kernel), rows of ceil(Wp/2) pairs x 256 bytes
-    static const bool pair_off = getenv("DWN_DWS_NOPAIR") != nullptr;
-    const bool pair = TT<T>::IS_BF16 && (a.stride == 1 || a.stride == 2) && !pair_off;
+    const bool pair = TT<T>::IS_BF16 && (a.stride == 1 || a.stride == 2);
     auto tile_bytes = [&](int rb) {
         return pair ? (size_t)((rb - 1) * a.stride + 3) * ((Wp + 1) / 2) * 256 : (size_t)((rb - 1) * a.stride + 3) * Wp * 128;
     };
@@ -1303,8 +1302,7 @@ static int spatial_bwd_t(DwSpatialBwd a, hipStream_t s) {
     const int Wq = a.Wout + 2;
     auto rows_q = [&](int rb) { return (rb - 1 + 2) / a.stride + 2; };   // upper bound on staged output rows
     // bf16, stride 1: x-pair-packed gradient tile (dot2 kernel), rows of ceil(Wq/2) pairs x 256 bytes
-    static const bool pair_off = getenv("DWN_DWS_NOPAIR") != nullptr;
-    const bool pair = TT<T>::IS_BF16 && a.stride == 1 && !pair_off;
+    const bool pair = TT<T>::IS_BF16 && a.stride == 1;
     const size_t row_bytes = pair ? (size_t)((Wq + 1) / 2) * 256 : (size_t)Wq * 128;
     if (a.rows_band <= 0) {
         int rb = 1;
@@ -1517,7 +1515,7 @@ static int temporal_bwd_t(const DwTemporalBwd& a, hipStream_t s) {
     }
     dim3 grid(resident_grid_x(dw_temporal_bwd_kernel<T, 5, LD_AFFINE2, 4>, 0, slices, work), slices);
     if (!dy3 && a.dy_kind != LD_AFFINE2) return dwn_set_error(-3, "dw_temporal_bwd: unsupported dy loader");
-    static const int tb8 = getenv("DWN_DWT_TB") ? atoi(getenv("DWN_DWT_TB")) == 8 : (DWT_BWD_TB == 8);
+    constexpr bool tb8 = DWT_BWD_TB == 8;
     if (a.kt == 5) {
         if (dy3) hipLaunchKernelGGL((dw_temporal_bwd_kernel<T, 5, LD_DY3, 4>), grid, dim3(256), 0, s, a);
         else if (tb8) hipLaunchKernelGGL((dw_temporal_bwd_kernel<T, 5, LD_AFFINE2, 8>), grid, dim3(256), 0, s, a);

@@ -1,4 +1,4 @@
-// spat_covn_dw forward (reference: src/models/dwiseneuro.py:96-102), bf16 storage, 3x3, stride 1 or 2 — "row walk" kernels.
+// spat_covn_dw forward (reference: src/models/dwiseneuro.py:96-102), bf16 storage, 3x3, stride 1 or 2 — chained row-walk kernels.
 //
 //   y2 = dwS * SiLU(BN1(y1))   (+ Σy2, Σy2² for BatchNorm-2)
 //
@@ -41,316 +41,13 @@ __device__ __forceinline__ void wf_lds_barrier() {
 #endif
 }
 
-// LPW = output pixel pairs per plane row (Wout == 2*LPW in {32, 16, 8}); NG = 16/LPW planes side by side in one tile.
-// The staged tile has NPC = ST*LPW + 1 pair columns k = (wi = 2k-1, wi = 2k) and rows hi_first .. hi_first + rows_in - 1.
-template <int ST, int LPW>
-__global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_walk_kernel(const DwSpatialFwd a, const int R, const int rows_max) {
-    typedef bf16_t T;
-    constexpr int NT = 256, CS = 64, NG = 16 / LPW, NPC = ST * LPW + 1;
-    constexpr int NWC = ST == 1 ? 4 : 2;
-    __shared__ float lstat[2 * CS];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int cv = tid & 15, pl = tid >> 4;
-    const int grp = pl / LPW, jj = pl % LPW;
-    const int c0 = blockIdx.y * CS;
-    const int chan = c0 + cv * 4;
-    const bool chan_ok = chan < a.C;
-    const int chs = chan_ok ? chan : 0;
-    if (tid < 2 * CS) lstat[tid] = 0.f;
-    __syncthreads();
-
-    // packed weights per stencil row dy and channel: A = (w0,w1), B = (w2,0) [, C = (0,w0), D = (w1,w2)]
-    unsigned wp[3][NWC][4];
-    {
-        float w[9][4];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            ldc4(a.w + (i64)k * a.C + chs, w[k]);
-            if (!chan_ok) { w[k][0] = w[k][1] = w[k][2] = w[k][3] = 0.f; }
-        }
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                wp[dy][0][q] = pk_bf16(w[dy * 3 + 0][q], w[dy * 3 + 1][q]);
-                wp[dy][1][q] = pk_bf16(w[dy * 3 + 2][q], 0.f);
-                if constexpr (ST == 1) {
-                    wp[dy][2][q] = pk_bf16(0.f, w[dy * 3 + 0][q]);
-                    wp[dy][3][q] = pk_bf16(w[dy * 3 + 1][q], w[dy * 3 + 2][q]);
-                }
-            }
-    }
-    float bs[4], bt[4];
-    ldc4(a.in.v1 + chs, bs); ldc4(a.in.v2 + chs, bt);
-    const wf_f2_t bs2[2] = {wf_f2_t{bs[0], bs[1]}, wf_f2_t{bs[2], bs[3]}}, bt2[2] = {wf_f2_t{bt[0], bt[1]}, wf_f2_t{bt[2], bt[3]}};
-    wf_f2_t st0[2] = {wf_f2_t{0.f, 0.f}, wf_f2_t{0.f, 0.f}}, st1[2] = {wf_f2_t{0.f, 0.f}, wf_f2_t{0.f, 0.f}};
-
-    const int Hin = a.Hin, Win = a.Win, Hout = a.Hout, Wout = a.Wout;
-    const int nbands = (Hout + R - 1) / R;
-    const int ngroups = (a.planes + NG - 1) / NG;
-    const int ntiles = ngroups * nbands;
-    const T* inp = reinterpret_cast<const T*>(a.in.p);
-    T* outp = reinterpret_cast<T*>(a.out);
-    unsigned* tile = reinterpret_cast<unsigned*>(wf_smem);        // [NG][rows_max][NPC][64] dwords
-    const int rowdw = NPC * CS;
-    unsigned* tplane = tile + grp * rows_max * rowdw + cv * 4;
-    const unsigned inrow = (unsigned)Win * (unsigned)a.in.ld, outrow = (unsigned)Wout * (unsigned)a.C;
-
-    auto act_pack = [&](const uint2& rlo, const uint2& rhi) {
-        wf_f2_t y0, y1v, z[2][2];
-        wf_unpack(rlo, y0, y1v);
-        {
-            const wf_f2_t h0 = y0 * bs2[0] + bt2[0], h1 = y1v * bs2[1] + bt2[1];
-            z[0][0] = h0 * wf_f2_t{sigmoidf_(h0.x), sigmoidf_(h0.y)};
-            z[0][1] = h1 * wf_f2_t{sigmoidf_(h1.x), sigmoidf_(h1.y)};
-        }
-        wf_unpack(rhi, y0, y1v);
-        {
-            const wf_f2_t h0 = y0 * bs2[0] + bt2[0], h1 = y1v * bs2[1] + bt2[1];
-            z[1][0] = h0 * wf_f2_t{sigmoidf_(h0.x), sigmoidf_(h0.y)};
-            z[1][1] = h1 * wf_f2_t{sigmoidf_(h1.x), sigmoidf_(h1.y)};
-        }
-        return make_uint4(pk_bf16(z[0][0].x, z[1][0].x), pk_bf16(z[0][0].y, z[1][0].y), pk_bf16(z[0][1].x, z[1][1].x), pk_bf16(z[0][1].y, z[1][1].y));
-    };
-
-    for (int tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
-        const int pg = tile_id / nbands, band = tile_id - pg * nbands;
-        const int plane = pg * NG + grp;
-        const bool pvalid = plane < a.planes && chan_ok;
-        const int psafe = plane < a.planes ? plane : 0;
-        const int ho0 = band * R;
-        const int nro = (Hout - ho0 < R) ? Hout - ho0 : R;
-        const int hi_first = ho0 * ST - 1;
-        const int rows_in = (nro - 1) * ST + 3;
-        // ---------------- stage SiLU(BN1(y1)), x-pair-packed, zero halo: own pair column for every row
-        if constexpr (ST == 1) {
-            const T* in0 = inp + (i64)psafe * Hin * Win * a.in.ld + chs;
-            constexpr int NB = 4;
-            {
-                const int kc = jj;                                              // pair column: pixels wi = 2kc-1, 2kc
-                const unsigned cmask = (kc > 0 ? 0x0000ffffu : 0u) | 0xffff0000u;
-                const unsigned colhi = (unsigned)(2 * kc) * (unsigned)a.in.ld;
-                const unsigned lodelta = kc > 0 ? (unsigned)a.in.ld : 0u;
-                unsigned* tcol = tplane + kc * CS;
-                for (int r0 = 0; r0 < rows_in; r0 += NB) {
-                    uint2 rr[NB][2];
-                    bool ok[NB];
-#pragma unroll
-                    for (int u = 0; u < NB; ++u) {
-                        const int hi = hi_first + r0 + u;
-                        ok[u] = pvalid && r0 + u < rows_in && (unsigned)hi < (unsigned)Hin;
-                        const unsigned off = ok[u] ? (unsigned)hi * inrow + colhi : lodelta;
-                        rr[u][1] = wf_ld8(in0 + off);
-                        rr[u][0] = wf_ld8(in0 + off - lodelta);
-                    }
-#pragma unroll
-                    for (int u = 0; u < NB; ++u) {
-                        if (r0 + u < rows_in) {
-                            uint4 o = act_pack(rr[u][0], rr[u][1]);
-                            const unsigned m = ok[u] ? cmask : 0u;
-                            o.x &= m; o.y &= m; o.z &= m; o.w &= m;
-                            *reinterpret_cast<uint4*>(tcol + (r0 + u) * rowdw) = o;
-                        }
-                    }
-                }
-            }
-            // last pair column (wi = Win-1, halo): row r = jj, jj + LPW, ... of this plane
-            const unsigned collast = (unsigned)(Win - 1) * (unsigned)a.in.ld;
-            for (int r = jj; r < rows_in; r += LPW) {
-                const int hi = hi_first + r;
-                const bool okr = pvalid && (unsigned)hi < (unsigned)Hin;
-                const unsigned off = okr ? (unsigned)hi * inrow + collast : 0u;
-                const uint2 v = wf_ld8(in0 + off);
-                uint4 o = act_pack(v, v);
-                const unsigned m = okr ? 0x0000ffffu : 0u;
-                o.x &= m; o.y &= m; o.z &= m; o.w &= m;
-                *reinterpret_cast<uint4*>(tplane + r * rowdw + (NPC - 1) * CS) = o;
-            }
-        } else {
-            // stride 2 stages four input pixels per output: 16-byte loads (8 channels per staging lane, 32 lanes = one lane
-            // per pair column), twice the bytes per load instruction and half the per-item overhead of the 4-channel role
-            constexpr int SLW = 2 * LPW;                                       // staging lanes per plane row
-            const int scv = tid & 7, spl = tid >> 3;
-            const int sgrp = spl / SLW, kc = spl % SLW;
-            const int splane = pg * NG + sgrp;
-            const int sch = c0 + scv * 8;
-            const bool svalid = splane < a.planes && sch < a.C;
-            const int schs = sch < a.C ? sch : 0;
-            const T* in0 = inp + (i64)(splane < a.planes ? splane : 0) * Hin * Win * a.in.ld + schs;
-            wf_f2_t s8[4], t8[4];
-            {
-                float sf[8], tf[8];
-                ldc4(a.in.v1 + schs, sf); ldc4(a.in.v1 + schs + 4, sf + 4);
-                ldc4(a.in.v2 + schs, tf); ldc4(a.in.v2 + schs + 4, tf + 4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { s8[i] = wf_f2_t{sf[2 * i], sf[2 * i + 1]}; t8[i] = wf_f2_t{tf[2 * i], tf[2 * i + 1]}; }
-            }
-            auto act_pack8 = [&](const uint4& rlo, const uint4& rhi, const unsigned m, unsigned* dst) {
-                const unsigned wa[4] = {rlo.x, rlo.y, rlo.z, rlo.w}, wb[4] = {rhi.x, rhi.y, rhi.z, rhi.w};
-                unsigned o[8];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const wf_f2_t ya = wf_f2_t{__uint_as_float(wa[i] << 16), __uint_as_float(wa[i] & 0xffff0000u)};
-                    const wf_f2_t yb = wf_f2_t{__uint_as_float(wb[i] << 16), __uint_as_float(wb[i] & 0xffff0000u)};
-                    const wf_f2_t ha = ya * s8[i] + t8[i], hb = yb * s8[i] + t8[i];
-                    const wf_f2_t za = ha * wf_f2_t{sigmoidf_(ha.x), sigmoidf_(ha.y)};
-                    const wf_f2_t zb = hb * wf_f2_t{sigmoidf_(hb.x), sigmoidf_(hb.y)};
-                    o[2 * i] = pk_bf16(za.x, zb.x) & m;
-                    o[2 * i + 1] = pk_bf16(za.y, zb.y) & m;
-                }
-                reinterpret_cast<uint4*>(dst)[0] = make_uint4(o[0], o[1], o[2], o[3]);
-                reinterpret_cast<uint4*>(dst)[1] = make_uint4(o[4], o[5], o[6], o[7]);
-            };
-            unsigned* splane_t = tile + sgrp * rows_max * rowdw + scv * 8;
-            constexpr int NB = 4;
-            {
-                const unsigned cmask = (kc > 0 ? 0x0000ffffu : 0u) | 0xffff0000u;
-                const unsigned colhi = (unsigned)(2 * kc) * (unsigned)a.in.ld;
-                const unsigned lodelta = kc > 0 ? (unsigned)a.in.ld : 0u;
-                unsigned* tcol = splane_t + kc * CS;
-                for (int r0 = 0; r0 < rows_in; r0 += NB) {
-                    uint4 rr[NB][2];
-                    bool ok[NB];
-#pragma unroll
-                    for (int u = 0; u < NB; ++u) {
-                        const int hi = hi_first + r0 + u;
-                        ok[u] = svalid && r0 + u < rows_in && (unsigned)hi < (unsigned)Hin;
-                        const unsigned off = ok[u] ? (unsigned)hi * inrow + colhi : lodelta;
-                        rr[u][1] = *reinterpret_cast<const uint4*>(in0 + off);
-                        rr[u][0] = *reinterpret_cast<const uint4*>(in0 + off - lodelta);
-                    }
-#pragma unroll
-                    for (int u = 0; u < NB; ++u)
-                        if (r0 + u < rows_in) act_pack8(rr[u][0], rr[u][1], ok[u] ? cmask : 0u, tcol + (r0 + u) * rowdw);
-                }
-            }
-            const unsigned collast = (unsigned)(Win - 1) * (unsigned)a.in.ld;
-            for (int r = kc; r < rows_in; r += SLW) {
-                const int hi = hi_first + r;
-                const bool okr = svalid && (unsigned)hi < (unsigned)Hin;
-                const unsigned off = okr ? (unsigned)hi * inrow + collast : 0u;
-                const uint4 v = *reinterpret_cast<const uint4*>(in0 + off);
-                act_pack8(v, v, okr ? 0x0000ffffu : 0u, splane_t + r * rowdw + (NPC - 1) * CS);
-            }
-        }
-        __syncthreads();
-        // ---------------- walk down the output rows of this thread's output pair column (outputs 2jj, 2jj+1)
-        if (pvalid) {
-            T* out0 = outp + ((i64)plane * Hout + ho0) * Wout * a.C + chan + (unsigned)(2 * jj) * (unsigned)a.C;
-            const unsigned* tc = tplane + (ST == 1 ? jj : 2 * jj) * CS;       // first tile pair of this output pair
-            auto finish = [&](const int oy, const float* acc0, const float* acc1) {
-                T* dst = out0 + (unsigned)oy * outrow;
-                const uint2 pk0 = make_uint2(pk_bf16(acc0[0], acc0[1]), pk_bf16(acc0[2], acc0[3]));
-                const uint2 pk1 = make_uint2(pk_bf16(acc1[0], acc1[1]), pk_bf16(acc1[2], acc1[3]));
-                *reinterpret_cast<uint2*>(dst) = pk0;
-                *reinterpret_cast<uint2*>(dst + a.C) = pk1;
-                wf_f2_t r0, r1;
-                wf_unpack(pk0, r0, r1);
-                st0[0] += r0; st0[1] += r1; st1[0] += r0 * r0; st1[1] += r1 * r1;
-                wf_unpack(pk1, r0, r1);
-                st0[0] += r0; st0[1] += r1; st1[0] += r0 * r0; st1[1] += r1 * r1;
-            };
-            if constexpr (ST == 1) {
-                uint4 tw[3][2];                              // tile rows oy, oy+1, oy+2: pairs jj, jj+1
-                tw[0][0] = *reinterpret_cast<const uint4*>(tc); tw[0][1] = *reinterpret_cast<const uint4*>(tc + CS);
-                tw[1][0] = *reinterpret_cast<const uint4*>(tc + rowdw); tw[1][1] = *reinterpret_cast<const uint4*>(tc + rowdw + CS);
-                auto row_step = [&](const int oy, const uint4 (&t0)[2], const uint4 (&t1)[2], uint4 (&t2)[2]) {
-                    t2[0] = *reinterpret_cast<const uint4*>(tc + (oy + 2) * rowdw);
-                    t2[1] = *reinterpret_cast<const uint4*>(tc + (oy + 2) * rowdw + CS);
-                    float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const uint4 p0 = dy == 0 ? t0[0] : dy == 1 ? t1[0] : t2[0];
-                        const uint4 p1 = dy == 0 ? t0[1] : dy == 1 ? t1[1] : t2[1];
-                        const unsigned x0[4] = {p0.x, p0.y, p0.z, p0.w}, x1[4] = {p1.x, p1.y, p1.z, p1.w};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            acc0[q] = wf_dot2(x0[q], wp[dy][0][q], acc0[q]);
-                            acc0[q] = wf_dot2(x1[q], wp[dy][1][q], acc0[q]);
-                            acc1[q] = wf_dot2(x0[q], wp[dy][NWC - 2][q], acc1[q]);
-                            acc1[q] = wf_dot2(x1[q], wp[dy][NWC - 1][q], acc1[q]);
-                        }
-                    }
-                    finish(oy, acc0, acc1);
-                };
-                for (int oy = 0; oy < nro; oy += 3) {
-                    row_step(oy, tw[0], tw[1], tw[2]);
-                    if (oy + 1 < nro) row_step(oy + 1, tw[1], tw[2], tw[0]);
-                    if (oy + 2 < nro) row_step(oy + 2, tw[2], tw[0], tw[1]);
-                }
-            } else {
-                // stride 2: output ox reads staged columns 2ox .. 2ox+2 = P[ox] and the low half of P[ox+1]; rows 2oy .. 2oy+2
-                uint4 ta[3], tb[3], tcw[3];                  // tile rows 2oy (ta), 2oy+1 (tb), 2oy+2 (tcw): pairs 2jj, 2jj+1, 2jj+2
-#pragma unroll
-                for (int m = 0; m < 3; ++m) ta[m] = *reinterpret_cast<const uint4*>(tc + m * CS);
-                auto row_step = [&](const int oy, const uint4 (&r0)[3], uint4 (&r1)[3], uint4 (&r2)[3]) {
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) {
-                        r1[m] = *reinterpret_cast<const uint4*>(tc + (2 * oy + 1) * rowdw + m * CS);
-                        r2[m] = *reinterpret_cast<const uint4*>(tc + (2 * oy + 2) * rowdw + m * CS);
-                    }
-                    float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const uint4 p0 = dy == 0 ? r0[0] : dy == 1 ? r1[0] : r2[0];
-                        const uint4 p1 = dy == 0 ? r0[1] : dy == 1 ? r1[1] : r2[1];
-                        const uint4 p2 = dy == 0 ? r0[2] : dy == 1 ? r1[2] : r2[2];
-                        const unsigned x0[4] = {p0.x, p0.y, p0.z, p0.w}, x1[4] = {p1.x, p1.y, p1.z, p1.w}, x2[4] = {p2.x, p2.y, p2.z, p2.w};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            acc0[q] = wf_dot2(x0[q], wp[dy][0][q], acc0[q]);
-                            acc0[q] = wf_dot2(x1[q], wp[dy][1][q], acc0[q]);
-                            acc1[q] = wf_dot2(x1[q], wp[dy][0][q], acc1[q]);
-                            acc1[q] = wf_dot2(x2[q], wp[dy][1][q], acc1[q]);
-                        }
-                    }
-                    finish(oy, acc0, acc1);
-                };
-                // the bottom tile row of one output row is the top row of the next: ta / tcw alternate
-                for (int oy = 0; oy < nro; oy += 2) {
-                    row_step(oy, ta, tb, tcw);
-                    if (oy + 1 < nro) row_step(oy + 1, tcw, tb, ta);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (a.stats) {
-        // fold the wave's four pixel lanes (8 sums -> 2 per lane) with two transposing lane swaps, then LDS atomics
-        const unsigned v[8] = {__float_as_uint(st0[0].x), __float_as_uint(st0[0].y), __float_as_uint(st0[1].x), __float_as_uint(st0[1].y),
-                               __float_as_uint(st1[0].x), __float_as_uint(st1[0].y), __float_as_uint(st1[1].x), __float_as_uint(st1[1].y)};
-        float c4[4], d2[2];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const wf_u32x2_t r = __builtin_amdgcn_permlane16_swap(v[k], v[k + 4], false, false);
-            c4[k] = __uint_as_float(r.x) + __uint_as_float(r.y);
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const wf_u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c4[k]), __float_as_uint(c4[k + 2]), false, false);
-            d2[k] = __uint_as_float(r.x) + __uint_as_float(r.y);
-        }
-        const int r = lane >> 4;                          // lane row r holds value index (r&1)*4 + (r>>1)*2 + {0,1}
-        DET_WAVES_BEGIN
-#pragma unroll
-        for (int k = 0; k < 2; ++k) atomicAdd(&lstat[(r & 1) * CS + cv * 4 + (r >> 1) * 2 + k], d2[k]);
-        DET_WAVES_END
-        __syncthreads();
-        DET_ENTER();
-        if (tid < 2 * CS) {
-            const int which = tid / CS, c = c0 + tid % CS;
-            if (c < a.C) stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.C, which, c, lstat[tid]);
-        }
-    }
-    DET_EXIT();
-}
-
 // ------------------------------------------------------------------------------------------------
-// CHAINED bands (round 3): same arithmetic and dot2 order as dw_spatial_fwd_walk_kernel (y2 bit-identical), other schedule.
+// CHAINED rows.  LPW = output pixel pairs per plane row (Wout == 2*LPW in {32, 16, 8}); NG = 16/LPW planes side by side in one
+// tile; the staged tile has NPC = ST*LPW + 1 pair columns k = (wi = 2k-1, wi = 2k).
 // A workgroup walks a whole plane group top to bottom in chunks of RB output rows and keeps the activated tile as a RING of
 // row slots: the halo rows a chunk needs are the previous chunk's last rows, still in LDS, so no input row is fetched or
-// activated twice (the banded kernel re-read 2 of 11 rows at stride 1 and 1 of 5 at stride 2), and a chunk's rows are
-// fetched in ONE batch (one dependent round trip per chunk instead of three or four per band).
+// activated twice, and a chunk's rows are fetched in ONE batch (one dependent round trip per chunk).  y2 is bit-identical to
+// the pair kernel's (same dot2 order).
 //   stride 1: chunk c stages input rows s .. s+RB-1 (s = c*RB) and produces output rows s-1 .. s+RB-2; ring of RB+2 rows
 //   stride 2: chunk c stages input rows 2s .. 2s+2RB-1 and produces output rows s .. s+RB-1;          ring of 2RB+1 rows
 // ring slot of input row r = (r + 1) mod RQ; row -1 (slot 0) is the zero row above the plane.
@@ -682,50 +379,13 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(cons
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
-#ifndef WF_LDS_BUDGET
-#define WF_LDS_BUDGET (52 * 1024)          // three workgroups per CU
-#endif
-
 bool dw_spatial_fwd_walk_supported(const DwSpatialFwd& a, int dtype) {
-    const char* off = getenv("DWN_DWS_WALK_OFF");          // read per call: lets one process A/B the two implementations
-    if ((off && off[0] == '1') || dtype != DWN_BF16 || a.ks != 3 || a.C % 8) return false;
-    const char* s2 = getenv("DWN_DWS_FWD_WALK_S2");       // "0": stride 2 through the pair kernel (A/B)
-    if (a.stride != 1 && !(a.stride == 2 && !(s2 && s2[0] == '0'))) return false;
+    if (a.impl == 1 || dtype != DWN_BF16 || a.ks != 3 || a.C % 8) return false;      // impl 1: the pair / generic kernels (tests)
+    if (a.stride != 1 && a.stride != 2) return false;
     if (a.Wout != 32 && a.Wout != 16 && a.Wout != 8) return false;
     if (a.Win != a.Wout * a.stride || a.Hout != (a.Hin - 1) / a.stride + 1) return false;
     if ((i64)a.Hin * a.Win * a.in.ld >= (1ll << 31)) return false;
     return true;
-}
-
-template <int ST, int LPW>
-static int launch_fw(const DwSpatialFwd& a, hipStream_t s) {
-    constexpr int NG = 16 / LPW, NPC = ST * LPW + 1;
-    const size_t rowb = (size_t)NG * NPC * 256;
-    int R = a.rows_band;
-    if (R <= 0) {
-        R = 1;
-        while (R < a.Hout && (size_t)(R * ST + 3) * rowb <= (size_t)WF_LDS_BUDGET) ++R;
-        const int nb = (a.Hout + R - 1) / R;
-        R = (a.Hout + nb - 1) / nb;                   // even split: no ragged last band
-    }
-    if (R > a.Hout) R = a.Hout;
-    const int rows_max = (R - 1) * ST + 3;
-    const size_t lds = (size_t)rows_max * rowb;
-    if (lds > 150 * 1024) return dwn_set_error(-5, "dw_spatial_fwd: rows_band too large for the LDS tile");
-    auto kern = dw_spatial_fwd_walk_kernel<ST, LPW>;
-    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        (void)hipGetLastError();
-    int bpc = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kern, 256, lds) != hipSuccess || bpc < 1) { (void)hipGetLastError(); bpc = 2; }
-    const int slices = (a.C + 63) / 64;
-    const int nbands = (a.Hout + R - 1) / R;
-    const i64 work = (i64)((a.planes + NG - 1) / NG) * nbands;
-    i64 gx = (256 * bpc) / slices;
-    if (gx < 1) gx = 1;
-    if (gx > work) gx = work;
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, slices), dim3(256), lds, s, a, R, rows_max);
-    DWN_CHECK_LAUNCH();
-    return 0;
 }
 
 template <int ST, int LPW, int RB>
@@ -746,12 +406,10 @@ static int launch_fc(const DwSpatialFwd& a, hipStream_t s) {
     DWN_CHECK_LAUNCH();
     return 0;
 }
-// chained kernels: output rows per chunk from a.rows_band / DWN_DWS_FCHAIN_RB
+// output rows per chunk: a.rows_band, or the measured best at the metric shapes (tools/fwd_chain_check.py)
 template <int ST, int LPW>
 static int launch_fc_rb(const DwSpatialFwd& a, hipStream_t s) {
-    const char* e = getenv("DWN_DWS_FCHAIN_RB");
-    // measured best at the metric shapes (tools/fwd_chain_check.py)
-    const int rb = a.rows_band > 0 ? a.rows_band : (e ? atoi(e) : (ST == 1 ? (LPW == 16 ? 4 : 6) : (LPW == 4 ? 1 : 2)));
+    const int rb = a.rows_band > 0 ? a.rows_band : (ST == 1 ? (LPW == 16 ? 4 : 6) : (LPW == 4 ? 1 : 2));
     if constexpr (ST == 1) {
         if (rb <= 2) return launch_fc<1, LPW, 2>(a, s);
         if (rb <= 4) return launch_fc<1, LPW, 4>(a, s);
@@ -766,23 +424,12 @@ static int launch_fc_rb(const DwSpatialFwd& a, hipStream_t s) {
 }
 
 int launch_dw_spatial_fwd_walk(const DwSpatialFwd& a, hipStream_t s) {
-    const char* ch = getenv("DWN_DWS_FCHAIN");            // read per call: A/B inside one process ("0": banded round-2 kernels)
-    if (!(ch && ch[0] == '0')) {
-        if (a.stride == 1) {
-            if (a.Wout == 32) return launch_fc_rb<1, 16>(a, s);
-            if (a.Wout == 16) return launch_fc_rb<1, 8>(a, s);
-            return launch_fc_rb<1, 4>(a, s);
-        }
-        if (a.Wout == 32) return launch_fc_rb<2, 16>(a, s);
-        if (a.Wout == 16) return launch_fc_rb<2, 8>(a, s);
-        return launch_fc_rb<2, 4>(a, s);
-    }
     if (a.stride == 1) {
-        if (a.Wout == 32) return launch_fw<1, 16>(a, s);
-        if (a.Wout == 16) return launch_fw<1, 8>(a, s);
-        return launch_fw<1, 4>(a, s);
+        if (a.Wout == 32) return launch_fc_rb<1, 16>(a, s);
+        if (a.Wout == 16) return launch_fc_rb<1, 8>(a, s);
+        return launch_fc_rb<1, 4>(a, s);
     }
-    if (a.Wout == 32) return launch_fw<2, 16>(a, s);
-    if (a.Wout == 16) return launch_fw<2, 8>(a, s);
-    return launch_fw<2, 4>(a, s);
+    if (a.Wout == 32) return launch_fc_rb<2, 16>(a, s);
+    if (a.Wout == 16) return launch_fc_rb<2, 8>(a, s);
+    return launch_fc_rb<2, 4>(a, s);
 }

@@ -424,8 +424,7 @@ static bool rc_fits(int Cin, int E, int Win, int Wout, int stride, int R, bool* 
 }
 
 static bool rc_supported(int dtype, int Cin, int E, int ks, int stride, int Hin, int Win) {
-    static const bool off = getenv("DWN_RC_OFF") != nullptr;
-    if (off || dtype != DWN_BF16 || ks != 3 || (stride != 1 && stride != 2)) return false;
+    if (dtype != DWN_BF16 || ks != 3 || (stride != 1 && stride != 2)) return false;
     if ((Cin != 64 && Cin != 128) || E % 64 || E <= 0) return false;
     if (Hin < 1 || Win < 2) return false;
     return rc_fits(Cin, E, Win, (Win - 1) / stride + 1, stride, 1, nullptr);

@@ -945,13 +945,16 @@ int k_residual_bwd_dx(const LoadDesc& xin, const void* da0, const void* dout, co
 // ------------------------------------------------------------------------------------------------
 // Squeeze-Excite (SqueezeExcite3d, dwiseneuro.py:38-43)
 // ------------------------------------------------------------------------------------------------
-// pooled[b][c] += sum over a chunk of the sample's rows of silu(bn3(y3))
+// pooled[b][c] += sum over a chunk of the sample's rows of silu(bn3(y3)), in 64-bit fixed point (pool_fix, dwn_common.h):
+// a thread's own sum runs over a fixed set of rows in a fixed order, and everything after it is integer addition, so the
+// pooled sums — and with them the gate and the whole forward pass — do not depend on the order in which waves and
+// workgroups arrive (no ordering needed in the deterministic build either)
 template <typename T>
 __global__ __launch_bounds__(256) void se_pool_kernel(LoadDesc z3, int C, int rows_per_sample, int chunks,
-                                                      float* pooled, T* z3out) {
+                                                      long long* pooled, T* z3out) {
     SLICE_SETUP(C)
-    __shared__ float lacc[NCV * KC];
-    if (tid < NCV * KC) lacc[tid] = 0.f;
+    __shared__ unsigned long long lacc[NCV * KC];
+    if (tid < NCV * KC) lacc[tid] = 0ull;
     __syncthreads();
     const int b = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
     const int per = (rows_per_sample + chunks - 1) / chunks;
@@ -986,17 +989,14 @@ __global__ __launch_bounds__(256) void se_pool_kernel(LoadDesc z3, int C, int ro
             }
         }
     }
-    DET_WAVES_BEGIN
 #pragma unroll
-    for (int i = 0; i < KC; ++i) atomicAdd(&lacc[cv * KC + i], acc[i]);
-    DET_WAVES_END
+    for (int i = 0; i < KC; ++i) atomicAdd(&lacc[cv * KC + i], (unsigned long long)pool_fix(acc[i]));
     __syncthreads();
-    DET_ENTER();
-    if (tid < NCV * KC && c0 + tid < C) atomicAdd(pooled + (i64)b * C + c0 + tid, lacc[tid]);
-    DET_EXIT();
+    if (tid < NCV * KC && c0 + tid < C)
+        atomicAdd(reinterpret_cast<unsigned long long*>(pooled) + (i64)b * C + c0 + tid, lacc[tid]);
 }
 
-int k_se_pool(const LoadDesc& z3, int B, int C, int rows_per_sample, float* pooled, void* z3out, int dtype, hipStream_t s) {
+int k_se_pool(const LoadDesc& z3, int B, int C, int rows_per_sample, long long* pooled, void* z3out, int dtype, hipStream_t s) {
     int KCv = dtype == DWN_BF16 ? 8 : 4;
     int slices = (C + NCV * KCv - 1) / (NCV * KCv);
     int chunks = (rows_per_sample + 255) / 256;
@@ -1013,7 +1013,7 @@ int k_se_pool(const LoadDesc& z3, int B, int C, int rows_per_sample, float* pool
 
 // SE MLP forward.  grid = (B, SPLIT): every workgroup recomputes the tiny hidden layer (R x C MACs) of its sample
 // and produces a 1/SPLIT slice of the C gates, so the launch fills the chip instead of B = 32 workgroups.
-__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* pooled_sum, float inv_s, const float* wr,
+__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const long long* pooled_sum, float inv_s, const float* wr,
                                                          const float* br, const float* we, const float* be, int C,
                                                          int R, float* pmean, float* hid_pre, float* gate) {
     extern __shared__ float sh[];          // [C] mean + [R] hid
@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* pooled_sum
     const int b = blockIdx.x, tid = threadIdx.x;
     const int split = gridDim.y, part = blockIdx.y;
     for (int c = tid; c < C; c += 256) {
-        float v = pooled_sum[(i64)b * C + c] * inv_s;
+        float v = pool_unfix(pooled_sum[(i64)b * C + c]) * inv_s;
         pm[c] = v;
         if (part == 0) pmean[(i64)b * C + c] = v;
     }
@@ -1088,9 +1088,7 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* dg, const 
 
 // ---- latency-oriented variants for R <= SE_RT hidden units (the model's R = Cmid / 32 <= 56).
 // The generic kernels above walk the hidden units one after another per wave: ~R/4 dependent rounds of L2 latency
-// (40-50 us per launch).  Here every thread owns a fixed set of channels and keeps one partial sum per hidden unit in
-// registers, so all R x C/256 weight loads of the squeeze layer are independent; the partials are combined with
-// xor-shuffles and one LDS atomic per wave.
+// (40-50 us per launch); they remain for R > SE_RT and odd R.
 #define SE_RT 64
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -1098,85 +1096,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// RP = compile-time bound on R (16 / 32 / 64), walked in register blocks of RB = min(RP, 32) hidden units (64
-// accumulators per thread spill).  Hidden units r >= R re-read row R-1 (clamped index) and are ignored: every load of
-// the squeeze layer is unconditional, so all RB x C/256 of them are in flight together.
-template <int RP>
-__global__ __launch_bounds__(256) void se_mlp_fwd_fast_kernel(const float* pooled_sum, float inv_s, const float* wr,
-                                                              const float* br, const float* we, const float* be, int C,
-                                                              int R, float* pmean, float* hid_pre, float* gate) {
-    constexpr int RB = RP < 32 ? RP : 32;
-    __shared__ float hid[RP];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int split = gridDim.y, part = blockIdx.y;
-    if (tid < RP) hid[tid] = 0.f;
-    __syncthreads();
-#pragma unroll 1
-    for (int r0 = 0; r0 < RP; r0 += RB) {
-        if (r0 >= R) break;
-        float acc[RB];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) acc[r] = 0.f;
-        for (int c = tid; c < C; c += 256) {
-            const float v = pooled_sum[(i64)b * C + c] * inv_s;
-            if (part == 0 && r0 == 0) pmean[(i64)b * C + c] = v;
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                const int rr = r0 + r < R ? r0 + r : R - 1;
-                acc[r] = fmaf(wr[(i64)rr * C + c], v, acc[r]);
-            }
-        }
-        DET_WAVES_BEGIN
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const float t = wave_sum(acc[r]);
-            if (lane == 0 && r0 + r < R) atomicAdd(&hid[r0 + r], t);
-        }
-        DET_WAVES_END
-    }
-    __syncthreads();
-    if (tid < R) {
-        const float h = hid[tid] + br[tid];
-        if (part == 0) hid_pre[(i64)b * R + tid] = h;
-        hid[tid] = siluf_(h);
-    }
-    __syncthreads();
-    const int per = (C + split - 1) / split;
-    const int c_end = (part + 1) * per < C ? (part + 1) * per : C;
-    for (int c = part * per + tid; c < c_end; c += 256) {
-        float a = be[c];
-        const float* wrow = we + (i64)c * R;
-#pragma unroll 1
-        for (int r0 = 0; r0 < RP; r0 += 16) {
-            if (r0 >= R) break;
-            float wv[16];
-            if ((R & 3) == 0) {        // rows of `we` are 16-byte aligned: 4x fewer (uncoalesced, stride R) requests
-                const float4* w4 = reinterpret_cast<const float4*>(wrow);
-                const int nq = R >> 2;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int qi = (r0 >> 2) + q;
-                    const float4 t = w4[qi < nq ? qi : nq - 1];
-                    wv[4 * q] = t.x; wv[4 * q + 1] = t.y; wv[4 * q + 2] = t.z; wv[4 * q + 3] = t.w;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) wv[r] = wrow[r0 + r < R ? r0 + r : R - 1];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a = fmaf(wv[r], r0 + r < R ? hid[r0 + r] : 0.f, a);
-        }
-        gate[(i64)b * C + c] = sigmoidf_(a);
-    }
-}
-
-// Round-3 forward: the squeeze layer by ROWS.  Wave w owns hidden units w, w+4, ... (RP/4 of them, all unrolled) and walks
-// the channels with 16-byte loads (lane -> 4 consecutive channels, 256 channels per wave step): a quarter of the load
-// instructions of the thread-per-channel form above, every one of them independent, one xor-shuffle sum per owned unit and NO
-// LDS atomics (a hidden unit has exactly one owner wave — nothing to order in the deterministic build either).
+// The squeeze layer by ROWS.  Wave w owns hidden units w, w+4, ... (RP/4 of them, all unrolled) and walks
+// the channels with 16-byte loads (lane -> 4 consecutive channels, 256 channels per wave step): every load independent,
+// one xor-shuffle sum per owned unit and NO LDS atomics (a hidden unit has exactly one owner wave — nothing to order in the deterministic build either).
 // Requires C % 4 == 0 (16-byte rows of `wr`).
 template <int RP>
-__global__ __launch_bounds__(256) void se_mlp_fwd_rows_kernel(const float* pooled_sum, float inv_s, const float* wr,
+__global__ __launch_bounds__(256) void se_mlp_fwd_rows_kernel(const long long* pooled_sum, float inv_s, const float* wr,
                                                               const float* br, const float* we, const float* be, int C,
                                                               int R, float* pmean, float* hid_pre, float* gate) {
     constexpr int RPW = RP / 4;
@@ -1187,11 +1112,12 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_rows_kernel(const float* poole
     float acc[RPW];
 #pragma unroll
     for (int q = 0; q < RPW; ++q) acc[q] = 0.f;
-    const float4* ps4 = reinterpret_cast<const float4*>(pooled_sum + (i64)b * C);
+    const longlong2* ps2 = reinterpret_cast<const longlong2*>(pooled_sum + (i64)b * C);
     float4* pm4 = reinterpret_cast<float4*>(pmean + (i64)b * C);
     for (int c4 = lane; c4 < C4; c4 += 64) {
-        float4 v = ps4[c4];
-        v.x *= inv_s; v.y *= inv_s; v.z *= inv_s; v.w *= inv_s;
+        const longlong2 p0 = ps2[2 * c4], p1 = ps2[2 * c4 + 1];
+        float4 v;
+        v.x = pool_unfix(p0.x) * inv_s; v.y = pool_unfix(p0.y) * inv_s; v.z = pool_unfix(p1.x) * inv_s; v.w = pool_unfix(p1.y) * inv_s;
         if (part == 0 && wave == 0) pm4[c4] = v;
         float4 w[RPW];
 #pragma unroll
@@ -1243,74 +1169,6 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_rows_kernel(const float* poole
     }
 }
 
-template <int RP>
-__global__ __launch_bounds__(256) void se_mlp_bwd_fast_kernel(const float* dg, const float* gate, const float* hid_pre,
-                                                              const float* wr, const float* we, int C, int R,
-                                                              float inv_s, float* dgp_out, float* dhp_out, float* dps) {
-    constexpr int RB = RP < 32 ? RP : 32;
-    __shared__ float dhp[RP];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int split = gridDim.y, part = blockIdx.y;
-    if (tid < RP) dhp[tid] = 0.f;
-    __syncthreads();
-#pragma unroll 1
-    for (int r0 = 0; r0 < RP; r0 += RB) {
-        if (r0 >= R) break;
-        float acc[RB];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) acc[r] = 0.f;
-        for (int c = tid; c < C; c += 256) {
-            const float g = gate[(i64)b * C + c];
-            const float v = dg[(i64)b * C + c] * g * (1.f - g);
-            if (part == 0 && r0 == 0) dgp_out[(i64)b * C + c] = v;
-            const float* wrow = we + (i64)c * R;
-            if ((R & 3) == 0 && (RB & 3) == 0) {
-                const float4* w4 = reinterpret_cast<const float4*>(wrow);
-                const int nq = R >> 2;
-#pragma unroll
-                for (int q = 0; q < RB / 4; ++q) {
-                    const int qi = (r0 >> 2) + q;
-                    const float4 t = w4[qi < nq ? qi : nq - 1];
-                    acc[4 * q] = fmaf(t.x, v, acc[4 * q]); acc[4 * q + 1] = fmaf(t.y, v, acc[4 * q + 1]);
-                    acc[4 * q + 2] = fmaf(t.z, v, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(t.w, v, acc[4 * q + 3]);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < RB; ++r) acc[r] = fmaf(wrow[r0 + r < R ? r0 + r : R - 1], v, acc[r]);
-            }
-        }
-        DET_WAVES_BEGIN
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const float t = wave_sum(acc[r]);
-            if (lane == 0 && r0 + r < R) atomicAdd(&dhp[r0 + r], t);
-        }
-        DET_WAVES_END
-    }
-    __syncthreads();
-    if (tid < R) {
-        const float v = dhp[tid] * silu_gradf_(hid_pre[(i64)b * R + tid]);
-        dhp[tid] = v;
-        if (part == 0) dhp_out[(i64)b * R + tid] = v;
-    }
-    __syncthreads();
-    const int per = (C + split - 1) / split;
-    const int c_end = (part + 1) * per < C ? (part + 1) * per : C;
-    for (int c = part * per + tid; c < c_end; c += 256) {
-        float a = 0.f;
-#pragma unroll 1
-        for (int r0 = 0; r0 < RP; r0 += 16) {
-            if (r0 >= R) break;
-            float wv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) wv[r] = wr[(i64)(r0 + r < R ? r0 + r : R - 1) * C + c];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a = fmaf(wv[r], r0 + r < R ? dhp[r0 + r] : 0.f, a);
-        }
-        dps[(i64)b * C + c] = a * inv_s;
-    }
-}
-
 // Folding wave reduction: every lane holds N partial sums (N a power of two <= 64); afterwards lane l holds the wave total
 // of value l % N.  At distance d a lane keeps the half of its live values whose index bit matches its own lane bit and
 // adds the partner's copy of them: N - 1 + (plain steps) shuffles instead of 6 N for N separate butterfly sums.
@@ -1341,7 +1199,7 @@ __device__ __forceinline__ float wave_fold(float (&v)[N], int lane) {
     return v[0];
 }
 
-// Round-3 backward data path: all RP partial sums of the excite layer's transpose product in one pass (16-/8-byte loads of the
+// Backward data path: all RP partial sums of the excite layer's transpose product in one pass (16-/8-byte loads of the
 // `we` rows), one folding reduction per wave, the four wave totals combined through LDS slots — no LDS atomics (nothing to
 // order in the deterministic build).  Requires R even.
 template <int RP, int VW>
@@ -1439,11 +1297,9 @@ __global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const float* dgp, con
     }
 }
 
-int k_se_mlp_fwd(const float* pooled_sum, float inv_s, const float* wr, const float* br, const float* we,
+int k_se_mlp_fwd(const long long* pooled_sum, float inv_s, const float* wr, const float* br, const float* we,
                  const float* be, int B, int C, int R, float* pmean, float* hid_pre, float* gate, hipStream_t s) {
-    const char* v2 = getenv("DWN_SE_ROWS");                  // "0": the thread-per-channel kernels (A/B)
-    if (!(v2 && v2[0] == '0') && (C & 3) == 0 && R <= SE_RT &&
-        !(((size_t)pooled_sum | (size_t)wr | (size_t)pmean) & 15)) {
+    if ((C & 3) == 0 && R <= SE_RT && !(((size_t)pooled_sum | (size_t)wr | (size_t)pmean) & 15)) {
         if (R <= 16)
             hipLaunchKernelGGL(se_mlp_fwd_rows_kernel<16>, dim3(B, 8), dim3(256), 0, s, pooled_sum, inv_s, wr, br, we, be, C, R,
                                pmean, hid_pre, gate);
@@ -1453,29 +1309,17 @@ int k_se_mlp_fwd(const float* pooled_sum, float inv_s, const float* wr, const fl
         else
             hipLaunchKernelGGL(se_mlp_fwd_rows_kernel<SE_RT>, dim3(B, 8), dim3(256), 0, s, pooled_sum, inv_s, wr, br, we, be, C,
                                R, pmean, hid_pre, gate);
-        DWN_CHECK_LAUNCH();
-        return 0;
-    }
-    if (R <= 16)
-        hipLaunchKernelGGL(se_mlp_fwd_fast_kernel<16>, dim3(B, 8), dim3(256), 0, s, pooled_sum, inv_s, wr, br, we, be, C, R,
-                           pmean, hid_pre, gate);
-    else if (R <= 32)
-        hipLaunchKernelGGL(se_mlp_fwd_fast_kernel<32>, dim3(B, 8), dim3(256), 0, s, pooled_sum, inv_s, wr, br, we, be, C, R,
-                           pmean, hid_pre, gate);
-    else if (R <= SE_RT)
-        hipLaunchKernelGGL(se_mlp_fwd_fast_kernel<SE_RT>, dim3(B, 8), dim3(256), 0, s, pooled_sum, inv_s, wr, br, we, be, C, R,
-                           pmean, hid_pre, gate);
-    else
+    } else {
         hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(B, 8), dim3(256), (C + R) * sizeof(float), s, pooled_sum, inv_s, wr, br,
                            we, be, C, R, pmean, hid_pre, gate);
+    }
     DWN_CHECK_LAUNCH();
     return 0;
 }
 int k_se_mlp_bwd(const float* dg, const float* gate, const float* hid_pre, const float* pmean, const float* wr,
                  const float* we, int B, int C, int R, float inv_s, float* dgp, float* dhp, float* dps, float* dwr,
                  float* dbr, float* dwe, float* dbe, hipStream_t s) {
-    const char* v2 = getenv("DWN_SE_ROWS");                  // "0": the thread-per-channel kernels with LDS atomics (A/B)
-    if (!(v2 && v2[0] == '0') && (R & 1) == 0 && R <= SE_RT && !((size_t)we & 15)) {
+    if ((R & 1) == 0 && R <= SE_RT && !((size_t)we & 15)) {
 #define SE_BWD_FOLD(RP_) do { \
         if ((R & 3) == 0) hipLaunchKernelGGL((se_mlp_bwd_fold_kernel<RP_, 4>), dim3(B, 8), dim3(256), 0, s, dg, gate, hid_pre, wr, we, C, R, inv_s, dgp, dhp, dps); \
         else hipLaunchKernelGGL((se_mlp_bwd_fold_kernel<RP_, 2>), dim3(B, 8), dim3(256), 0, s, dg, gate, hid_pre, wr, we, C, R, inv_s, dgp, dhp, dps); } while (0)
@@ -1483,24 +1327,10 @@ int k_se_mlp_bwd(const float* dg, const float* gate, const float* hid_pre, const
         else if (R <= 32) SE_BWD_FOLD(32);
         else SE_BWD_FOLD(SE_RT);
 #undef SE_BWD_FOLD
-        DWN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 255) / 256, R), dim3(256), 0, s, dgp, dhp, pmean, hid_pre, B, C, R,
-                           dwr, dbr, dwe, dbe);
-        DWN_CHECK_LAUNCH();
-        return 0;
-    }
-    if (R <= 16)
-        hipLaunchKernelGGL(se_mlp_bwd_fast_kernel<16>, dim3(B, 8), dim3(256), 0, s, dg, gate, hid_pre, wr, we, C, R, inv_s, dgp,
-                           dhp, dps);
-    else if (R <= 32)
-        hipLaunchKernelGGL(se_mlp_bwd_fast_kernel<32>, dim3(B, 8), dim3(256), 0, s, dg, gate, hid_pre, wr, we, C, R, inv_s, dgp,
-                           dhp, dps);
-    else if (R <= SE_RT)
-        hipLaunchKernelGGL(se_mlp_bwd_fast_kernel<SE_RT>, dim3(B, 8), dim3(256), 0, s, dg, gate, hid_pre, wr, we, C, R, inv_s,
-                           dgp, dhp, dps);
-    else
+    } else {
         hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(B, 8), dim3(256), (C + R) * sizeof(float), s, dg, gate, hid_pre, wr, we,
                            C, R, inv_s, dgp, dhp, dps);
+    }
     DWN_CHECK_LAUNCH();
     hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 255) / 256, R), dim3(256), 0, s, dgp, dhp, pmean, hid_pre, B, C, R,
                        dwr, dbr, dwe, dbe);

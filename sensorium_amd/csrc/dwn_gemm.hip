@@ -774,11 +774,9 @@ static int launch_nn_k(const GemmNN& g, hipStream_t s) {
     if ((nranges * ntn) % 8 != 0) nranges = 8;
     dim3 grid(nranges * ntn, g.groups);
     if constexpr (!TT<T>::IS_BF16 && NN_F32_X3 != 0) {
-        // fp32 products on the bf16 matrix cores (see NN_F32_X3): asked for per call (the eval-mode forward does), DWN_F32_SPLIT=0 never,
-        // =2 always (A/B)
-        const char* e = getenv("DWN_F32_SPLIT");
-        const bool split = e ? (e[0] == '2' || (e[0] != '0' && g.f32_split)) : g.f32_split != 0;
-        if (split) {
+        // fp32 products on the bf16 matrix cores (see NN_F32_X3): asked for per call (dwn_gemm_nn_args.f32_split; the eval-mode
+        // forward does unless the caller wants the native fp32 MFMA)
+        if (g.f32_split != 0) {
             hipLaunchKernelGGL((gemm_nn_kernel<T, ALD, EPI, BNv, SINGLE, true>), grid, dim3(256), 0, s, g);
             DWN_CHECK_LAUNCH();
             return 0;
@@ -801,13 +799,10 @@ template <int ALD, int EPI> struct HasSingle2 {
 };
 
 // LDS-DMA ring variant (SINGLE == 3): one workgroup per CU with a two-k-tile lead instead of two per CU with a one-k-tile lead.
-// DWN_NN_DMA=0 never, =1 whenever eligible; default: when a workgroup has few M-tiles to amortise its k chains over.
+// Used when a workgroup has few M-tiles to amortise its k chains over.
 static bool nn_use_dma(const GemmNN& g, int bn) {
-    static const char* e = getenv("DWN_NN_DMA");
     if (g.K % 64 != 0 || g.K < 128 || (g.epi == EPI_STORE_CAT && g.K1 % 64 != 0)) return false;
-    static const char* er = getenv("DWN_NN_DMA_READOUT");
-    if (g.epi == EPI_READOUT && !(er && er[0] == '1')) return false;   // softplus + transposed fp32 stores: that epilogue wants a second workgroup on the CU
-    if (e) return e[0] == '1';
+    if (g.epi == EPI_READOUT) return false;   // softplus + transposed fp32 stores: that epilogue wants a second workgroup on the CU
     // measured (profiles/r2_gemm_dma.txt): wins 5-16 % on the gated project conv (per-sample weights, K = 448..1792) and on
     // K >= 512 products with at most ~5 tiles per CU; loses where K is four k-tiles (the epilogue dominates) and on the
     // big-M K-concat products
@@ -821,14 +816,12 @@ static int launch_nn_t(const GemmNN& g, hipStream_t s) {
     constexpr int BK = 128 / (int)sizeof(T);
     // the dh3 epilogue keeps four per-column coefficient vectors live: at 128 columns it spills (88-140 B/lane of
     // scratch, measured 2.7 TB/s); the 64-column tile fits (224 VGPRs) and the extra A re-reads stay in the XCD's L2
-    static const bool dh3_wide = getenv("DWN_DH3_WIDE") != nullptr;
-    const bool n64 = g.N <= 64 || (EPI == EPI_DH3 && !dh3_wide);
+    const bool n64 = g.N <= 64 || EPI == EPI_DH3;
     if constexpr (HasSingle<ALD, EPI>::value) {
         if (g.K <= BK) return n64 ? launch_nn_k<T, ALD, EPI, 64, 1>(g, s) : launch_nn_k<T, ALD, EPI, 128, 1>(g, s);
     }
     if constexpr (HasSingle2<ALD, EPI>::value) {
-        static const bool no_s2 = getenv("DWN_NN_NO_S2") != nullptr;
-        if (g.K <= 2 * BK && !g.b_sample_stride && !no_s2)
+        if (g.K <= 2 * BK && !g.b_sample_stride)
             return n64 ? launch_nn_k<T, ALD, EPI, 64, 2>(g, s) : launch_nn_k<T, ALD, EPI, 128, 2>(g, s);
     }
     if constexpr (ALD == LD_PLAIN && TT<T>::IS_BF16) {

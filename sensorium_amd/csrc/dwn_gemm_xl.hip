@@ -282,17 +282,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nn_xl_kernel(const XlArgs g) {
 
 #undef XL_ADV
 
-// shapes this kernel takes over (DWN_NN_XL=0 never, =1 whenever the arguments allow it)
+// shapes this kernel takes over (dwn_gemm_nn_args.variant: DWN_NN_XL128 / DWN_NN_XL256 force it where the arguments allow it)
 bool gemm_nn_xl_eligible(const GemmNN& g, int dtype) {
 #ifdef DWN_DETERMINISTIC
     return false;                                         // the deterministic build keeps to the kernels with ordered reductions
 #endif
-    const char* e = getenv("DWN_NN_XL");                  // read per call: A/B inside one process
-    if (e && e[0] == '0') return false;
+    if (g.variant == DWN_NN_TILE128) return false;
     if (dtype != DWN_BF16 || g.a_kind != LD_PLAIN || g.epi != EPI_STORE || g.b_sample_stride || g.a2) return false;
     if (g.K % 8 || g.N % 8 || g.a.ld % 8 || g.ldb % 8 || g.ldc % 8 || g.M < 1) return false;
     if (((size_t)g.a.p | (size_t)g.b | (size_t)g.c) & 15) return false;
-    if (e && e[0] == '1') return true;
+    if (g.variant == DWN_NN_XL128 || g.variant == DWN_NN_XL256) return true;
     // measured (tools/xl_check.py): wins on the big-M, K = 256 expand convs of the 256-channel blocks (321 -> 222 us at
     // 147456 x 1792 x 256, 80 -> 66 us at 40960 rows); the M = 1024 cortex / readout-gradient shapes stay with the 128x128 kernel
     // (16-75 us there against 20-86 us here: too few tiles to amortise the 256-row pipeline's fill)
@@ -306,8 +305,7 @@ int launch_gemm_nn_xl(const GemmNN& g, hipStream_t s) {
     a.stats = g.stats; a.stat_nchan = g.stat_nchan;
     const i64 ntm = (g.M + 255) / 256;
     const i64 tiles256 = ntm * ((g.N + 255) / 256) * g.groups;
-    const char* fbn = getenv("DWN_NN_XL_BN");
-    const bool wide = fbn ? atoi(fbn) == 256 : tiles256 >= 256;          // enough 256-column tiles to fill the chip
+    const bool wide = g.variant != DWN_NN_AUTO ? g.variant == DWN_NN_XL256 : tiles256 >= 256;      // enough 256-column tiles to fill the chip
     const int grid = 256;                                                 // one workgroup per CU (LDS), a multiple of 8
     if (wide) {
         constexpr size_t lds = 2 * (256 * 128 + 256 * 128) + 2 * 256 * sizeof(float);

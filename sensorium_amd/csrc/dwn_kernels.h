@@ -50,8 +50,8 @@ int k_residual_bwd_dy4(const void* y4, const void* dout, const float* abc4, cons
                        void* dy4, int dtype, hipStream_t s);
 int k_residual_bwd_dx(const LoadDesc& xin, const void* da0, const void* dout, const float* abcsc, const ResGeom& gm,
                       void* dx, int dtype, hipStream_t s);
-int k_se_pool(const LoadDesc& z3, int B, int C, int rows_per_sample, float* pooled, void* z3out, int dtype, hipStream_t s);
-int k_se_mlp_fwd(const float* pooled_sum, float inv_s, const float* wr, const float* br, const float* we,
+int k_se_pool(const LoadDesc& z3, int B, int C, int rows_per_sample, long long* pooled, void* z3out, int dtype, hipStream_t s);
+int k_se_mlp_fwd(const long long* pooled_sum, float inv_s, const float* wr, const float* br, const float* we,
                  const float* be, int B, int C, int R, float* pmean, float* hid_pre, float* gate, hipStream_t s);
 int k_se_mlp_bwd(const float* dg, const float* gate, const float* hid_pre, const float* pmean, const float* wr,
                  const float* we, int B, int C, int R, float inv_s, float* dgp, float* dhp, float* dps, float* dwr,

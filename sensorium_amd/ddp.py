@@ -170,9 +170,6 @@ class GradBuckets:
                 b["flags_dev"].copy_(host, non_blocking=True)
                 b["flags_sent"] = flags
             b["flat"][b["numel"]:].copy_(b["flags_dev"])   # the previous step's reduced tail is overwritten
-        if b["flat"].is_cuda:
-            from .ops import side_join
-            side_join(b["flat"].device)              # gradients still being written on the backward's side stream
         buf = b["flat"]
         if b["comm"] is not None:
             b["comm"].copy_(b["flat"])                   # one rounding to the exchange type

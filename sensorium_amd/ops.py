@@ -57,55 +57,9 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
 
-# ------------------------------------------------------------------------------------------------
-# second stream of the backward pass
-# ------------------------------------------------------------------------------------------------
-# The conv_pw weight gradient of blocks 4-8 (a stand-alone TN GEMM, ~1 ms per step) feeds nothing on the data-gradient
-# chain: it is launched on a side stream behind an event, so it overlaps with the next block's short, latency-bound
-# launches (BatchNorm finalisations, SE MLP, residual passes) instead of standing in front of them.  Consumers of the
-# gradients join first: the end-of-backward callback below, GradBuckets before it starts a bucket's all-reduce, the fused
-# optimizer before it steps.
-# MEASURED (round 3, same box, interleaved runs): 24.67 / 24.80 ms per step on one stream, 25.18 / 27.02 ms with the side
-# stream — the TN GEMM's persistent grid takes CUs and HBM bandwidth from the critical-path kernels it runs beside, which
-# costs more than the idle slots it fills.  So it is OFF by default: DWN_SIDE_STREAM=1 (or set_side_stream(True)) turns it on.
-class _Side:
-    def __init__(self, device):
-        self.stream = torch.cuda.Stream(device=device)
-        self.pending = False
-        self.callback_queued = False
-
-
-_SIDE: dict = {}
-_SIDE_ENABLED = os.environ.get("DWN_SIDE_STREAM", "0") == "1"
-
-
-def set_side_stream(enabled: bool) -> None:
-    global _SIDE_ENABLED
-    _SIDE_ENABLED = bool(enabled)
-
-
-def _side(device) -> Optional[_Side]:
-    if not _SIDE_ENABLED:
-        return None
-    st = _SIDE.get(device.index)
-    if st is None:
-        st = _SIDE[device.index] = _Side(device)
-    return st
-
-
-def side_join(device=None) -> None:
-    """Make the current stream wait for everything queued on the side stream(s) (no-op when nothing is pending)."""
-    for idx, st in _SIDE.items():
-        if st.pending and (device is None or device.index == idx):
-            torch.cuda.current_stream(torch.device("cuda", idx)).wait_stream(st.stream)
-            st.pending = False
-
-
-def _end_of_backward(idx: int) -> None:
-    st = _SIDE.get(idx)
-    if st is not None:
-        st.callback_queued = False
-        side_join(torch.device("cuda", idx))
+# conv_pwl backward implementation forced for a process (the block / model parity tests are re-run under both): "new" =
+# per-sample products + recompute epilogue, "old" = materialised du; unset = the library chooses by shape
+_PWL_BWD = {"": 0, "new": 1, "old": 2}[os.environ.get("DWN_PWL_BWD", "")]
 
 
 def grad_out(param: torch.Tensor, zero: bool = False) -> torch.Tensor:
@@ -359,23 +313,10 @@ class BlockFn(torch.autograd.Function):
         a.dw_pwl = dw_pwl.data_ptr()
         a.dse_wr = dse_wr.data_ptr(); a.dse_br = dse_br.data_ptr(); a.dse_we = dse_we.data_ptr()
         a.dse_be = dse_be.data_ptr()
+        a.pwl_bwd = _PWL_BWD                       # before the workspace is sized: the per-sample path carves B x Cout x Cmid floats
         ws = _ws(L.lib.dwn_block_workspace_bytes(C.byref(a), 1), dev)
         a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
-        side = _side(dev)
-        a.defer_pw_wgrad = int(side is not None)
         L.check(L.lib.dwn_block_backward(C.byref(a), dev.index, _stream(dev)), "dwn_block_backward")
-        if side is not None and L.lib.dwn_block_pw_wgrad_deferred(C.byref(a)):
-            # dW1 on the side stream, behind everything queued so far; its operands must outlive this function on that stream
-            side.stream.wait_stream(torch.cuda.current_stream(dev))
-            L.check(L.lib.dwn_block_backward_pw_wgrad(C.byref(a), dev.index, side.stream.cuda_stream),
-                    "dwn_block_backward_pw_wgrad")
-            for t_ in (buf_a, y1, x, ws, dw_pw):
-                t_.record_stream(side.stream)
-            side.pending = True
-            if not side.callback_queued:
-                side.callback_queued = True
-                idx = dev.index
-                torch.autograd.Variable._execution_engine.queue_callback(lambda: _end_of_backward(idx))
         grads = (dw_pw, dg[0], db[0], dw_dws, dg[1], db[1], dw_dwt, dg[2], db[2], dse_wr, dse_br, dse_we, dse_be,
                  dw_pwl, dg[3], db[3], dg[4], db[4])
         return (dx, None, None, None, None, None, None) + grads

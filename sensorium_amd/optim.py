@@ -103,8 +103,6 @@ class FusedAdamWEma(torch.optim.Optimizer):
             dev = live[0].device
             if not live[0].is_cuda:
                 raise RuntimeError("FusedAdamWEma: parameters must be on a GPU (no CPU fallback)")
-            from .ops import side_join
-            side_join(dev)                           # weight gradients the backward left running on its side stream
             # one launch per distinct step count: parameters a step left without a gradient (the other mice's readouts under
             # forward(x, index), dwiseneuro.py:404-405) are skipped like torch.optim.AdamW skips them, so their bias
             # corrections lag; ordinarily every parameter shares one count and this is a single launch

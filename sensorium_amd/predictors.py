@@ -115,10 +115,9 @@ class Predictor:
         sum is divided by the accumulated blend weights (src/predictors.py:43-55; like the reference, the predictions themselves
         are not multiplied by the blend weights).  Accumulation happens on the device, one pass per window position (frames
         are distinct within a pass: the blend itself is order-independent), one device-to-host copy per trial.
-        Reproducibility: the bf16 eval forward sums the SqueezeExcite pooling with fp32 atomics inside the temporal kernel, so
-        two runs agree to summation order (~1e-6 of the largest prediction in fp32, ~1e-4 in bf16), not bit for bit.  DWN_DETERMINISTIC=1 (the ordered-reduction build of the library,
-        tests/test_gpu_determinism.py) makes predictions bit-reproducible; DWN_EVAL_Z3_OFF=1 alone only moves the pooling to its
-        own pass, whose sums are still added in arrival order."""
+        Reproducibility: the eval forward is bit-reproducible from call to call — the SqueezeExcite pooling sums inside the
+        temporal kernel are 64-bit fixed-point integer adds (any arrival order, same sum) and the blend accumulates in a fixed
+        order."""
         inputs, mouse_index = self._make_inputs(video, behavior, pupil_center, mouse_index)
         gen = self.indexes_generator
         device = self.model.device

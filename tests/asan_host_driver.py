@@ -11,7 +11,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import sensorium_amd._lib as L
 
 lib = L.lib
-assert lib.dwn_abi_version() == 3
+assert lib.dwn_abi_version() == 4
 for cname, struct in L._STRUCTS.items():
     assert lib.dwn_sizeof(cname.encode()) == C.sizeof(struct), cname
 
@@ -36,9 +36,9 @@ for dtype in (L.DWN_F32, L.DWN_BF16):
                         n = lib.dwn_block_workspace_bytes(C.byref(a), bwd)
                         assert n > 0
                     assert lib.dwn_block_forward_writes(C.byref(a)) in (0, 1, 2, 3)
-                    for d in (0, 1):
-                        a.defer_pw_wgrad = d
-                        assert lib.dwn_block_pw_wgrad_deferred(C.byref(a)) in (0, 1)
+                    for mode in (0, 1, 2):       # conv_pwl backward path: by shape / per-sample products / materialised du
+                        a.pwl_bwd = mode
+                        assert lib.dwn_block_workspace_bytes(C.byref(a), 1) > 0
                     lib.dwn_pw_bwd_fused_supported(dtype, B * T * h * w, a.Cmid, a.Cin)
                     calls += 8
             h, w = (h - 1) // st + 1, (w - 1) // st + 1
@@ -69,7 +69,6 @@ a = L.BlockArgs(); a.dtype = L.DWN_BF16; a.B = 2; a.T = 4; a.Hin = 8; a.Win = 16
 a.Cin = 64; a.Cmid = 448; a.Cout = 64; a.stride = 1; a.ks = 3; a.kt = 5; a.se_r = 14; a.training = 1
 expect_error(lib.dwn_block_forward(C.byref(a), 0, None))
 expect_error(lib.dwn_block_backward(C.byref(a), 0, None))
-expect_error(lib.dwn_block_backward_pw_wgrad(C.byref(a), 0, None))
 s = L.StemArgs(); s.dtype = L.DWN_BF16; s.training = 1; s.B = 2; s.Cin = 5; s.C0 = 64; s.S = 128
 expect_error(lib.dwn_stem_forward(C.byref(s), 0, None))
 expect_error(lib.dwn_stem_backward(C.byref(s), 0, None))

@@ -38,7 +38,7 @@ def test_deterministic_build_repeats_training_steps_bit_for_bit(kind):
 
 def test_deterministic_build_repeats_ensemble_predictions_bit_for_bit():
     """Inference (src/predictors.py:36-55 through EnsemblePredictor, eval-mode kernels: the y1-rebuilding stencil, fused
-    temporal pass off in this build, fp32 split products): two predictions of one trial, bf16 and fp32, identical."""
+    temporal pass with integer pooling sums, fp32 split products): two predictions of one trial, bf16 and fp32, identical."""
     r = _run("predict", True)
     assert r["det"] == 1 and r["tensors"] == 2
     assert r["identical"] == 1, f"{r['differing']} of 2 predictions differ between two runs ({r['max_rel']:.2e})"

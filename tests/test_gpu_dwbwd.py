@@ -1,10 +1,9 @@
 """Row-walk spatial depth-wise backward kernels (sensorium_amd/csrc/dwn_dwbwd.hip; reference op: the backward of
-src/models/dwiseneuro.py:96-102) against the kernels they replace, through the C-ABI entry dwn_dw_spatial_bwd with
-DWN_DWS_WALK_OFF toggled per call.  The replaced kernels are pinned to the oracle by tests/test_gpu_block.py; here
+src/models/dwiseneuro.py:96-102) against the library's second implementation (dwn_dw_spatial_bwd_args.impl = 1: the pair /
+generic kernels), through the C-ABI entry dwn_dw_spatial_bwd.  Those kernels are pinned to the oracle by tests/test_gpu_block.py; here
 the two implementations must agree: dh1 BIT-identical (same dot2 order; stride 2 with bf16-representable stencil weights,
 which is what the dot2 kernels see anyway), dW and the BatchNorm-backward sums to summation order / bf16 rounding of z1."""
 import ctypes as C
-import os
 
 import pytest
 import torch
@@ -25,9 +24,8 @@ def _desc(p, ld, **kw):
     return d
 
 
-def _both(planes, Hin, Win, Cc, stride, rows_band=0, seed=0, impl="chain"):
-    """impl: "chain" = the round-3 chained stride-1 kernel (ring of row slots + LDS-DMA y1, the default), "banded" = the
-    round-2 banded row-walk kernel (stride 2 has only the banded kernel)."""
+def _both(planes, Hin, Win, Cc, stride, rows_band=0, seed=0):
+    """"new" = the product kernels (stride 1: chained rows with LDS-DMA y1; stride 2: banded row walk), "old" = impl 1."""
     d = dev()
     s = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device=d); g.manual_seed(seed)
@@ -40,33 +38,20 @@ def _both(planes, Hin, Win, Cc, stride, rows_band=0, seed=0, impl="chain"):
     abc = torch.randn(3 * Cc, device=d, generator=g) * 0.5
     w = (torch.randn(9, Cc, device=d, generator=g) / 3.0).to(BF).float()
     out = {}
-    old_env = os.environ.get("DWN_DWS_WALK_OFF")
-    old_chain = os.environ.get("DWN_DWS_CHAIN")
-    try:
-        for mode in ("old", "new"):
-            os.environ["DWN_DWS_WALK_OFF"] = "1" if mode == "old" else "0"
-            os.environ["DWN_DWS_CHAIN"] = "1" if impl == "chain" else "0"
-            dh1 = torch.full_like(y1, float("nan"))
-            dw = torch.zeros(Cc, 9, device=d)
-            st = torch.zeros(32 * 2 * Cc, dtype=torch.float64, device=d)
-            a = L.DwSpatialBwdArgs()
-            a.dy = _desc(dh2, Cc, q=y2, v1=abc, v2=abc[Cc:], v3=abc[2 * Cc:])
-            a.y1 = _desc(y1, Cc, v1=coef, v2=coef[Cc:], v3=coef[2 * Cc:], v4=coef[3 * Cc:])
-            a.w = w.data_ptr(); a.dh1 = dh1.data_ptr(); a.dw = dw.data_ptr(); a.planes = planes; a.Hin = Hin; a.Win = Win
-            a.Hout = Hout; a.Wout = Wout; a.C = Cc; a.stride = stride; a.ks = 3; a.stats = st.data_ptr()
-            a.rows_band = rows_band if mode == "new" else 0
-            L.check(L.lib.dwn_dw_spatial_bwd(C.byref(a), L.DWN_BF16, d.index, s), "dwn_dw_spatial_bwd")
-            torch.cuda.synchronize()
-            out[mode] = (dh1, dw, st.view(32, 2, Cc).sum(0))
-    finally:
-        if old_env is None:
-            os.environ.pop("DWN_DWS_WALK_OFF", None)
-        else:
-            os.environ["DWN_DWS_WALK_OFF"] = old_env
-        if old_chain is None:
-            os.environ.pop("DWN_DWS_CHAIN", None)
-        else:
-            os.environ["DWN_DWS_CHAIN"] = old_chain
+    for mode in ("old", "new"):
+        dh1 = torch.full_like(y1, float("nan"))
+        dw = torch.zeros(Cc, 9, device=d)
+        st = torch.zeros(32 * 2 * Cc, dtype=torch.float64, device=d)
+        a = L.DwSpatialBwdArgs()
+        a.dy = _desc(dh2, Cc, q=y2, v1=abc, v2=abc[Cc:], v3=abc[2 * Cc:])
+        a.y1 = _desc(y1, Cc, v1=coef, v2=coef[Cc:], v3=coef[2 * Cc:], v4=coef[3 * Cc:])
+        a.w = w.data_ptr(); a.dh1 = dh1.data_ptr(); a.dw = dw.data_ptr(); a.planes = planes; a.Hin = Hin; a.Win = Win
+        a.Hout = Hout; a.Wout = Wout; a.C = Cc; a.stride = stride; a.ks = 3; a.stats = st.data_ptr()
+        a.impl = 1 if mode == "old" else 0
+        a.rows_band = rows_band if mode == "new" else 0
+        L.check(L.lib.dwn_dw_spatial_bwd(C.byref(a), L.DWN_BF16, d.index, s), "dwn_dw_spatial_bwd")
+        torch.cuda.synchronize()
+        out[mode] = (dh1, dw, st.view(32, 2, Cc).sum(0))
     return out["old"], out["new"]
 
 
@@ -79,12 +64,9 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("impl", ["chain", "banded"])
 @pytest.mark.parametrize("case", CASES)
-def test_walk_kernels_match_replaced_kernels(case, impl):
-    if impl == "banded" and case[4] == 2:
-        pytest.skip("stride 2 has one implementation (covered under impl=chain)")
-    (d0, w0, s0), (d1, w1, s1) = _both(*case, impl=impl)
+def test_walk_kernels_match_replaced_kernels(case):
+    (d0, w0, s0), (d1, w1, s1) = _both(*case)
     assert not torch.isnan(d1.float()).any()
     if case[4] == 1:
         assert torch.equal(d0.view(torch.int16), d1.view(torch.int16)), "dh1 differs"
@@ -99,13 +81,10 @@ def test_walk_kernels_match_replaced_kernels(case, impl):
     assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-4
 
 
-@pytest.mark.parametrize("impl", ["chain", "banded"])
 @pytest.mark.parametrize("stride,rows_band", [(1, 1), (1, 2), (1, 4), (1, 7), (2, 2), (2, 4), (2, 6)])
-def test_walk_kernels_band_heights(stride, rows_band, impl):
-    if impl == "banded" and stride == 2:
-        pytest.skip("stride 2 has one implementation")
+def test_walk_kernels_band_heights(stride, rows_band):
     H, W = (18, 32) if stride == 1 else (36, 64)
-    (d0, w0, s0), (d1, w1, s1) = _both(3, H, W, 64, stride, rows_band=rows_band, impl=impl)
+    (d0, w0, s0), (d1, w1, s1) = _both(3, H, W, 64, stride, rows_band=rows_band)
     assert float((d0.float() != d1.float()).float().mean()) < (1e-3 if stride == 2 else 1e-30)
     assert float((w0 - w1).norm() / w0.norm()) < 2e-3
     assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-4

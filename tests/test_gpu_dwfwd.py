@@ -1,9 +1,8 @@
-"""Row-walk spatial depth-wise forward kernels (sensorium_amd/csrc/dwn_dwfwd.hip; reference op src/models/dwiseneuro.py:96-102)
-— the banded round-2 kernel and the chained round-3 kernel (ring of row slots, default) — against the pair kernel they replace,
-through dwn_dw_spatial_fwd with DWN_DWS_WALK_OFF / DWN_DWS_FCHAIN toggled per call: y2 BIT-identical, BatchNorm-2 sums to
-summation order, both strides.  (The pair kernel is pinned to the oracle by tests/test_gpu_block.py.)"""
+"""Chained row-walk spatial depth-wise forward kernels (sensorium_amd/csrc/dwn_dwfwd.hip; reference op
+src/models/dwiseneuro.py:96-102) against the library's second implementation, the pair kernel (dwn_dw_spatial_fwd_args.impl = 1),
+through the C-ABI: y2 BIT-identical, BatchNorm-2 sums to summation order, both strides.  (The pair kernel is pinned to the
+oracle by tests/test_gpu_block.py.)"""
 import ctypes as C
-import os
 
 import pytest
 import torch
@@ -16,7 +15,7 @@ from tests.gpu_helpers import dev  # noqa: E402
 BF = torch.bfloat16
 
 
-def _both(planes, Hin, Win, Cc, stride, rows_band=0, seed=0, impl="chain"):
+def _both(planes, Hin, Win, Cc, stride, rows_band=0, seed=0):
     d = dev()
     s = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device=d); g.manual_seed(seed)
@@ -25,50 +24,39 @@ def _both(planes, Hin, Win, Cc, stride, rows_band=0, seed=0, impl="chain"):
     coef = torch.cat([torch.rand(Cc, device=d, generator=g) + 0.5, torch.randn(Cc, device=d, generator=g) * 0.3])
     w = torch.randn(9, Cc, device=d, generator=g) / 3.0
     out = {}
-    saved = {k: os.environ.get(k) for k in ("DWN_DWS_WALK_OFF", "DWN_DWS_FCHAIN")}
-    try:
-        for mode in ("old", "new"):
-            os.environ["DWN_DWS_WALK_OFF"] = "1" if mode == "old" else "0"
-            os.environ["DWN_DWS_FCHAIN"] = "1" if impl == "chain" else "0"
-            y2 = torch.full((planes * Hout * Wout, Cc), float("nan"), dtype=BF, device=d)
-            st = torch.zeros(32 * 2 * Cc, dtype=torch.float64, device=d)
-            a = L.DwSpatialFwdArgs()
-            di = L.LoadDesc()
-            di.p = x.data_ptr(); di.ld = Cc; di.rows_per_sample = 1; di.v1 = coef.data_ptr(); di.v2 = coef[Cc:].data_ptr(); di.act = 1
-            a.inp = di
-            a.w = w.data_ptr(); a.out = y2.data_ptr(); a.planes = planes; a.Hin = Hin; a.Win = Win; a.Hout = Hout
-            a.Wout = Wout; a.C = Cc; a.stride = stride; a.ks = 3; a.stats = st.data_ptr()
-            a.rows_band = rows_band if mode == "new" else 0
-            L.check(L.lib.dwn_dw_spatial_fwd(C.byref(a), L.DWN_BF16, d.index, s), "dwn_dw_spatial_fwd")
-            torch.cuda.synchronize()
-            out[mode] = (y2, st.view(32, 2, Cc).sum(0))
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    for mode in ("old", "new"):
+        y2 = torch.full((planes * Hout * Wout, Cc), float("nan"), dtype=BF, device=d)
+        st = torch.zeros(32 * 2 * Cc, dtype=torch.float64, device=d)
+        a = L.DwSpatialFwdArgs()
+        di = L.LoadDesc()
+        di.p = x.data_ptr(); di.ld = Cc; di.rows_per_sample = 1; di.v1 = coef.data_ptr(); di.v2 = coef[Cc:].data_ptr(); di.act = 1
+        a.inp = di
+        a.w = w.data_ptr(); a.out = y2.data_ptr(); a.planes = planes; a.Hin = Hin; a.Win = Win; a.Hout = Hout
+        a.Wout = Wout; a.C = Cc; a.stride = stride; a.ks = 3; a.stats = st.data_ptr()
+        a.impl = 1 if mode == "old" else 0
+        a.rows_band = rows_band if mode == "new" else 0
+        L.check(L.lib.dwn_dw_spatial_fwd(C.byref(a), L.DWN_BF16, d.index, s), "dwn_dw_spatial_fwd")
+        torch.cuda.synchronize()
+        out[mode] = (y2, st.view(32, 2, Cc).sum(0))
     return out["old"], out["new"]
 
 
-@pytest.mark.parametrize("impl", ["chain", "banded"])
 @pytest.mark.parametrize("case", [(3, 18, 32, 64, 1), (5, 9, 16, 128, 1), (7, 5, 8, 64, 1), (2, 3, 32, 72, 1), (9, 1, 8, 64, 1),
                                   (1, 20, 16, 64, 1), (130, 9, 16, 448, 1), (131, 5, 8, 448, 1), (1, 2, 32, 64, 1), (4, 7, 8, 200, 1),
                                   # stride 2 (on by default since round 2; same cases as tests/test_gpu_dwbwd.py)
                                   (3, 36, 64, 64, 2), (7, 9, 16, 64, 2), (2, 4, 64, 72, 2), (129, 18, 32, 448, 2), (5, 18, 32, 128, 2),
                                   (9, 1, 16, 64, 2), (3, 7, 32, 64, 2), (3, 5, 16, 64, 2), (130, 9, 16, 448, 2)])
-def test_fwd_walk_matches_pair_kernel(case, impl):
-    (y0, s0), (y1, s1) = _both(*case, impl=impl)
+def test_fwd_walk_matches_pair_kernel(case):
+    (y0, s0), (y1, s1) = _both(*case)
     assert not torch.isnan(y1.float()).any()
     assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
     assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-5
 
 
-@pytest.mark.parametrize("impl", ["chain", "banded"])
 @pytest.mark.parametrize("stride,rows_band", [(1, 1), (1, 2), (1, 4), (1, 7), (2, 1), (2, 2), (2, 3), (2, 4)])
-def test_fwd_walk_band_heights(stride, rows_band, impl):
-    """rows_band = output rows per band (banded) / per chunk (chained: rounded up to a built chunk height)."""
+def test_fwd_walk_band_heights(stride, rows_band):
+    """rows_band = output rows per chunk (rounded up to a built chunk height)."""
     H, W = (18, 32) if stride == 1 else (36, 64)
-    (y0, s0), (y1, s1) = _both(3, H, W, 64, stride, rows_band=rows_band, impl=impl)
+    (y0, s0), (y1, s1) = _both(3, H, W, 64, stride, rows_band=rows_band)
     assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
     assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-5

@@ -34,7 +34,7 @@ def test_temporal_forward_eval_epilogue(dtype, B, T, HW, Cc, kt):
 
     def run(z):
         out = torch.full((M, Cc), float("nan"), device=dev()).to(dtype)
-        pooled = torch.zeros(B, Cc, device=dev())
+        pooled = torch.zeros(B, Cc, dtype=torch.int64, device=dev())      # 64-bit fixed point, units of 2^-32 (include/dwn.h)
         a = L.DwTemporalFwdArgs()
         a.inp = _desc(y2, Cc, v1=coef2, v2=coef2[Cc:], act=1)
         a.w = w.data_ptr(); a.out = out.data_ptr(); a.B = B; a.T = T; a.HW = HW; a.C = Cc; a.kt = kt
@@ -45,14 +45,17 @@ def test_temporal_forward_eval_epilogue(dtype, B, T, HW, Cc, kt):
         return out, pooled
 
     y3, _ = run(False)
-    z3, pooled = run(True)
+    z3, pooled_fix = run(True)
+    _, again = run(True)
+    assert torch.equal(pooled_fix, again), "integer pooling sums must not depend on the arrival order"
+    pooled = pooled_fix.double() / 2.0 ** 32
     h = y3.float() * coef3[:Cc] + coef3[Cc:]
     want = (h * torch.sigmoid(h)).to(dtype)
     # same arithmetic on the same rounded y3; the kernel's sigmoid is exp + rcp (1 ulp-level differences)
     tol = 2e-2 if dtype == torch.bfloat16 else 2e-6
     assert not torch.isnan(z3.float()).any()
     assert float((z3.float() - want.float()).abs().max() / want.float().abs().max()) < tol
-    want_pool = z3.float().view(B, T * HW, Cc).sum(1)            # sums of the values as stored
+    want_pool = z3.double().view(B, T * HW, Cc).sum(1)           # sums of the values as stored
     assert float((pooled - want_pool).abs().max() / want_pool.abs().max()) < 1e-5
     # argument errors: statistics and the eval epilogue exclude each other
     a = L.DwTemporalFwdArgs()

@@ -53,11 +53,9 @@ def test_gemm_nn_plain_with_stats(L, dtype, M, N, K):
 @pytest.mark.parametrize("bn", [128, 256])
 @pytest.mark.parametrize("M,N,K,groups", [(256, 256, 64, 1), (300, 264, 72, 1), (1000, 128, 448, 1), (777, 1000, 200, 1), (257, 24, 8, 1),
                                           (200, 48, 32, 2), (900, 1000, 328, 2), (2100, 1792, 256, 1)])
-def test_gemm_nn_xl_kernel(L, M, N, K, groups, bn, monkeypatch):
+def test_gemm_nn_xl_kernel(L, M, N, K, groups, bn):
     """The 256-row LDS-DMA kernel (dwn_gemm_xl.hip: conv_pw of the 256-channel blocks, src/models/dwiseneuro.py:91) forced onto
     ragged shapes: M / N / K tails, groups, both tile widths, with the BatchNorm sums."""
-    monkeypatch.setenv("DWN_NN_XL", "1")
-    monkeypatch.setenv("DWN_NN_XL_BN", str(bn))
     torch.manual_seed(M + N + K)
     dtype = torch.bfloat16
     a = torch.randn(M, groups * K, device=dev()).to(dtype)
@@ -70,6 +68,7 @@ def test_gemm_nn_xl_kernel(L, M, N, K, groups, bn, monkeypatch):
     g.b = b.data_ptr(); g.ldb = K; g.c = c.data_ptr(); g.ldc = groups * N
     g.M, g.N, g.K, g.groups = M, N, K, groups
     g.stats = st.data_ptr(); g.stat_nchan = groups * N; g.epi = L.EPI_STORE
+    g.variant = L.NN_XL256 if bn == 256 else L.NN_XL128
     L.check(L.lib.dwn_gemm_nn(C.byref(g), _dt(L, dtype), 0, stream()), "gemm_nn")
     torch.cuda.synchronize()
     ref = torch.cat([a[:, i * K:(i + 1) * K].double() @ b[i * N:(i + 1) * N].double().t() for i in range(groups)], 1)

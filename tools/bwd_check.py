@@ -53,7 +53,6 @@ def run(planes, Hin, Win, Cc, stride, rows_band=0, time=True, seed=0):
         w = w.to(BF).float()          # bf16-exact weights: the fp32-weight generic kernel and the dot2 kernels see the same numbers
     res = {}
     for mode in ("old", "new"):
-        os.environ["DWN_DWS_WALK_OFF"] = "1" if mode == "old" else "0"
         dh1 = torch.full_like(y1, float("nan"))
         dw = torch.zeros(Cc, 9, device=dev)
         st = torch.zeros(32 * 2 * Cc, dtype=torch.float64, device=dev)
@@ -62,6 +61,7 @@ def run(planes, Hin, Win, Cc, stride, rows_band=0, time=True, seed=0):
         a.y1 = desc(y1, Cc, v1=coef, v2=coef[Cc:], v3=coef[2 * Cc:], v4=coef[3 * Cc:])
         a.w = w.data_ptr(); a.dh1 = dh1.data_ptr(); a.dw = dw.data_ptr(); a.planes = planes; a.Hin = Hin; a.Win = Win
         a.Hout = Hout; a.Wout = Wout; a.C = Cc; a.stride = stride; a.ks = 3; a.stats = st.data_ptr()
+        a.impl = 1 if mode == "old" else 0
         a.rows_band = rows_band if mode == "new" else 0
 
         def fn():

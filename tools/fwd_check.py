@@ -47,13 +47,13 @@ def run(planes, Hin, Win, Cc, stride, rows_band=0, time=True, seed=0):
     w = torch.randn(9, Cc, device=dev, generator=g) / 3.0
     res = {}
     for mode in ("old", "new"):
-        os.environ["DWN_DWS_WALK_OFF"] = "1" if mode == "old" else "0"
         out = torch.full((planes * Hout * Wout, Cc), float("nan"), dtype=BF, device=dev)
         st = torch.zeros(32 * 2 * Cc, dtype=torch.float64, device=dev)
         a = L.DwSpatialFwdArgs()
         a.inp = desc(x, Cc, v1=coef, v2=coef[Cc:], act=1)
         a.w = w.data_ptr(); a.out = out.data_ptr(); a.planes = planes; a.Hin = Hin; a.Win = Win; a.Hout = Hout
         a.Wout = Wout; a.C = Cc; a.stride = stride; a.ks = 3; a.stats = st.data_ptr()
+        a.impl = 1 if mode == "old" else 0
         a.rows_band = rows_band if mode == "new" else 0
 
         def fn():

@@ -33,13 +33,12 @@ def run(M, N, K, groups=1, stats=True, time=True, seed=0, check=True):
     b = (torch.randn(groups * N, K, device=dev, generator=g_) / K ** 0.5).to(BF)
     res = {}
     for mode in ("base", "xl128", "xl256"):
-        os.environ["DWN_NN_XL"] = "0" if mode == "base" else "1"
-        os.environ["DWN_NN_XL_BN"] = "256" if mode == "xl256" else "128"
         c = torch.full((M, groups * N), float("nan"), dtype=BF, device=dev)
         st = torch.zeros(32 * 2 * groups * N, dtype=torch.float64, device=dev)
         g = L.GemmNNArgs()
         d = L.LoadDesc(); d.p = a.data_ptr(); d.ld = groups * K; d.rows_per_sample = 1
         g.a = d; g.a_kind = L.LD_PLAIN
+        g.variant = {"base": L.NN_TILE128, "xl128": L.NN_XL128, "xl256": L.NN_XL256}[mode]
         g.b = b.data_ptr(); g.ldb = K; g.c = c.data_ptr(); g.ldc = groups * N
         g.M, g.N, g.K, g.groups = M, N, K, groups
         if stats:
