@@ -139,16 +139,17 @@ def lib_sha16():
 
 def cpu_baseline(frames, height, width, expansion):
     """The CPU oracle (a port: oracle/dwiseneuro_oracle.py, pinned to the reference by tests/golden) timed on this host on a
-    BOUNDED sample of the benchmark workload, following BASELINE.md section 2: fwd + loss + bwd of B=2 clips at the
-    benchmark's T, HxW and width, fp32, all host cores (capped at 32: more only adds contention at these sizes), three
-    warm-up steps (one tiny, two full), then the MEDIAN of five timed steps (CPU step time drifts run to run).
-    B=2 instead of the largest batch that fits keeps the sample at ~20-25 s on the GPU box's host (B=4: ~50 s)."""
+    BOUNDED sample of the benchmark workload, following BASELINE.md section 2: fwd + loss + bwd of B=4 clips (the largest
+    batch that plan names: ~13 GB of host memory) at the benchmark's T, HxW and width, fp32, all host cores (capped at 32:
+    more only adds contention at these sizes).  Warm-ups: one tiny, one at a quarter of the frames (timed, to size the
+    sample), one at the timed size; then the MEDIAN of three full-length steps when one stays under ~12 s (about 30-40 s of
+    CPU work in all), else of five quarter-length steps (the path is linear in T)."""
     from oracle import dwiseneuro_oracle as orc
     import numpy as np
     orc.DW_IMPL = "library"        # depth-wise convs through torch's conv3d, like the reference's CPU path
     threads = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
-    bsz = 2
+    bsz = 4
     sd = orc.make_state_dict(readout_outputs=(NUM_NEURONS_MOUSE0,), expansion_ratio=expansion, seed=0)
     sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and "inv_freq" not in k
               else v) for k, v in sd.items()}
@@ -167,26 +168,39 @@ def cpu_baseline(frames, height, width, expansion):
 
     step(2)                                    # warm-up 1: thread pool, allocator
     t_q = max(4, frames // 4)
-    step(t_q)                                  # warm-up 2
     t0 = time.perf_counter()
-    step(t_q)                                  # warm-up 3, timed to size the sample
+    step(t_q)                                  # warm-up 2, timed to size the sample
     quarter = time.perf_counter() - t0
-    # full clips when a step stays under ~5 s (five timed steps + warm-ups within the bounded sample), else a quarter of
-    # the frames (the path is linear in T)
-    t_s = frames if quarter * (frames / t_q) < 5.0 else t_q
-    if t_s != t_q:
-        step(t_s)                              # one more warm-up at the timed size
+    full = quarter * (frames / t_q) < 12.0
+    t_s, n_timed = (frames, 3) if full else (t_q, 5)
+    step(t_s)                                  # warm-up 3 at the timed size
     times = []
-    for _ in range(5):
+    for _ in range(n_timed):
         t0 = time.perf_counter()
         step(t_s)
         times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
     return {"value": round(bsz * (t_s / frames) / med, 4), "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": f"median of 5 fwd+loss+bwd steps (after 3 warm-ups) of the CPU oracle on B={bsz} clips, {t_s} of "
-                      f"{frames} frames, {height}x{width}, expansion {expansion}, 1 readout, fp32, torch "
-                      f"{torch.__version__}, mkldnn={torch.backends.mkldnn.is_available()}; step times "
-                      f"{min(times):.2f}-{max(times):.2f} s; scaled to full clips"}
+            "sample": f"median of {n_timed} fwd+loss+bwd steps (after 3 warm-ups) of the CPU oracle on B={bsz} clips (BASELINE.md "
+                      f"section 2: the largest batch its plan names), {t_s} of {frames} frames, {height}x{width}, expansion "
+                      f"{expansion}, 1 readout, fp32, torch {torch.__version__}, mkldnn={torch.backends.mkldnn.is_available()}; "
+                      f"step times {min(times):.2f}-{max(times):.2f} s; scaled to full clips"}
+
+
+def other_config(extra):
+    """One more workload of BASELINE.json `configs` through this same script as a child process (never an exec), condensed."""
+    import subprocess
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-inference",
+           "--no-rooflines", "--no-fwd-bwd", "--no-other-configs", *extra]
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+    except Exception as e:                      # reported, not fatal: the metric line must still be printed
+        return {"error": f"{type(e).__name__}: {e}"}
+    r = d.get("roofline") or {}
+    return {"workload": d["config"]["workload"], "ms_per_step": d["ms_per_step"], "clips_per_s": d["value"], "steps": d["steps"],
+            "loss": d.get("loss"), "dominant_family": r.get("kernel"), "frac": r.get("frac"), "achieved_gbs": r.get("achieved")}
 
 
 def self_launch(n, argv):
@@ -249,6 +263,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inference", action="store_true", help="skip the 7-fold sliding-window inference leg (BASELINE.json "
                     "configs[4]) that runs after the timed training region")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE.json configs[2] / configs[3] legs (ten readouts; "
+                    "distillation step) that run as child processes after the timed region")
     ap.add_argument("--no-rooflines", action="store_true", help="skip the extra untimed steps that time every kernel family")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel family (adds event overhead)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU testing)")
@@ -491,17 +507,21 @@ def main():
             out["family_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in fam_ms.items()}
         elif fam_all:
             out["family_ms_per_step"] = {k: round(v[0] / prof_steps, 3) for k, v in fam_all.items()}
-        if world == 1 and not args.no_inference and default_shape:
-            # BASELINE.json configs[4] (scripts/predict.py:44-50 + src/predictors.py:36-55): after the timed region, the
-            # training model freed; fp32 is the reference's prediction precision (src/argus_models.py:89-99)
-            del model, batch0, last
+        if world == 1 and default_shape and not (args.no_inference and args.no_other_configs):
+            del model, batch0, last            # the legs below run after the timed region, on a freed device
             torch.cuda.empty_cache()
+        if world == 1 and not args.no_inference and default_shape:
+            # BASELINE.json configs[4] (scripts/predict.py:44-50 + src/predictors.py:36-55); fp32 is the reference's prediction
+            # precision (src/argus_models.py:89-99)
             sys.path.insert(0, str(ROOT / "tools"))
             from bench_predict import ensemble_bench
             inf = {"workload": "7-fold ensemble, one 300-frame trial at 64x64, window 16 step 2 (270 windows), 90 windows per "
                                "forward (three exact batches; the reference runs one window per forward, predictors.py:46-54 — "
                                "the batch size does not change the result), all folds in one captured hipGraph per window batch, "
                                "blend on the device",
+                   "fp32_products": "bf16x3 (the default of DwiseNeuro.set_fp32_eval_products: every fp32 GEMM operand split into bf16 "
+                                    "hi + lo, three bf16 MFMAs with fp32 accumulation; 5.8e-7 relative L2 from the native fp32 MFMA "
+                                    "on the full-width eval forward; 'native' selects v_mfma_f32_16x16x4_f32)",
                    "hbm_frac_is": "bytes the eval-mode pass structure executes (tools/bench_predict.py::eval_executed_bytes) "
                                   "/ time / 8 TB/s"}
             for dt_ in ("bf16", "fp32"):
@@ -515,6 +535,16 @@ def main():
                 except ValueError:
                     pass
             out["inference"] = inf
+        if world == 1 and not args.no_other_configs and default_shape:
+            # BASELINE.json configs[2] and configs[3] on this one GPU (their 8-GPU form is the same step per rank + the gradient
+            # exchange): each as a fresh child process of this script, same shape and dtype, 10 timed steps
+            torch.cuda.empty_cache()
+            out["other_configs"] = {
+                "ten_readouts": other_config(["--mice", "10"]),
+                "distillation": other_config(["--mice", "10", "--distill"]),
+                "note": "NOT the metric config: same clip shape / dtype / step definition with the ten per-mouse readouts of "
+                        "src/constants.py:38 (configs[2]) and the configs/distillation_001.py step (configs[3]); frac = the "
+                        "dominant kernel family's HBM fraction in that run"}
         if world == 1 and not args.no_cpu_baseline and args.mice == 1 and not args.distill:
             out["cpu_baseline"] = cpu_baseline(args.frames, args.height, args.width, args.expansion)
         print(json.dumps(out), flush=True)

@@ -31,6 +31,13 @@ extern "C" {
 #define DWN_ABI_VERSION 4
 #define DWN_F32 0
 #define DWN_BF16 1
+/* How the dtype-f32 GEMMs of a block / cortex layer / readout multiply.  NATIVE: v_mfma_f32_16x16x4_f32.  SPLIT3: each operand
+ * as bf16 hi + lo, three bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate): 5.8e-7 relative L2 from NATIVE on the full-width
+ * eval forward, a sixth of the matrix-core time.  AUTO: SPLIT3 in the eval-mode forward, NATIVE in training (where the
+ * analytically-zero gradients' summation noise would otherwise exceed the parity tests' floors). */
+#define DWN_F32_AUTO 0
+#define DWN_F32_NATIVE 1
+#define DWN_F32_SPLIT3 2
 #define DWN_NREP 32 /* replicas of every cross-workgroup statistics buffer: double[DWN_NREP][2][C] */
 
 /* operand loader kinds (how a kernel reads one 16-byte channel vector of an operand) */
@@ -229,6 +236,7 @@ typedef struct dwn_block_args {
      * recomputes du in its epilogue and (2) the materialised du = dy4 . W2 with a separate reduction pass; 1 / 2 force one
      * (the parity tests run both implementations against the oracle) */
     int pwl_bwd;
+    int f32_products;                        /* DWN_F32_AUTO / _NATIVE / _SPLIT3: how dtype f32 multiplies (see below) */
 } dwn_block_args;
 
 /* AdaptiveAvgPool3d((None,1,1)) — dwiseneuro.py:374,400 */
@@ -248,6 +256,7 @@ typedef struct dwn_cortex_args {
     const void* dout; void* dx; float* dw;  /* backward */
     const float* dout_mask; int dout_mask_ld; /* optional [B][C] multiplier on dout (readout Dropout1d backward) */
     void* ws; size_t ws_bytes;
+    int f32_products;                         /* DWN_F32_AUTO / _NATIVE / _SPLIT3 */
 } dwn_cortex_args;
 
 /* Readout — dwiseneuro.py:283-287 */
@@ -265,6 +274,7 @@ typedef struct dwn_readout_args {
      * fp32 weight for both).  Non-null in backward: used as is — the caller kept it from the forward of the same step —
      * instead of packing the weight again. */
     void* wt;
+    int f32_products;                       /* DWN_F32_AUTO (= native here: the readout has no training flag) / _NATIVE / _SPLIT3 */
 } dwn_readout_args;
 
 typedef struct dwn_tensor_entry {

@@ -35,6 +35,7 @@ DWN_NREP = 32
 LD_PLAIN, LD_PE, LD_BNACT, LD_AFFINE2, LD_DY3, LD_GATE = 0, 1, 2, 3, 4, 5
 EPI_STORE, EPI_READOUT, EPI_DG, EPI_STORE_CAT, EPI_DH3 = 0, 1, 2, 3, 4
 NN_AUTO, NN_XL128, NN_XL256, NN_TILE128 = 0, 1, 2, 3
+F32_AUTO, F32_NATIVE, F32_SPLIT3 = 0, 1, 2
 FAMILIES = ("pw_fwd", "dws_fwd", "dwt_fwd", "se_pool", "pwl_fwd", "resid_fwd", "resid_bwd", "pwl_dgrad", "pwl_wgrad",
             "bn3_reduce", "dwt_bwd", "dws_bwd", "pw_dgrad", "pw_wgrad", "cortex_fwd", "cortex_bwd", "readout_fwd",
             "readout_bwd")
@@ -116,7 +117,7 @@ class BlockArgs(C.Structure):
                 ("dout", c_p), ("dx", c_p), ("buf_a", c_p), ("buf_b", c_p), ("dy4", c_p), ("da0", c_p),
                 ("dw_pw", c_p), ("dw_dws", c_p), ("dw_dwt", c_p), ("dw_pwl", c_p), ("dse_wr", c_p),
                 ("dse_br", c_p), ("dse_we", c_p), ("dse_be", c_p),
-                ("ws", c_p), ("ws_bytes", c_sz), ("pwl_bwd", c_i)]
+                ("ws", c_p), ("ws_bytes", c_sz), ("pwl_bwd", c_i), ("f32_products", c_i)]
 
 
 class PoolArgs(C.Structure):
@@ -128,13 +129,14 @@ class CortexArgs(C.Structure):
     _fields_ = [("dtype", c_i), ("training", c_i), ("B", c_i), ("T", c_i), ("Cin", c_i), ("C", c_i),
                 ("groups", c_i), ("eps", c_f), ("momentum", c_f), ("x", c_p), ("out", c_p), ("y", c_p),
                 ("w", c_p), ("bn", BN), ("bnsc", BN), ("drop_scale", c_p), ("dout", c_p), ("dx", c_p),
-                ("dw", c_p), ("dout_mask", c_p), ("dout_mask_ld", c_i), ("ws", c_p), ("ws_bytes", c_sz)]
+                ("dw", c_p), ("dout_mask", c_p), ("dout_mask_ld", c_i), ("ws", c_p), ("ws_bytes", c_sz), ("f32_products", c_i)]
 
 
 class ReadoutArgs(C.Structure):
     _fields_ = [("dtype", c_i), ("B", c_i), ("T", c_i), ("Cin", c_i), ("groups", c_i), ("n_out", c_i),
                 ("softplus_beta", c_f), ("x", c_p), ("w", c_p), ("bias", c_p), ("drop_mask", c_p), ("out", c_p),
-                ("dout", c_p), ("dx", c_p), ("dw", c_p), ("dbias", c_p), ("ws", c_p), ("ws_bytes", c_sz), ("wt", c_p)]
+                ("dout", c_p), ("dx", c_p), ("dw", c_p), ("dbias", c_p), ("ws", c_p), ("ws_bytes", c_sz), ("wt", c_p),
+                ("f32_products", c_i)]
 
 
 class TensorEntry(C.Structure):

@@ -214,6 +214,12 @@ class MouseModel(Model):
             if self.model_ema is not None:
                 self.buckets.gather_ema()
 
+    def needs_sync(self) -> bool:
+        """Sharded optimizer: True while this rank's copy of the parameters / EMA network is incomplete, i.e. until EVERY
+        rank has called ``sync_for_read()`` after the last training step."""
+        b = self.buckets
+        return b is not None and b.shard and (b.ema_dirty or bool(b._param_handles))
+
     def _eval_module(self):
         self.sync_for_read()
         return self.nn_module if self.model_ema is None else self.model_ema.ema

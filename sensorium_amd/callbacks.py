@@ -127,8 +127,18 @@ class Checkpoint(Callback):
         import torch.distributed as dist
         return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
 
+    @staticmethod
+    def _sync_all_ranks(state: State):
+        """Sharded optimizer: the parameter / EMA slices other ranks own arrive by all-gather — a collective, so it runs here,
+        on EVERY rank, before the writer-only part (a rank-0-only gather would hang or pair up with the other ranks' next
+        reduce-scatter)."""
+        sync = getattr(state.model, "sync_for_read", None)
+        if sync is not None:
+            sync()
+
     def save_checkpoint(self, state: State):
         file_path = self._format_file_path(state)
+        self._sync_all_ranks(state)
         if not self._is_writer():                 # data parallel: parameters are identical, rank 0 writes
             return
         self.dir_path.mkdir(parents=True, exist_ok=True)
@@ -154,6 +164,12 @@ class Checkpoint(Callback):
 
     def catch_exception(self, state: State):
         if self.save_after_exception and self._is_writer():
+            needs = getattr(state.model, "needs_sync", None)
+            if needs is not None and needs():
+                # an exception is not known to have reached every rank: no collective from here
+                state.logger.warning("Checkpoint: model not saved after the exception — the sharded optimizer's slices are "
+                                     "spread over the ranks and gathering them needs every rank")
+                return
             exc = type(state.exception).__name__
             self.save_model(state, self.dir_path / f"model-{state.epoch:03d}-{exc}.pth")
 

@@ -211,6 +211,11 @@ BlockWs carve_block(const dwn_block_args& a, int backward, void* base, size_t ca
     return w;
 }
 
+// dwn.h DWN_F32_*: does this fp32 GEMM run as three bf16 products?
+static inline int f32_split_of(int policy, bool eval_forward) {
+    return policy == DWN_F32_SPLIT3 ? 1 : policy == DWN_F32_NATIVE ? 0 : (eval_forward ? 1 : 0);
+}
+
 ResGeom geom_of(const dwn_block_args& a) {
     ResGeom gm;
     gm.BT = a.B * a.T; gm.T = a.T; gm.Hin = a.Hin; gm.Win = a.Win; gm.Hout = a.Hout; gm.Wout = a.Wout;
@@ -406,7 +411,7 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     } else {
     {
         GemmNN g = nn_base(xin, LD_PLAIN, w.wpw, a.Cin, a.y1, a.Cmid, (int)Min, a.Cmid, a.Cin, 1);
-        g.f32_split = !tr;                 // eval-mode fp32: bf16 hi/lo products (dwn_gemm.hip NN_F32_X3); training keeps the fp32 MFMA
+        g.f32_split = f32_split_of(a.f32_products, !tr);      // eval-mode fp32: bf16 hi/lo products (dwn_gemm.hip NN_F32_X3) unless NATIVE
         g.stats = tr ? w.st1 : nullptr; g.stat_nchan = a.Cmid;
         PROF(DWN_FAM_PW_FWD, launch_gemm_nn(g, dt, s));
     }
@@ -447,13 +452,13 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
         TRY(k_gate_weights(a.w_pwl, a.se_gate, w.wgated, a.B, a.Cout, a.Cmid, dt, s));
         GemmNN g = nn_base(ld_plain(a.z3, a.Cmid), LD_PLAIN, w.wgated, a.Cmid, a.y4, a.Cout, (int)Mout, a.Cout, a.Cmid, 1);
         g.b_sample_stride = (i64)a.Cout * a.Cmid; g.b_rows_per_sample = S_out;
-        g.stats = tr ? w.st4 : nullptr; g.stat_nchan = a.Cout; g.f32_split = !tr;
+        g.stats = tr ? w.st4 : nullptr; g.stat_nchan = a.Cout; g.f32_split = f32_split_of(a.f32_products, !tr);
         PROF(DWN_FAM_PWL_FWD, launch_gemm_nn(g, dt, s));
     } else {
         LoadDesc u = ld_plain(a.z3, a.Cmid);
         u.gate = a.se_gate; u.gate_ld = a.Cmid; u.rows_per_sample = S_out;
         GemmNN g = nn_base(u, LD_GATE, w.wpwl, a.Cmid, a.y4, a.Cout, (int)Mout, a.Cout, a.Cmid, 1);
-        g.stats = tr ? w.st4 : nullptr; g.stat_nchan = a.Cout; g.f32_split = !tr;
+        g.stats = tr ? w.st4 : nullptr; g.stat_nchan = a.Cout; g.f32_split = f32_split_of(a.f32_products, !tr);
         PROF(DWN_FAM_PWL_FWD, launch_gemm_nn(g, dt, s));
     }
     // shortcut (:125-134) + residual (:143); the two linear BatchNorms (conv_pwl.1.bn, bn_sc.bn) finalise in one launch
@@ -662,7 +667,7 @@ int dwn_cortex_forward(const dwn_cortex_args* ap, int device, void* stream) {
         TRY(k_prep(pa, dt, s));
     }
     GemmNN g = nn_base(ld_plain(a.x, a.Cin), LD_PLAIN, w.wp, Kg, a.y, a.C, M, Ng, Kg, a.groups);
-    g.stats = tr ? w.st : nullptr; g.stat_nchan = a.C; g.f32_split = !tr;
+    g.stats = tr ? w.st : nullptr; g.stat_nchan = a.C; g.f32_split = f32_split_of(a.f32_products, !tr);
     PROF(DWN_FAM_CORTEX_FWD, launch_gemm_nn(g, dt, s));
     if (tr) {
         TRY(k_colstats(ld_plain(a.x, a.Cin), LD_PLAIN, M, a.Cin, w.stsc, dt, s));
@@ -755,7 +760,7 @@ int dwn_readout_forward(const dwn_readout_args* ap, int device, void* stream) {
     }
     GemmNN g = nn_base(x, kind, w.wp, w.ldp, nullptr, 0, M, w.Rg, Kg, a.groups);
     g.epi = EPI_READOUT; g.bias = a.bias; g.sp_beta = a.softplus_beta; g.out_nct = a.out; g.Tn = a.T; g.n_valid = a.n_out;
-    g.f32_split = a.wt == nullptr && a.drop_mask == nullptr;      // no backward will follow (the caller kept no transposed pack): inference
+    g.f32_split = f32_split_of(a.f32_products, false);            // the caller says (it knows whether this is an inference forward)
     PROF(DWN_FAM_READOUT_FWD, launch_gemm_nn(g, dt, s));
     return 0;
 }

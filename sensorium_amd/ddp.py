@@ -215,6 +215,7 @@ class GradBuckets:
                 # autograd produced / accumulated this gradient in a tensor of its own: move it into the bucket
                 view.copy_(g)
                 param.grad = view
+            param._dwn_slot_out = False          # ops.grad_out hands the slot out once per backward pass
             b["arrived"][i] = True
             b["pending"] -= 1
             if b["pending"] == 0 and not b["optional"]:
@@ -233,6 +234,7 @@ class GradBuckets:
             b["arrived"] = [False] * b["count"]
             for p in b["params"]:
                 p.grad = None
+                p._dwn_slot_out = False
 
     def finish(self):
         """Wait for the outstanding all-reduces (call after backward, before the optimizer step); afterwards every

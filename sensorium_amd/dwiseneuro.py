@@ -309,6 +309,7 @@ class DwiseNeuro(nn.Module):
                  compute_dtype: Optional[torch.dtype] = None):
         super().__init__()
         self.compute_dtype = compute_dtype
+        self.fp32_eval_products = "bf16x3"     # see set_fp32_eval_products
         self.core = DepthwiseCore(in_channels=in_channels, features=core_features, spatial_strides=spatial_strides,
                                   spatial_kernel=spatial_kernel, temporal_kernel=temporal_kernel,
                                   expansion_ratio=expansion_ratio, se_reduce_ratio=se_reduce_ratio,
@@ -320,6 +321,21 @@ class DwiseNeuro(nn.Module):
         for n in readout_outputs:
             self.readouts.append(Readout(in_features=cortex_features[-1], out_features=n, groups=groups,
                                          softplus_beta=softplus_beta, drop_rate=drop_rate))
+
+    def set_fp32_eval_products(self, mode: str = "bf16x3") -> "DwiseNeuro":
+        """How the fp32 path multiplies in the EVAL-mode forward (val_step / predict run fp32, src/argus_models.py:73-99).
+        ``"bf16x3"`` (default): every fp32 GEMM operand is split into bf16 hi + lo and multiplied as hi*hi + hi*lo + lo*hi on
+        the bf16 matrix cores with fp32 accumulation — 5.8e-7 relative L2 (max 4e-6) from the native products on the full-width
+        model, a sixth of the matrix-core time.  ``"native"``: ``v_mfma_f32_16x16x4_f32`` everywhere, so training-mode and
+        eval-mode fp32 forwards of the same weights agree to fp32 rounding.  Training always uses the native products.
+        (C-ABI: ``f32_products`` of dwn_block_args / dwn_cortex_args / dwn_readout_args.)"""
+        if mode not in ("bf16x3", "native"):
+            raise ValueError("fp32 eval products: 'bf16x3' or 'native'")
+        self.fp32_eval_products = mode
+        for m in self.modules():
+            if isinstance(m, (InvertedResidual3d, ShuffleLayer, Readout)):
+                m._dwn_fp32_native = mode == "native"
+        return self
 
     def _draw_drop_paths(self, batch: int, device) -> None:
         """One uniform draw for every stochastic-depth layer of this forward pass (12 layers: 4 small launches instead

@@ -47,9 +47,7 @@ class EmaCheckpoint(Checkpoint):
     ``{'model_name', 'params', 'nn_state_dict'}`` so ``load_model`` / the predictor read it back unchanged."""
 
     def save_model(self, state, file_path):
-        sync = getattr(state.model, "sync_for_read", None)
-        if sync is not None:
-            sync()                       # sharded optimizer: EMA slices of the readouts gathered from their owners
+        state.model._require_synced("EmaCheckpoint.save_model")    # the gather ran on all ranks in Checkpoint.save_checkpoint
         nn_module = state.model.model_ema.ema
         torch.save({"model_name": type(state.model).__name__, "params": state.model.params,
                     "nn_state_dict": {k: v.detach().to("cpu") for k, v in nn_module.state_dict().items()}},

@@ -311,16 +311,28 @@ class Model:
         return dict(eng.run(val_loader, 0, 1).metrics)
 
     # -- persistence (argus file format: ema.py:63-72) -------------------------------------------------------
+    def _require_synced(self, what: str):
+        """Writing is rank-local (usually rank 0 alone), so it must not start a collective.  With the sharded optimizer the
+        slices other ranks own arrive through ``sync_for_read()``, which EVERY rank has to call first (``Checkpoint`` does,
+        on all ranks, before its writer-only part)."""
+        needs = getattr(self, "needs_sync", None)
+        if needs is not None and needs():
+            raise RuntimeError(f"{what}: with the sharded optimizer (ddp_shard_optimizer) call model.sync_for_read() on EVERY "
+                               "rank after the last training step, then save on the writer rank")
+
     def state_dict_for_save(self):
-        sync = getattr(self, "sync_for_read", None)
-        if sync is not None:
-            sync()
+        self._require_synced("state_dict_for_save")
         return {k: v.detach().to("cpu") for k, v in self.nn_module.state_dict().items()}
 
     def save(self, file_path, optimizer_state: bool = False):
         state = {"model_name": type(self).__name__, "params": self.params,
                  "nn_state_dict": self.state_dict_for_save()}
         if optimizer_state and self.optimizer is not None:
+            buckets = getattr(self, "buckets", None)
+            if buckets is not None and buckets.shard:
+                raise RuntimeError("save(optimizer_state=True): the sharded optimizer keeps only this rank's 1/N slice of the readout "
+                                   "moments; a checkpoint of it would silently drop the rest — save without optimizer state "
+                                   "(the reference never stores it, src/ema.py:67-72) or train with ddp_shard_optimizer off")
             state["optimizer_state_dict"] = self.optimizer.state_dict()
         Path(file_path).parent.mkdir(parents=True, exist_ok=True)
         torch.save(state, str(file_path))

@@ -53,6 +53,16 @@ def _check_bn(bn):
         raise RuntimeError("sensorium_amd: BatchNorm must be affine with running stats and a fixed momentum")
 
 
+def _f32_products(mod, inference_readout: bool = False) -> int:
+    """How this module's fp32 GEMMs multiply (include/dwn.h DWN_F32_*).  ``DwiseNeuro.set_fp32_eval_products`` stamps the
+    choice on its sub-modules: "bf16x3" (default: eval-mode forward as three bf16 products, 5.8e-7 from native; training always
+    native) or "native" (fp32 MFMA everywhere)."""
+    native = getattr(mod, "_dwn_fp32_native", False)
+    if inference_readout:               # the readout's C struct has no training flag: the caller says what this forward is
+        return L.F32_NATIVE if native else L.F32_SPLIT3
+    return L.F32_NATIVE if native else L.F32_AUTO
+
+
 def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
@@ -69,7 +79,11 @@ def grad_out(param: torch.Tensor, zero: bool = False) -> torch.Tensor:
     gradient is already being accumulated (``param.grad`` set: argus ``iter_size`` > 1) or no bucket exists, a new tensor in
     the parameter's own shape (same memory layout as the kernels' 2-D views, so autograd can take ownership)."""
     slot = getattr(param, "_dwn_grad_slot", None)
-    if slot is not None and param.grad is None:
+    if slot is not None and param.grad is None and not getattr(param, "_dwn_slot_out", False):
+        # handed out ONCE per backward pass: a second producer of the same parameter's gradient (a module applied twice, two
+        # forwards summed into one loss) gets a tensor of its own — two kernels writing the same slot before AccumulateGrad
+        # adds them would leave 2x the last contribution.  GradBuckets' hook clears the mark when the gradient has arrived.
+        param._dwn_slot_out = True
         flat, off = slot
         g = flat[off:off + param.numel()].view(param.shape)
         return g.zero_() if zero else g
@@ -210,6 +224,7 @@ def _block_args(blk, geom, x, dtype, training, coefs, saved, drop_scale, x_has_p
     a.drop_scale = _ptr(drop_scale)
     a.se_pmean = saved["pmean"].data_ptr(); a.se_hidpre = saved["hidpre"].data_ptr()
     a.se_gate = saved["gate"].data_ptr()
+    a.f32_products = _f32_products(blk)
     return a
 
 
@@ -376,6 +391,7 @@ class CortexFn(torch.autograd.Function):
         a.groups = layer.groups; a.eps = bn.eps; a.momentum = bn.momentum
         a.x = x.data_ptr(); a.out = out.data_ptr(); a.y = y.data_ptr(); a.w = weight.data_ptr()
         a.bn = _bn_struct(bn, coef); a.bnsc = _bn_struct(bnsc, coefsc); a.drop_scale = _ptr(drop_scale)
+        a.f32_products = _f32_products(layer)
         ws = _ws(L.lib.dwn_cortex_workspace_bytes(C.byref(a), 0), dev)
         a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
         L.check(L.lib.dwn_cortex_forward(C.byref(a), dev.index, _stream(dev)), "dwn_cortex_forward")
@@ -436,6 +452,8 @@ class ReadoutFn(torch.autograd.Function):
         a.softplus_beta = mod.softplus_beta
         a.x = x.data_ptr(); a.w = weight.data_ptr(); a.bias = bias.data_ptr(); a.drop_mask = _ptr(drop_mask)
         a.out = out.data_ptr()
+        # eval-mode forward (the module is not training; a no_grad forward of a training module keeps the training numerics)
+        a.f32_products = _f32_products(mod, inference_readout=True) if not mod.training else L.F32_NATIVE
         # a backward will follow: the pack pass also writes the weight in the data gradient's layout and backward reuses it
         # (the optimizer only touches the weight after backward)
         wt = None

@@ -50,11 +50,13 @@ def get_blend_weights(name: str, size: int) -> np.ndarray:
 class Predictor:
     def __init__(self, model, device: str = "cuda:0", blend_weights: str = "ones", *, frame_stack_size: Optional[int] = None,
                  frame_stack_step: Optional[int] = None, position: str = "last", windows_per_batch: int = 32,
-                 use_graph: bool = False):
+                 use_graph: bool = False, fp32_products: Optional[str] = None):
         """``model``: a checkpoint path — the reference's constructor ``Predictor(model_path, device, blend_weights)``
         (src/predictors.py:22-34: ``load_model(path, device=device, optimizer=None, loss=None)``, frame stack and inputs
         processor read from the stored params) — or an already built ``MouseModel`` together with ``frame_stack_size`` /
         ``frame_stack_step``.
+        ``fp32_products``: ``"native"`` / ``"bf16x3"`` — how an fp32 model multiplies in this predictor's forwards
+        (``DwiseNeuro.set_fp32_eval_products``; ``None`` keeps the model's setting, whose default is "bf16x3").
         ``windows_per_batch``: windows evaluated per forward (1 = the reference's launch pattern).
         ``use_graph``: capture the eval forward of one full window batch into a hipGraph (torch.cuda.CUDAGraph) per
         (mouse, shape) and replay it — the C-ABI neither allocates nor synchronises, so the ~500 launches of one
@@ -80,6 +82,10 @@ class Predictor:
             frame_stack_size, frame_stack_step = frame_stack_size or 16, frame_stack_step or 2
         self.model = model
         self.model.eval()
+        if fp32_products is not None:
+            for net in (self.model.nn_module, getattr(getattr(self.model, "model_ema", None), "ema", None)):
+                if net is not None:
+                    net.set_fp32_eval_products(fp32_products)
         self.use_graph = bool(use_graph)
         self._graphs: dict = {}
         self.frame_stack_size, self.frame_stack_step = int(frame_stack_size), int(frame_stack_step)

@@ -243,3 +243,35 @@ def test_deterministic_build_of_the_library_loads_and_matches_the_abi():
         assert det.dwn_sizeof(cname.encode()) == C.sizeof(struct), cname
     for name in L.SYMBOLS:
         assert hasattr(det, name), name
+
+
+def test_grad_out_hands_a_bucket_slot_out_once_per_backward():
+    """ops.grad_out: the first producer of a parameter's gradient writes into the parameter's all-reduce bucket slot, a second
+    one in the same backward pass (a module applied twice) gets a tensor of its own — autograd then adds two different buffers
+    instead of two aliases of one (round-3 advisor finding)."""
+    import torch
+    from sensorium_amd import ops
+    p = torch.nn.Parameter(torch.zeros(3, 4))
+    flat = torch.zeros(32)
+    p._dwn_grad_slot = (flat, 8)
+    g1 = ops.grad_out(p)
+    g2 = ops.grad_out(p, zero=True)
+    assert g1.data_ptr() == flat[8:].data_ptr() and g1.shape == p.shape
+    assert g2.data_ptr() != g1.data_ptr() and not g2.any()
+    p._dwn_slot_out = False                     # what GradBuckets' hook / zero_grad do
+    assert ops.grad_out(p).data_ptr() == g1.data_ptr()
+
+
+def test_fp32_eval_products_setting_reaches_every_gemm_module():
+    import torch
+    from sensorium_amd import DwiseNeuro, ops
+    import sensorium_amd._lib as L
+    net = DwiseNeuro(readout_outputs=(7,), core_features=(8, 8), spatial_strides=(2, 1), expansion_ratio=3, se_reduce_ratio=4,
+                     cortex_features=(16, 32))
+    blk, layer, ro = net.core.blocks[1], net.cortex.layers[0], net.readouts[0]
+    assert ops._f32_products(blk) == L.F32_AUTO and ops._f32_products(ro, inference_readout=True) == L.F32_SPLIT3
+    net.set_fp32_eval_products("native")
+    assert {ops._f32_products(m) for m in (blk, layer)} == {L.F32_NATIVE}
+    assert ops._f32_products(ro, inference_readout=True) == L.F32_NATIVE
+    with pytest.raises(ValueError):
+        net.set_fp32_eval_products("fp16")
