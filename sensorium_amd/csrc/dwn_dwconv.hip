@@ -778,7 +778,43 @@ __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFw
     T* outp = reinterpret_cast<T*>(a.out);
     const i64 tstride = (i64)a.HW * a.C;
     if (chan_ok) {
-        for (i64 pos = (i64)blockIdx.x * LP + pl; pos < npos; pos += (i64)gridDim.x * LP) {
+        // ZOUT: a workgroup takes a CONTIGUOUS run of positions, so its lanes stay inside one sample for many iterations and the
+        // SqueezeExcite pooling sums wait in registers (pacc) until the sample changes: ~10x fewer atomics than a flush per
+        // position (5 M eight-byte atomics on 40 K addresses per launch at the inference batch)
+        i64 p_beg = (i64)blockIdx.x * LP + pl, p_end = npos, p_step = (i64)gridDim.x * LP;
+        if constexpr (ZOUT) {
+            const i64 per = ((npos + (i64)gridDim.x * LP - 1) / ((i64)gridDim.x * LP)) * LP;
+            p_beg = (i64)blockIdx.x * per + pl;
+            p_end = p_beg - pl + per < npos ? p_beg - pl + per : npos;
+            p_step = LP;
+        }
+        [[maybe_unused]] float pacc[4] = {0.f, 0.f, 0.f, 0.f};
+        [[maybe_unused]] i64 pacc_b = -1;
+        // adds pacc into pooled[pacc_b] (64-bit fixed point, pool_fix: whatever the arrival order, the same total).  The wave's
+        // pixel lanes that share a channel vector hold one sample almost always: then they are folded with xor-shuffles and
+        // the first NCV lanes add 4 channels each.  Called by all lanes that are still in the loop (or by all, after it).
+        [[maybe_unused]] auto pool_flush = [&]() {
+            const int b0 = __builtin_amdgcn_readfirstlane((int)pacc_b);
+            const bool uniform = __popcll(__ballot(1)) == 64 && __all((int)pacc_b == b0) && b0 >= 0;
+            if (uniform) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int o = NCV; o < 64; o <<= 1) pacc[i] += __shfl_xor(pacc[i], o);
+                if ((tid & 63) < NCV) {
+                    unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.pooled) + (i64)b0 * a.C + chan;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) atomicAdd(dst + i, (unsigned long long)pool_fix(pacc[i]));
+                }
+            } else if (pacc_b >= 0) {
+                unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.pooled) + pacc_b * a.C + chan;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) atomicAdd(dst + i, (unsigned long long)pool_fix(pacc[i]));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pacc[i] = 0.f;
+        };
+        for (i64 pos = p_beg; pos < p_end; pos += p_step) {
             const i64 b = pos / a.HW, hw = pos % a.HW;
             const T* ip = inp + (b * a.T * a.HW + hw) * a.C + chan;      // element (t = 0)
             T* op = outp + (b * a.T * a.HW + hw) * a.C + chan;
@@ -833,27 +869,14 @@ __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFw
             }
             if constexpr (ZOUT) {
                 if (a.pooled) {
-                    // the wave's pixel lanes that share a channel vector: one sample almost always (positions are consecutive);
-                    // then fold them with xor-shuffles and let the first NCV lanes add 4 channels each
-                    const int b0 = __builtin_amdgcn_readfirstlane((int)b);
-                    const bool uniform = __popcll(__ballot(1)) == 64 && __all((int)b == b0);
-                    // 64-bit fixed-point sums (pool_fix): whatever the arrival order, the same total
-                    unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.pooled) + b * a.C + chan;
-                    if (uniform) {
+                    if (__any(b != pacc_b)) { pool_flush(); pacc_b = b; }      // a lane entered another sample: everybody flushes
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-#pragma unroll
-                            for (int o = NCV; o < 64; o <<= 1) ps[i] += __shfl_xor(ps[i], o);
-                        if ((tid & 63) < NCV) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) atomicAdd(dst + i, (unsigned long long)pool_fix(ps[i]));
-                        }
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) atomicAdd(dst + i, (unsigned long long)pool_fix(ps[i]));
-                    }
+                    for (int i = 0; i < 4; ++i) pacc[i] += ps[i];
                 }
             }
+        }
+        if constexpr (ZOUT) {
+            if (a.pooled) pool_flush();
         }
     }
     if (a.stats) block_stats_flush<T>(lstat, st0, st1, cv, c0, a.C, a.stats, blockIdx.x % DWN_NREP);

@@ -49,11 +49,18 @@ def test_bf16_full_width_digest_and_gradient_directions(golden_dir):
     assert abs(l16 - float(z["loss"])) <= 2e-4 * abs(float(z["loss"]))
     assert abs(float(p16.double().norm()) - float(z["pred_l2"])) <= 1e-3 * float(z["pred_l2"])
     tot16 = math.sqrt(sum(float(g.norm()) ** 2 for g in g16.values()))
-    # total gradient norm: +0.7 ... +1.0 % in round 3 (deterministic build: +0.62 % every time; round 2: -0.03 ... -0.17 %).  The
-    # weight gradients at the END of the nine-block bf16 backward chain carry a gain error of a few per cent at this tiny batch
-    # (stem weight x 1.05-1.07 now, x 1.01-1.02 in round 2; block-1 conv_pw x 1.005 now, x 0.98 then): where the bf16 roundings
-    # sit moved (stem statistics from the exact input moments instead of the rounded y0), the size of the error did not; the
-    # per-parameter bar for bf16 gradients is 8e-2, checked below through the cosines
+    tot32 = math.sqrt(sum(float(g.norm()) ** 2 for g in g32.values()))
+    # Round-4 root cause (profiles/r4_bf16_parity.json, tests/bf16_gain_report.py): bf16 storage leaves every core gradient with
+    # 6-9 % of rounding NOISE (one stage in bf16 alone: 0.4-3.5 %, adding in quadrature over stem + 9 blocks + head), not a gain
+    # error: the GAIN <g16, g32> / |g32|^2 of the whole gradient vector is 1 to a few 1e-4, and noise can only ADD length —
+    # |g16| = |g32| sqrt(gain^2 + rho^2), rho ~ 0.08-0.11 => +0.3 ... +0.9 % — which is what the round-3 "+0.62 %" was.  (The
+    # stem weight's x1.04-1.07 at this batch is that noise projected on a 320-element gradient: 0.98-1.00 at B=32, T=32, below.)
+    # So: the 8e-3 bound sits on the gain, where a systematic error would show; the length is bounded through the noise.
+    dot = sum(float((g16[k] * g32[k]).sum()) for k in g32)
+    gain = dot / tot32 ** 2
+    rho = math.sqrt(max(tot16 ** 2 / tot32 ** 2 - gain ** 2, 0.0))
+    assert abs(gain - 1.0) <= 8e-3, gain
+    assert rho <= 0.15, rho
     assert abs(tot16 - float(z["grad_total_norm"])) <= 2e-2 * float(z["grad_total_norm"])
     # bf16 against fp32 HIP, element-wise
     assert float((p16 - p32).norm() / p32.norm()) <= 8e-3
@@ -105,3 +112,30 @@ def test_bf16_training_trajectory_tracks_fp32():
     c16 = orc.corr(finals["bf16"].transpose(0, 2, 1).reshape(tt.shape), tt, axis=0).mean()
     assert abs(c32 - c16) <= 2e-3
     assert np.corrcoef(finals["fp32"].ravel(), finals["bf16"].ravel())[0, 1] >= 0.999
+
+
+def test_bf16_gradient_gain_at_the_metric_batch():
+    """B=32, T=32, 36x64 (the benchmarked step), bf16 against the fp32 HIP path (itself pinned to the reference at 1e-3; no
+    oracle needed at this size): gain = <g16, g32> / |g32|^2.  Whole gradient: 1 +- 5e-3.  Every parameter carrying >= 1 % of the
+    gradient's length: 1 +- 2e-2.  The rest (tiny gradients that are small differences of large sums: the SqueezeExcite reduce
+    layers, some BatchNorm biases; measured 0.95-1.15 and moving from run to run with the product build's summation order):
+    1 +- 0.25, cosine >= 0.9.  Measured: profiles/r4_bf16_parity.json."""
+    model = _model()
+    rng = np.random.default_rng(20231122)
+    x, targets, _ = synth_inputs(rng, 32, 32, 36, 64, (7863,))
+    x, t, w = torch.from_numpy(x).to(dev()), torch.from_numpy(targets[0]).to(dev()), torch.ones(32, 1, device=dev())
+    _, _, g32 = _fwd_bwd(model, x, t, w, False)
+    _, _, g16 = _fwd_bwd(model, x, t, w, True)
+    tot32 = math.sqrt(sum(float(g.norm()) ** 2 for g in g32.values()))
+    gain_all = sum(float((g16[k] * g32[k]).sum()) for k in g32) / tot32 ** 2
+    assert abs(gain_all - 1.0) <= 5e-3, gain_all
+    for k in g32:
+        if analytically_zero_grad(k):
+            continue
+        n32 = float(g32[k].norm())
+        gain = float((g16[k] * g32[k]).sum()) / n32 ** 2
+        cos = float((g16[k] * g32[k]).sum()) / (n32 * float(g16[k].norm()))
+        if n32 >= 1e-2 * tot32:
+            assert abs(gain - 1.0) <= 2e-2, (k, gain)
+        else:
+            assert abs(gain - 1.0) <= 0.25 and cos >= 0.9, (k, gain, cos)
