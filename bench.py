@@ -266,6 +266,8 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE.json configs[2] / configs[3] legs (ten readouts; "
                     "distillation step) that run as child processes after the timed region")
     ap.add_argument("--no-rooflines", action="store_true", help="skip the extra untimed steps that time every kernel family")
+    ap.add_argument("--roctx", action="store_true", help="bracket every kernel-family launch with a roctx range (dwn:pw_fwd, ...): "
+                    "run under rocprofv3 --marker-trace --kernel-trace for a labelled timeline")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel family (adds event overhead)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU testing)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses cuda:0")
@@ -353,6 +355,8 @@ def main():
         mask = (1 << len(fam_names)) - 1
     else:
         mask = 1 << fam_names.index(args.roofline_family)
+    if args.roctx:
+        mask |= 1 << 63                      # include/dwn.h DWN_PROF_ROCTX
     sync()
     L.check(L.lib.dwn_profile_enable(mask, local_rank), "profile_enable")
     t0 = time.perf_counter()

@@ -320,6 +320,10 @@ enum {
     DWN_FAM_PW_DGRAD, DWN_FAM_PW_WGRAD, DWN_FAM_CORTEX_FWD, DWN_FAM_CORTEX_BWD, DWN_FAM_READOUT_FWD, DWN_FAM_READOUT_BWD,
     DWN_FAM_COUNT
 };
+/* family_mask bit DWN_PROF_ROCTX: additionally bracket every family launch with a roctx range named after the family
+ * ("dwn:pw_fwd", ...) so that rocprofv3 --marker-trace timelines are labelled; the roctx library is dlopen'ed on first use
+ * (librocprofiler-sdk-roctx.so, else libroctx64.so) and silently skipped when absent.  The range bit alone records no events. */
+#define DWN_PROF_ROCTX (1ull << 63)
 int dwn_profile_enable(unsigned long long family_mask, int device);
 int dwn_profile_collect(int family, double* total_ms, long long* launches);
 

@@ -26,14 +26,40 @@ int dwn_set_error(int code, const char* msg) {
 // ---- opt-in kernel-family timer (HIP events on the launch stream).  Off by default: zero cost and no state.
 // bench.py turns it on for the kernel family it reports a roofline for (dwn_profile_enable / _collect).
 #include <vector>
+#include <dlfcn.h>
 namespace {
 struct ProfFam { std::vector<hipEvent_t> beg, end; size_t used = 0; };
 static unsigned long long g_prof_mask = 0;
 static ProfFam g_prof[DWN_FAM_COUNT];
 constexpr size_t PROF_POOL = 8192;
+// roctx ranges per kernel family: resolved at run time so that the library has no link-time dependency
+static const char* const FAM_NAMES[DWN_FAM_COUNT] = {
+    "dwn:pw_fwd", "dwn:dws_fwd", "dwn:dwt_fwd", "dwn:se_pool", "dwn:pwl_fwd", "dwn:resid_fwd", "dwn:resid_bwd", "dwn:pwl_dgrad",
+    "dwn:pwl_wgrad", "dwn:bn3_reduce", "dwn:dwt_bwd", "dwn:dws_bwd", "dwn:pw_dgrad", "dwn:pw_wgrad", "dwn:cortex_fwd",
+    "dwn:cortex_bwd", "dwn:readout_fwd", "dwn:readout_bwd"};
+typedef int (*roctx_push_t)(const char*);
+typedef int (*roctx_pop_t)(void);
+static roctx_push_t g_roctx_push = nullptr;
+static roctx_pop_t g_roctx_pop = nullptr;
+static bool roctx_resolve() {
+    static int state = 0;                         // 0 untried, 1 ok, -1 absent
+    if (state == 0) {
+        state = -1;
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+            void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            g_roctx_push = (roctx_push_t)dlsym(h, "roctxRangePushA");
+            g_roctx_pop = (roctx_pop_t)dlsym(h, "roctxRangePop");
+            if (g_roctx_push && g_roctx_pop) { state = 1; break; }
+        }
+    }
+    return state == 1;
+}
 struct ProfScope {
-    int fam; hipStream_t s; bool on;
-    ProfScope(int f, hipStream_t st) : fam(f), s(st), on(false) {
+    int fam; hipStream_t s; bool on; bool range;
+    ProfScope(int f, hipStream_t st) : fam(f), s(st), on(false), range(false) {
+        if (g_prof_mask == 0) return;
+        if ((g_prof_mask & DWN_PROF_ROCTX) && g_roctx_push) { g_roctx_push(FAM_NAMES[f]); range = true; }
         if (!((g_prof_mask >> f) & 1ull)) return;
         ProfFam& p = g_prof[f];
         if (p.used >= p.beg.size()) return;
@@ -41,10 +67,12 @@ struct ProfScope {
         (void)hipEventRecord(p.beg[p.used], s);
     }
     ~ProfScope() {
-        if (!on) return;
-        ProfFam& p = g_prof[fam];
-        (void)hipEventRecord(p.end[p.used], s);
-        p.used++;
+        if (on) {
+            ProfFam& p = g_prof[fam];
+            (void)hipEventRecord(p.end[p.used], s);
+            p.used++;
+        }
+        if (range) g_roctx_pop();
     }
 };
 }  // namespace
@@ -258,6 +286,7 @@ int dwn_profile_enable(unsigned long long family_mask, int device) {
             for (size_t i = 0; i < PROF_POOL; ++i) { HIP_TRY(hipEventCreate(&p.beg[i])); HIP_TRY(hipEventCreate(&p.end[i])); }
         }
     }
+    if (family_mask & DWN_PROF_ROCTX) (void)roctx_resolve();      // absent library: ranges are skipped, events still work
     g_prof_mask = family_mask;
     return 0;
 }
