@@ -530,14 +530,14 @@ def main():
                                   "/ time / 8 TB/s"}
             for dt_ in ("bf16", "fp32"):
                 inf[dt_] = ensemble_bench(dtype=dt_, device=dev, windows=90)
-            ptraf = ROOT / "profiles" / "r3_predict_pmc.json"
-            if ptraf.exists():
+            for ptraf in sorted((ROOT / "profiles").glob("r*_predict_pmc.json"), reverse=True):
                 try:
                     pj = json.loads(ptraf.read_text())
-                    if pj.get("lib_sha16") == lib_sha16():
-                        inf["pmc_traffic"] = pj
                 except ValueError:
-                    pass
+                    continue
+                if pj.get("lib_sha16") == lib_sha16():      # measured on this very library build, else not reported
+                    inf["pmc_traffic"] = pj
+                break
             out["inference"] = inf
         if world == 1 and not args.no_other_configs and default_shape:
             # BASELINE.json configs[2] and configs[3] on this one GPU (their 8-GPU form is the same step per rank + the gradient
