@@ -328,6 +328,7 @@ int dwn_profile_enable(unsigned long long family_mask, int device);
 int dwn_profile_collect(int family, double* total_ms, long long* launches);
 
 int dwn_abi_version(void);
+const char* dwn_source_hash(void);         /* sha256[:16] of the source files the library was built from (csrc/Makefile HASH_SRCS) */
 int dwn_sizeof(const char* struct_name);   /* sizeof of a struct of this header, -1 if unknown (binding self-check) */
 const char* dwn_last_error(void);
 

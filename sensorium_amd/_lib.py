@@ -182,6 +182,7 @@ _STRUCTS = {
 _P = C.POINTER
 SYMBOLS = {
     "dwn_abi_version": (c_i, []),
+    "dwn_source_hash": (C.c_char_p, []),
     "dwn_sizeof": (c_i, [C.c_char_p]),
     "dwn_last_error": (C.c_char_p, []),
     "dwn_profile_enable": (c_i, [C.c_ulonglong, c_i]),
@@ -231,6 +232,19 @@ class DwnError(RuntimeError):
     pass
 
 
+# csrc/Makefile HASH_SRCS, in its order
+HASH_SRCS = ("dwn_api.hip", "dwn_gemm.hip", "dwn_gemm_xl.hip", "dwn_dwconv.hip", "dwn_dwrc.hip", "dwn_dwbwd.hip", "dwn_dwfwd.hip",
+             "dwn_elementwise.hip", "dwn_data.hip", "dwn_common.h", "dwn_internal.h", "dwn_kernels.h", "../../include/dwn.h")
+
+
+def source_hash() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for name in HASH_SRCS:
+        h.update((_HERE / "csrc" / name).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def _load():
     if not LIB_PATH.exists():
         raise ImportError(
@@ -243,6 +257,10 @@ def _load():
         fn.argtypes = argtypes
     if lib.dwn_abi_version() != 4:
         raise ImportError("libdwiseneuro_hip.so ABI version mismatch")
+    built, have = lib.dwn_source_hash().decode(), source_hash()
+    if built != have and not os.environ.get("DWN_LIB_PATH"):        # (an explicitly chosen other build is an A/B run)
+        raise ImportError(f"{LIB_PATH.name} was built from other sources (binary {built}, tree {have}): rebuild it with "
+                          f"`make -C {LIB_PATH.parent}` — binaries are not in git, so what runs must be what is committed")
     for cname, struct in _STRUCTS.items():
         n = lib.dwn_sizeof(cname.encode())
         if n != C.sizeof(struct):

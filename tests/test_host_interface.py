@@ -275,3 +275,14 @@ def test_fp32_eval_products_setting_reaches_every_gemm_module():
     assert ops._f32_products(ro, inference_readout=True) == L.F32_NATIVE
     with pytest.raises(ValueError):
         net.set_fp32_eval_products("fp16")
+
+
+def test_library_is_built_from_the_sources_in_the_tree():
+    """Binaries are not in git; what the GPU box runs must be what is committed: the library carries the hash of the sources it was
+    built from (csrc/Makefile HASH_SRCS) and sensorium_amd/_lib.py refuses to load one built from other sources."""
+    import sensorium_amd._lib as L
+    mk = (Path(L.__file__).resolve().parent / "csrc" / "Makefile").read_text()
+    srcs = re.search(r"^SRCS = (.*)$", mk, re.M).group(1).split()
+    hdrs = re.search(r"^HDRS = (.*)$", mk, re.M).group(1).split()
+    assert tuple(srcs + hdrs) == L.HASH_SRCS
+    assert L.lib.dwn_source_hash().decode() == L.source_hash()
