@@ -174,6 +174,39 @@ class MouseModel(Model):
             return
         fill_distill_targets(self.distill_model(input), target, self.distill_ratio)
 
+    def _active_samples(self, batch):
+        """Per mouse, the device index tensor of the samples whose loss weight is not zero — or None when that is not known
+        WITHOUT a device read-back (weights already on the device with no host copy attached) or when it is everybody
+        (distillation fills every weight, argus_models.py:37-41).  The readouts' backward then skips the other rows: their
+        gradient is exactly zero (losses.py:15-17), and with ten one-hot mice that is 28 of 32 samples per readout."""
+        if self.distill_model is not None and self.distill_ratio:
+            return None
+        try:
+            weights = batch[1][1]
+        except (TypeError, IndexError, KeyError):
+            return None
+        if not torch.is_tensor(weights) or weights.dim() != 2 or weights.shape[1] != len(self.nn_module.readouts):
+            return None
+        host = weights if not weights.is_cuda else getattr(weights, "_dwn_host", None)
+        if host is None or host.shape != weights.shape:
+            return None
+        key = (id(host), host._version, str(self.device))
+        cached = getattr(self, "_active_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        mask = host != 0
+        if bool(mask.all()):
+            out = None
+        else:
+            counts = mask.sum(0).tolist()
+            order = torch.cat([mask[:, m].nonzero().flatten() for m in range(mask.shape[1])]).to(self.device)
+            out, lo = [], 0
+            for c in counts:
+                out.append(order[lo:lo + c])
+                lo += c
+        self._active_cache = (key, out, host)          # (host kept alive: its id is part of the key)
+        return out
+
     # -- argus_models.py:43-71 -----------------------------------------------------------------------------
     def train_step(self, batch, state=None, sync_loss: bool = True) -> dict:
         self._ensure_optimizer()
@@ -184,13 +217,18 @@ class MouseModel(Model):
             self.optimizer.zero_grad(set_to_none=True)
         loss_value = 0
         for chunk_batch in deep_chunk(batch, self.iter_size):
+            active = self._active_samples(chunk_batch)
             input, target = deep_to(chunk_batch, self.device, non_blocking=True)
+            for m, readout in enumerate(self.nn_module.readouts):
+                readout._dwn_active = None if active is None else active[m]
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
                 self.add_distill_predictions(input, target)
                 prediction = self.nn_module(input)
                 loss = self.loss(prediction, target)
                 loss = loss / self.iter_size
             loss.backward()
+            for readout in self.nn_module.readouts:
+                readout._dwn_active = None
             loss_value = loss_value + (loss.item() if sync_loss else loss.detach())
         if self.buckets is not None:
             self.buckets.finish()

@@ -1855,50 +1855,92 @@ int k_readout_dz(const float* dout, const float* out, float beta, int B, int Tn,
 }
 
 // loss += sum_{b,n,t} w[b] * (x - y*log(x + eps));  dpred = gscale * w[b] * (1 - y/(x+eps))
+// grid = (chunks, B): a workgroup works inside ONE sample, so the weight is a scalar and a sample whose weight is zero (every
+// sample of the other mice with one-hot mouse weights, src/datasets.py:185-186) costs no reads at all; 16-byte accesses when the
+// sample length allows (VEC = 4).
+template <int VEC>
 __global__ __launch_bounds__(256) void poisson_fwd_kernel(const float* pred, const float* target, const float* w,
-                                                          i64 per_sample, i64 total, float eps, double* loss) {
-    double acc = 0.0;
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < total; i += (i64)gridDim.x * 256) {
-        float wb = w[i / per_sample];
-        if (wb != 0.f) {
-            float x = pred[i], y = target[i];
-            acc += (double)(wb * (x - y * __logf(x + eps)));
+                                                          i64 per_sample, float eps, double* loss) {
+    const float wb = w[blockIdx.y];
+#ifndef DWN_DETERMINISTIC
+    if (wb == 0.f) return;                               // (uniform; the ordered build must still pass its ticket below)
+#endif
+    const float* x = pred + (i64)blockIdx.y * per_sample;
+    const float* y = target + (i64)blockIdx.y * per_sample;
+    float acc = 0.f;
+    for (i64 i = ((i64)blockIdx.x * 256 + threadIdx.x) * VEC; wb != 0.f && i < per_sample; i += (i64)gridDim.x * 256 * VEC) {
+        if constexpr (VEC == 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + i), yv = *reinterpret_cast<const float4*>(y + i);
+            acc += (xv.x - yv.x * __logf(xv.x + eps)) + (xv.y - yv.y * __logf(xv.y + eps)) +
+                   (xv.z - yv.z * __logf(xv.z + eps)) + (xv.w - yv.w * __logf(xv.w + eps));
+        } else {
+            acc += x[i] - y[i] * __logf(x[i] + eps);
         }
     }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    double accd = (double)(wb * acc);
+    for (int o = 32; o > 0; o >>= 1) accd += __shfl_xor(accd, o);
     __shared__ double part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = accd;
     __syncthreads();
     DET_ENTER();
     if (threadIdx.x == 0) atomicAdd(loss, part[0] + part[1] + part[2] + part[3]);
     DET_EXIT();
 }
+template <int VEC>
 __global__ __launch_bounds__(256) void poisson_bwd_kernel(const float* pred, const float* target, const float* w,
-                                                          const float* gscale, i64 per_sample, i64 total, float eps,
-                                                          float* dpred) {
-    const float gs = gscale ? *gscale : 1.0f;
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < total; i += (i64)gridDim.x * 256) {
-        float wb = w[i / per_sample];
-        dpred[i] = wb != 0.f ? gs * wb * (1.0f - target[i] / (pred[i] + eps)) : 0.f;
+                                                          const float* gscale, i64 per_sample, float eps, float* dpred) {
+    const float wb = w[blockIdx.y];
+    const float g = (gscale ? *gscale : 1.0f) * wb;
+    const float* x = pred + (i64)blockIdx.y * per_sample;
+    const float* y = target + (i64)blockIdx.y * per_sample;
+    float* d = dpred + (i64)blockIdx.y * per_sample;
+    for (i64 i = ((i64)blockIdx.x * 256 + threadIdx.x) * VEC; i < per_sample; i += (i64)gridDim.x * 256 * VEC) {
+        if constexpr (VEC == 4) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (wb != 0.f) {
+                const float4 xv = *reinterpret_cast<const float4*>(x + i), yv = *reinterpret_cast<const float4*>(y + i);
+                o = make_float4(g * (1.0f - yv.x / (xv.x + eps)), g * (1.0f - yv.y / (xv.y + eps)),
+                                g * (1.0f - yv.z / (xv.z + eps)), g * (1.0f - yv.w / (xv.w + eps)));
+            }
+            *reinterpret_cast<float4*>(d + i) = o;
+        } else {
+            d[i] = wb != 0.f ? g * (1.0f - y[i] / (x[i] + eps)) : 0.f;
+        }
     }
 }
 __global__ void f64_to_f32_kernel(const double* src, float* dst, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = (float)src[i];
 }
+// per_sample = elements of one sample, total = B * per_sample
+static inline bool poisson_vec4(const float* a, const float* b, const float* c, i64 per_sample) {
+    return (per_sample & 3) == 0 && !(((size_t)a | (size_t)b | (size_t)c) & 15);
+}
 int k_poisson_fwd(const float* pred, const float* target, const float* w, i64 per_sample, i64 total, float eps,
                   double* loss, hipStream_t s) {
-    i64 blocks = (total + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(poisson_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pred, target, w, per_sample, total, eps, loss);
+    const i64 B = per_sample > 0 ? total / per_sample : 0;
+    if (B <= 0) return 0;
+    if (B > 65535) return dwn_set_error(-2, "poisson loss: batch is a grid dimension (<= 65535)");
+    i64 chunks = (per_sample + 1023) / 1024;
+    const i64 cap = (4096 + B - 1) / B;
+    if (chunks > cap) chunks = cap;
+    dim3 grid((unsigned)chunks, (unsigned)B);
+    if (poisson_vec4(pred, target, pred, per_sample)) hipLaunchKernelGGL(poisson_fwd_kernel<4>, grid, dim3(256), 0, s, pred, target, w, per_sample, eps, loss);
+    else hipLaunchKernelGGL(poisson_fwd_kernel<1>, grid, dim3(256), 0, s, pred, target, w, per_sample, eps, loss);
     DWN_CHECK_LAUNCH();
     return 0;
 }
 int k_poisson_bwd(const float* pred, const float* target, const float* w, const float* gscale, i64 per_sample,
                   i64 total, float eps, float* dpred, hipStream_t s) {
-    i64 blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(poisson_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pred, target, w, gscale, per_sample, total, eps, dpred);
+    const i64 B = per_sample > 0 ? total / per_sample : 0;
+    if (B <= 0) return 0;
+    if (B > 65535) return dwn_set_error(-2, "poisson loss: batch is a grid dimension (<= 65535)");
+    i64 chunks = (per_sample + 1023) / 1024;
+    const i64 cap = (4096 + B - 1) / B;
+    if (chunks > cap) chunks = cap;
+    dim3 grid((unsigned)chunks, (unsigned)B);
+    if (poisson_vec4(pred, target, dpred, per_sample)) hipLaunchKernelGGL(poisson_bwd_kernel<4>, grid, dim3(256), 0, s, pred, target, w, gscale, per_sample, eps, dpred);
+    else hipLaunchKernelGGL(poisson_bwd_kernel<1>, grid, dim3(256), 0, s, pred, target, w, gscale, per_sample, eps, dpred);
     DWN_CHECK_LAUNCH();
     return 0;
 }

@@ -298,6 +298,11 @@ class BatchAssembler:
             L.check(L.lib.dwn_assemble_targets(table.data_ptr(), B, T, table.data_ptr() + off_ptr,
                                                self._n_dev.data_ptr(), len(self.num_neurons), max(self.num_neurons),
                                                weights.data_ptr(), dev.index, stream), "dwn_assemble_targets")
+            # the host knows the owner of every sample (the kernel writes exactly these one-hot rows): MouseModel.train_step
+            # uses the copy to run each readout's backward on its own samples only, without reading the device tensor back
+            host = torch.zeros(B, len(self.num_neurons), dtype=torch.float32)
+            host[torch.arange(B), torch.tensor([p.mouse for p in picks])] = 1.0
+            weights._dwn_host = host
             return x, (targets, weights)
         return x
 

@@ -465,6 +465,9 @@ class ReadoutFn(torch.autograd.Function):
         L.check(L.lib.dwn_readout_forward(C.byref(a), dev.index, _stream(dev)), "dwn_readout_forward")
         ctx.mod = mod; ctx.has_mask = drop_mask is not None
         ctx.wt = wt
+        # samples whose loss weight for this mouse is not zero (MouseModel.train_step knows them on the host): the backward
+        # then runs on those rows only — the gradient w.r.t. the other rows' predictions is exactly zero (losses.py:15-17)
+        ctx.active = getattr(mod, "_dwn_active", None)
         tensors = [x, weight, bias, out]
         if drop_mask is not None:
             tensors.append(drop_mask)
@@ -481,10 +484,21 @@ class ReadoutFn(torch.autograd.Function):
         dout = dout.contiguous().float()
         B, T, Cin = x.shape
         n = mod.out_features
-        dx = torch.empty_like(x)
         conv = mod.layer[1]
         dw = grad_out(conv.weight, zero=True)
         db = grad_out(conv.bias, zero=True)
+        idx, dx_full = ctx.active, None
+        if idx is not None and idx.numel() < B:
+            # compact backward: the three products see nb x T rows instead of B x T (ten readouts with one-hot mouse
+            # weights: 3-4 of 32 samples each); zero rows contribute exactly nothing to dW / dbias and get dx = 0
+            dx_full = torch.zeros_like(x)
+            if idx.numel() == 0:
+                return dx_full, None, None, dw, db
+            x, out, dout = x.index_select(0, idx), out.index_select(0, idx), dout.index_select(0, idx)
+            if drop_mask is not None:
+                drop_mask = drop_mask.index_select(0, idx)
+            B = idx.numel()
+        dx = torch.empty_like(x)
         a = L.ReadoutArgs()
         a.dtype = _DT[x.dtype]; a.B = B; a.T = T; a.Cin = Cin; a.groups = mod.groups; a.n_out = n
         a.softplus_beta = mod.softplus_beta
@@ -496,6 +510,9 @@ class ReadoutFn(torch.autograd.Function):
         ws = _ws(L.lib.dwn_readout_workspace_bytes(C.byref(a), 1), dev)
         a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
         L.check(L.lib.dwn_readout_backward(C.byref(a), dev.index, _stream(dev)), "dwn_readout_backward")
+        if dx_full is not None:
+            dx_full.index_copy_(0, idx, dx)
+            dx = dx_full
         return dx, None, None, dw, db
 
 

@@ -30,5 +30,7 @@ def make_batch(batch: int, frames: int, height: int, width: int, readout_outputs
     tt = [torch.from_numpy(t) for t in targets]
     wt = torch.from_numpy(weights)
     if device is not None:
+        host = wt
         xt, tt, wt = xt.to(device), [t.to(device) for t in tt], wt.to(device)
+        wt._dwn_host = host           # the host knows which mouse every sample belongs to: MouseModel.train_step uses it (no read-back)
     return xt, (tt, wt)

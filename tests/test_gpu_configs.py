@@ -106,3 +106,46 @@ def test_distillation_step_matches_reference(golden_dir):
     _close([float(named[f"readouts.{m}.layer.1.weight"].grad.double().norm()) for m in range(10)], z["grad_readout_w"], 5e-3,
            "readout gradient norms")
     _close([float(named[k].grad.double().norm()) for k in TRACKED], z["grad_tracked"], 5e-3, "trunk gradient norms")
+
+
+def test_sparse_readout_backward_equals_dense_with_one_hot_mice():
+    """Config 3's batch structure (src/datasets.py:172-187: one-hot mouse weights): MouseModel.train_step runs every readout's
+    backward on its own samples only (the other rows' loss gradient is exactly zero, src/losses.py:15-17).  Same loss, same
+    gradients as the dense backward (summation order only); an absent mouse gets zero gradients."""
+    from sensorium_amd.argus_models import MouseModel
+    from sensorium_amd.synthetic import make_batch
+    kw = dict(readout_outputs=(40, 56, 24, 72), core_features=(16, 16, 32), spatial_strides=(2, 1, 2), expansion_ratio=3,
+              se_reduce_ratio=4, cortex_features=(64, 128), drop_rate=0.3, drop_path_rate=0.0)
+    params = {"nn_module": ("dwiseneuro", kw), "loss": ("mice_poisson", {}), "optimizer": ("AdamW", {"lr": 1e-3, "weight_decay": 0.05}),
+              "device": "cuda:0", "amp": False, "iter_size": 1}
+    x, (targets, weights) = make_batch(6, 4, 12, 16, kw["readout_outputs"][:3] + (72,), seed=5, device=dev())
+    host = weights._dwn_host.clone()
+    host[:, 3] = 0.0                                     # mouse 3 owns no sample of this batch; mice 0-2 own two each
+    host[5] = torch.tensor([0.0, 1.0, 0.0, 0.0])
+    weights.copy_(host)
+    for m in range(4):
+        targets[m] *= host[:, m].to(dev())[:, None, None]
+    results = {}
+    for mode in ("dense", "sparse"):
+        torch.manual_seed(3)
+        torch.cuda.manual_seed_all(3)
+        model = MouseModel(params)
+        w = weights.clone()
+        if mode == "sparse":
+            w._dwn_host = host
+        out = model.train_step([x, [targets, w]])
+        grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in model.nn_module.named_parameters()}
+        results[mode] = (out["loss"], grads)
+        if mode == "sparse":
+            assert model._active_cache[1] is not None and [int(i.numel()) for i in model._active_cache[1]] == [2, 2, 1, 0]
+        else:
+            assert getattr(model, "_active_cache", None) is None
+    (l0, g0), (l1, g1) = results["dense"], results["sparse"]
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    tot = math.sqrt(sum(float(g.double().norm()) ** 2 for g in g0.values() if g is not None))
+    for k in g0:
+        assert (g0[k] is None) == (g1[k] is None), k
+        if g0[k] is not None:
+            # (floor: the analytically-zero gradients are summation noise of ~1e-6 in either order)
+            assert float((g0[k].double() - g1[k].double()).norm()) <= 1e-5 * float(g0[k].double().norm()) + 1e-6 * tot, k
+    assert not g1["readouts.3.layer.1.weight"].any() and not g0["readouts.3.layer.1.weight"].any()
