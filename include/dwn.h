@@ -130,6 +130,11 @@ typedef struct dwn_gemm_tn_args {
      * accumulate into dw + b*dw_sample_stride — B separate [R][Cc] matrices P_b = load(P)_b^T load(Q)_b.
      * splits_per_sample is chosen by the library. */
     int rows_per_sample; int splits_per_sample; long long dw_sample_stride;
+    /* 1: the caller wants dW = the product, not dW += : when the launch needs only one M-split the tiles are written with plain
+     * stores (the 64-byte-segment fp32 atomics are the slow part of a weight gradient with a big output: 16 M floats for a
+     * readout) and dW need not be zeroed; when it needs more, the library zeroes dW itself first.  Needs lddw == Cc and
+     * rows_per_sample == 0 (the [groups * R][Cc] matrix is one contiguous block). */
+    int overwrite;
 } dwn_gemm_tn_args;
 
 /* depth-wise (1,k,k) conv, stride (1,s,s), pad k/2 — dwiseneuro.py:96-100 */
@@ -267,7 +272,8 @@ typedef struct dwn_readout_args {
     const float* w; const float* bias;      /* [Npad][Cin/groups], [Npad] */
     const float* drop_mask;                 /* [B][Cin] Dropout1d factor or null */
     float* out;                             /* [B][N][T] fp32 */
-    const float* dout; void* dx; float* dw; float* dbias;   /* backward (dw, dbias zeroed by caller) */
+    const float* dout; void* dx; float* dw; float* dbias;   /* backward: dw is overwritten (no zeroing needed), dbias is
+                                                              * accumulated with atomics (zeroed by the caller) */
     void* ws; size_t ws_bytes;
     /* optional: the weight in the data gradient's operand layout, [groups][Cin/groups][Rp] in the compute type
      * (dwn_readout_wt_bytes).  Non-null in forward: written by the same pass that packs the forward layout (one read of the

@@ -62,7 +62,7 @@ class GemmTNArgs(C.Structure):
     _fields_ = [("p", LoadDesc), ("p_kind", c_i), ("q", LoadDesc), ("q_kind", c_i), ("M", c_i), ("R", c_i),
                 ("Cc", c_i), ("dw", c_p), ("lddw", c_ll), ("groups", c_i), ("rows_per_split", c_i),
                 ("nsplit", c_i), ("R_load", c_i), ("rows_per_sample", c_i), ("splits_per_sample", c_i),
-                ("dw_sample_stride", c_ll)]
+                ("dw_sample_stride", c_ll), ("overwrite", c_i)]
 
 
 class DwSpatialFwdArgs(C.Structure):

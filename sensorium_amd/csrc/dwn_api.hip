@@ -822,6 +822,10 @@ int dwn_readout_backward(const dwn_readout_args* ap, int device, void* stream) {
     }
     GemmTN g = tn_base(dz, LD_PLAIN, x, kind, M, w.Rg, Kg, a.dw, Kg, a.groups);
     g.R_load = w.Rp;
+    // every element of dw [Npad][Kg] is produced here: written with plain stores when the tiles alone fill the chip (the real
+    // readouts: 1984 tiles), zeroed + accumulated otherwise — the caller does not clear dw
+    g.overwrite = ((size_t)a.dw & 15) == 0 && ((size_t)a.groups * w.Rg * Kg) % 4 == 0;
+    if (!g.overwrite) TRY(k_fill_f32(a.dw, 0.f, a.groups * w.Rg * Kg, s));
     PROF(DWN_FAM_READOUT_BWD, launch_gemm_tn(g, dt, s));
     return 0;
 }

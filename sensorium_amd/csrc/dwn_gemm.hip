@@ -19,6 +19,7 @@
 // A[row l&15][k = 8*(l>>4)+j], B[k = 8*(l>>4)+j][col l&15]; C/D: col = l&15, row = 4*(l>>4)+reg.
 #include "dwn_internal.h"
 #include <type_traits>
+int k_zero(void* p, size_t nbytes, hipStream_t s);        // dwn_elementwise.hip
 
 #ifndef NN_DMA_NST
 #define NN_DMA_NST 3                 // stages of the LDS-DMA ring of gemm_nn_kernel<..., 3>
@@ -1073,11 +1074,15 @@ __global__ __launch_bounds__(256, (TnOcc<PLD, QLD>::value)) void gemm_tn_kernel(
             for (int r = 0; r < 4; ++r) {
                 int rr = r0 + wm * 64 + i * 16 + lg * 4 + r;
                 int cc = c0 + wn * 64 + j * 16 + lr;
-                if (rr < g.R && cc < g.Cc) atomicAdd(dw + (i64)rr * g.lddw + cc, acc[i][j][r]);
+                if (rr < g.R && cc < g.Cc) {
+                    if (g.overwrite == 2) dw[(i64)rr * g.lddw + cc] = acc[i][j][r];      // single M-split: this tile has one writer
+                    else atomicAdd(dw + (i64)rr * g.lddw + cc, acc[i][j][r]);
+                }
             }
     DET_EXIT();
 }
 
+#define TRY_(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
 template <typename T, int PLD, int QLD>
 static int launch_tn_t(const GemmTN& g_in, hipStream_t s) {
     GemmTN g = g_in;
@@ -1127,6 +1132,12 @@ static int launch_tn_t(const GemmTN& g_in, hipStream_t s) {
             g.rows_per_split = (int)rows;
             g.nsplit = (int)((g.M + rows - 1) / rows);
         }
+    }
+    if (g.overwrite) {
+        // dW = product: plain stores with one M-split (overwrite = 2 tells the kernel), else zero first and accumulate
+        if (g.rows_per_sample > 0 || g.lddw != g.Cc) return dwn_set_error(-2, "gemm_tn: overwrite needs lddw == Cc and no per-sample mode");
+        if (g.nsplit == 1) g.overwrite = 2;
+        else TRY_(k_zero(g.dw, (size_t)g.groups * g.R * g.lddw * sizeof(float), s));
     }
     dim3 grid(((g.R + 127) / 128) * ((g.Cc + 127) / 128), g.nsplit, g.groups);
     hipLaunchKernelGGL((gemm_tn_kernel<T, PLD, QLD>), grid, dim3(256), 0, s, g);

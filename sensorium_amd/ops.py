@@ -485,7 +485,7 @@ class ReadoutFn(torch.autograd.Function):
         B, T, Cin = x.shape
         n = mod.out_features
         conv = mod.layer[1]
-        dw = grad_out(conv.weight, zero=True)
+        dw = grad_out(conv.weight)                   # overwritten by dwn_readout_backward (no 64 MB clear per readout)
         db = grad_out(conv.bias, zero=True)
         idx, dx_full = ctx.active, None
         if idx is not None and idx.numel() < B:
@@ -493,7 +493,7 @@ class ReadoutFn(torch.autograd.Function):
             # weights: 3-4 of 32 samples each); zero rows contribute exactly nothing to dW / dbias and get dx = 0
             dx_full = torch.zeros_like(x)
             if idx.numel() == 0:
-                return dx_full, None, None, dw, db
+                return dx_full, None, None, dw.zero_(), db
             x, out, dout = x.index_select(0, idx), out.index_select(0, idx), dout.index_select(0, idx)
             if drop_mask is not None:
                 drop_mask = drop_mask.index_select(0, idx)
