@@ -1,6 +1,12 @@
 """Host-side training runtime (sensorium_amd/engine.py, callbacks.py, utils.py, CorrelationMetric): the argus surface
 scripts/train.py:41-146 drives.  CPU only — a two-layer toy ``Model`` stands in for ``MouseModel`` so the loop,
-callback order, schedules, checkpoints and ``load_model`` are exercised without a GPU."""
+callback order, schedules, checkpoints and ``load_model`` are exercised without a GPU.
+
+PARITY UNPINNED for this file's subject: pytorch-argus 1.0.0 is neither vendored in the reference nor installable offline, so the
+event order, epoch numbering and metric merging asserted below are argus' PUBLISHED behaviour restated (validation pass before
+epoch 1, epochs from 1, ``val_*`` merged before the user's epoch_complete callbacks) — they pin this runtime against itself and
+against how scripts/train.py uses the API, not against argus.  What IS pinned to the reference: ``init_weights`` / ``get_lr``
+(bit-exact against src/utils.py, below), the checkpoint file format (src/ema.py:67-72) and ``corr`` (src/metrics.py:11-31)."""
 import csv
 import importlib.util
 import math
