@@ -68,6 +68,11 @@ CASES = [
     (256, 256, 1, 7, 32, 2, 2, 5, 8),
     (256, 256, 2, 7, 32, 2, 32, 9, 16),
     (256, 256, 1, 7, 32, 7, 32, 5, 8),
+    # expansion 6 (the distillation student, configs/distillation_001.py:32: Cmid = 384 / 768 / 1536 — slices of 64 channels do
+    # not divide 384 evenly into the 448-wide tilings the expansion-7 shapes were tuned on) at the three widths, both strides
+    (64, 64, 2, 6, 32, 2, 4, 12, 16),
+    (128, 256, 1, 6, 32, 2, 4, 9, 16),
+    (256, 256, 2, 6, 32, 1, 4, 9, 16),
 ]
 
 
@@ -139,7 +144,7 @@ def test_block_train_forward_backward(case, dtype, drop):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case_id", [1, 3, 4, 9, 10, 12, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("case_id", [1, 3, 4, 9, 10, 12, 14, 15, 16, 17, 18, 19, 20, 21])
 def test_block_eval_forward(dtype, case_id):
     """Eval-mode forward.  The cases with 64 / 128 input channels take, in bf16, the y1-recomputing stencil
     (dwn_dw_spatial_fwd_rc: conv_pw never runs as its own pass) — except case 14, whose 130-pixel rows fit neither register

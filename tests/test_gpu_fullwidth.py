@@ -152,3 +152,43 @@ def test_full_width_fold_ensemble_matches_reference(fold_setup, amp, bound, cent
     for k, m in enumerate(models):
         one = Predictor(m, blend_weights="ones", frame_stack_size=16, frame_stack_step=2, windows_per_batch=5).predict_trial(inputs, 1)
         _check(one, z, "per_model", k, bound, centred)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_config0_forward_matches_reference(golden_dir, bf16):
+    """BASELINE.json configs[0] at its exact shape (1 readout, B=2, T=16, 36x64, expansion 7): train-mode forward and eval-mode
+    forward (BatchNorm statistics := the clip's own, calibrated through the oracle as the generator did through the reference)
+    against the reference's digests — fp32 1e-3, bf16 2e-2 on the sampled elements (and against their varying part: the
+    predictions sit on the softplus pedestal)."""
+    from sensorium_amd import DwiseNeuro
+    z = np.load(golden_dir / "config0_digest.npz")
+    sd = orc.make_state_dict(readout_outputs=(7863,), expansion_ratio=7, seed=17, randomize_bn=True)
+    rng = np.random.default_rng(20231127)
+    x, _, _ = synth_inputs(rng, 2, 16, 36, 64, (7863,))
+    assert float(x.astype(np.float64).sum()) == float(z["input_checksum"])
+    xt = torch.from_numpy(x)
+    keep = orc.BN_MOMENTUM
+    orc.BN_MOMENTUM = 1.0
+    try:
+        stats = {}
+        with torch.no_grad():
+            orc.forward(sd, xt, strides=STRIDES, readout_outputs=(7863,), training=True, new_stats=stats)
+    finally:
+        orc.BN_MOMENTUM = keep
+    sd_cal = dict(sd)
+    sd_cal.update({k: v.to(sd[k].dtype) for k, v in stats.items()})
+    idx = z["sample_idx"]
+    tol, ctol = (2e-2, 0.2) if bf16 else (1e-3, 5e-3)
+    for mode, weights in (("train", sd), ("eval", sd_cal)):
+        model = DwiseNeuro(readout_outputs=(7863,), expansion_ratio=7, drop_rate=0.0, drop_path_rate=0.0)
+        model.load_state_dict(weights, strict=True)
+        model = model.to(dev())
+        model.train(mode == "train")
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+            p = model(xt.to(dev()))[0].float().cpu()
+        assert abs(float(p.double().norm()) - float(z[f"{mode}_l2"])) <= tol * float(z[f"{mode}_l2"]), mode
+        assert abs(float(p.double().mean()) - float(z[f"{mode}_mean"])) <= tol * abs(float(z[f"{mode}_mean"])), mode
+        got = p.numpy()[idx[:, 0], idx[:, 1], idx[:, 2]].astype(np.float64)
+        ref = z[f"{mode}_sample"].astype(np.float64)
+        assert np.linalg.norm(got - ref) <= tol * np.linalg.norm(ref), (mode, np.linalg.norm(got - ref) / np.linalg.norm(ref))
+        assert np.linalg.norm(got - ref) <= ctol * np.linalg.norm(ref - ref.mean()), (mode, "centred")
