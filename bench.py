@@ -24,6 +24,10 @@ import sys
 import time
 from pathlib import Path
 
+# more hardware queues than HIP's default 4, before the runtime starts: the RCCL stream must not share a queue with the compute
+# stream (sensorium_amd/ddp.py::init_rccl); no effect on one GPU (24.82-24.90 vs 24.83-24.90 ms/step measured)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
@@ -277,6 +281,10 @@ def main():
                     "-> all-gather of the parameters (hidden behind the next core forward) instead of all-reduce + full optimizer")
     ap.add_argument("--arena-gb", type=float, default=0.0, help="reserve ONE device segment of this size before the first step (allocated "
                     "and handed straight back to torch's caching allocator, which then carves every activation out of it)")
+    ap.add_argument("--compute-stream", action="store_true", help="run the steps on a stream of their own instead of the legacy default "
+                    "stream (which synchronises implicitly with every blocking stream)")
+    ap.add_argument("--ddp-single-rank", action="store_true", help="testing: run the data-parallel machinery (RCCL process group, flat "
+                    "buckets, hook-launched all-reduce, barrier + max-over-ranks timing) on ONE rank — the 8-GPU code path on a 1-GPU box")
     ap.add_argument("--dry-run", action="store_true", help="testing only: launcher + rendezvous + timing plumbing, no GPU work")
     args = ap.parse_args()
 
@@ -295,9 +303,16 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    ddp = world > 1 or args.ddp_single_rank
+    if ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29571")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            if os.environ.get("DWN_PG_DEFAULT_STREAM") == "1":       # tools/rccl_queue_probe.sh: the torch default, for comparison
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                from sensorium_amd.ddp import init_rccl
+                init_rccl(dev)                                       # RCCL kernels on a hardware queue of their own
         else:
             dist.init_process_group(args.backend)
 
@@ -312,6 +327,7 @@ def main():
     params["amp"] = args.dtype == "bf16"
     params["ddp_comm_dtype"] = args.ddp_comm
     params["ddp_shard_optimizer"] = bool(args.ddp_shard)
+    params["ddp_single_rank"] = bool(args.ddp_single_rank)
     torch.manual_seed(1234)            # identical init on every rank (GradBuckets also broadcasts rank 0)
     model = MouseModel(params)
     # reference init rule (src/utils.py:46-56): conv ~ N(0, sqrt(2/fan_out)), BN weight 1 / bias 0
@@ -341,13 +357,17 @@ def main():
         return x0, ([t.clone() for t in t0], w0.clone())
 
     def sync():
-        if world > 1:
+        if ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
     if args.arena_gb > 0:
         arena = torch.empty(int(args.arena_gb * (1 << 30)), dtype=torch.uint8, device=dev)
         del arena
+    if args.compute_stream:
+        cstream = torch.cuda.Stream(device=dev)
+        cstream.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(cstream)
     for _ in range(args.warmup):
         model.train_step(next_batch(), sync_loss=False)
     fam_names = L.FAMILIES
@@ -391,7 +411,7 @@ def main():
                 L.check(L.lib.dwn_profile_collect(i, C.byref(ms), C.byref(n)), "profile_collect")
                 fam_all[name] = (ms.value, n.value)
             L.check(L.lib.dwn_profile_enable(0, local_rank), "profile_disable")
-    if world > 1:
+    if ddp:
         dist.barrier()
     # SURVEY.md §8d asks for both figures: the same steps without optimizer / EMA (forward + loss + backward only)
     fwd_bwd_clips = None
@@ -410,7 +430,7 @@ def main():
     L.lib.dwn_profile_enable(0, local_rank)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if ddp:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -498,7 +518,7 @@ def main():
             "rooflines_note": "roofline = the dominant family, HIP events inside the timed region; rooflines = every family "
                               "(HBM fraction of its algorithmic bytes; GEMM families also their MFMA fraction) from "
                               f"{prof_steps} extra untimed steps with events around every launch",
-            "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+            "rccl_ranks": dist.get_world_size() if (ddp and dist.is_initialized()) else 1,
         }
         if model.buckets is not None:
             out["ddp"] = {"backend": dist.get_backend(), "buckets": len(model.buckets.buckets),
@@ -552,7 +572,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.mice == 1 and not args.distill:
             out["cpu_baseline"] = cpu_baseline(args.frames, args.height, args.width, args.expansion)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if ddp:
         dist.destroy_process_group()
 
 

@@ -141,14 +141,16 @@ class MouseModel(Model):
             raise RuntimeError("model has no optimizer (loaded with optimizer=None)")
         oname, okwargs = self._opt_spec
         params = [p for p in self.nn_module.parameters() if p.requires_grad]
-        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # params["ddp_single_rank"]: the exchange machinery on a ONE-rank process group as well (tests: RCCL on a one-GPU box)
+        single = bool(self.params.get("ddp_single_rank", False))
+        distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or single)
         if distributed:
             # broadcasts rank 0's parameters and buffers; params["ddp_comm_dtype"] / DWN_DDP_COMM=bf16: exchange bf16 copies
             comm = self.params.get("ddp_comm_dtype", os.environ.get("DWN_DDP_COMM"))
             comm = torch.bfloat16 if comm in (torch.bfloat16, "bf16", "bfloat16") else None
             # params["ddp_shard_optimizer"] / DWN_DDP_SHARD=1: reduce-scatter + sharded AdamW/EMA + all-gather for the readouts
             shard = self.params.get("ddp_shard_optimizer", os.environ.get("DWN_DDP_SHARD", "0") == "1")
-            self.buckets = GradBuckets(self.nn_module, comm_dtype=comm, shard_optional=bool(shard))
+            self.buckets = GradBuckets(self.nn_module, comm_dtype=comm, shard_optional=bool(shard), single_rank=single)
             if self._model_ema is not None:                   # ... so the EMA copy taken earlier must follow (val_step uses it)
                 self._model_ema.set(self.nn_module)
         self.optimizer = MouseModel.optimizer[oname](params, **okwargs)

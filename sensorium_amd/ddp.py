@@ -44,14 +44,45 @@ import torch
 import torch.distributed as dist
 
 
+import weakref
+
+def init_rccl(device: torch.device, **kwargs) -> None:
+    """``dist.init_process_group("nccl", device_id=device)`` with the RCCL kernels on a HIGH-PRIORITY stream.
+
+    Not a tuning nicety: HIP maps streams onto a few hardware queues (``GPU_MAX_HW_QUEUES``, 4 by default) and the stream
+    ProcessGroupNCCL takes from torch's normal-priority pool landed on the SAME hardware queue as the compute stream — every
+    collective then ran strictly between two compute kernels (rocprofv3, one rank over RCCL on an MI355X: 0 us of the 156 us
+    of collective kernels overlapped, ~10 us of idle on either side of each), i.e. the gradient exchange would not overlap
+    with backward at all.  On the high-priority pool's stream (or with ``GPU_MAX_HW_QUEUES=8`` in the environment before the
+    first HIP call — bench.py sets both) it gets a queue of its own and overlaps completely (tools/rccl_queue_probe.sh).
+    Call before anything else creates the default process group."""
+    opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    dist.init_process_group("nccl", device_id=device, pg_options=opts, **kwargs)
+
+
+_LIVE = weakref.WeakSet()          # GradBuckets with an exchange to run (flush_ready_all)
+
+
+def flush_ready_all() -> None:
+    """Called by the backward of a core block once its kernels are queued (sensorium_amd/ops.py): start the exchange of every
+    bucket that has become complete.  See ``GradBuckets._flush_ready`` for why not earlier."""
+    for gb in list(_LIVE):
+        if gb._ready:
+            gb._flush_ready()
+
+
 class GradBuckets:
     def __init__(self, module: torch.nn.Module, bucket_cap_mb: float = 12.0, process_group=None,
                  broadcast_init: bool = True, optional_prefixes=("readouts.",), comm_dtype: Optional[torch.dtype] = None,
-                 shard_optional: bool = False):
+                 shard_optional: bool = False, single_rank: bool = False):
+        """``single_rank``: run the whole exchange machinery (hooks, collectives in place, sharded optimizer) on a process
+        group of ONE rank too — every collective is then the identity, but it goes through the backend: this is how the RCCL
+        code path is exercised on a one-GPU box (tests/test_gpu_ddp.py)."""
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
-        self.shard = bool(shard_optional) and self.world > 1
+        self.active = self.world > 1 or (bool(single_rank) and dist.is_initialized())
+        self.shard = bool(shard_optional) and self.active
         self.module = module
         self.comm_dtype = None if comm_dtype in (None, torch.float32) else comm_dtype
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
@@ -61,7 +92,7 @@ class GradBuckets:
 
         def owner_module(p):          # "readouts.3.layer.1.weight" -> "readouts.3": sharded buckets never span two readouts
             return ".".join(name_of[id(p)].split(".")[:2])
-        if self.world > 1 and broadcast_init:
+        if self.active and broadcast_init:
             self._broadcast(list(module.parameters()) + list(module.buffers()))
         self.buckets: List[dict] = []
         cap = int(bucket_cap_mb * 1024 * 1024 / 4)
@@ -81,6 +112,7 @@ class GradBuckets:
         if cur:
             self._add_bucket(cur, id(cur[0]) in optional, owner_module(cur[0]))
         self._handles: List = []
+        self._ready: List = []                     # complete buckets whose collective has not been started yet (_flush_ready)
         self._param_handles: List = []
         self._flag_handle = None
         self._hooks = []
@@ -95,7 +127,8 @@ class GradBuckets:
                     self._owned[id(p)] = (a, z) if z > a else (0, 0)
                 sub = module.get_submodule(b["owner"])
                 self._module_hooks.append(sub.register_forward_pre_hook(lambda m, args: self.wait_params()))
-        if self.world > 1:
+        if self.active:
+            _LIVE.add(self)
             for bi, b in enumerate(self.buckets):
                 for p, off in zip(b["params"], b["offsets"]):
                     p._dwn_grad_slot = (b["flat"], off)       # ops.grad_out: the HIP backward writes the gradient here
@@ -205,6 +238,19 @@ class GradBuckets:
             self._flags_buf = self._flags_src.clone()
             self._flag_handle = (dist.all_reduce(self._flags_buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), sharded)
 
+    def _flush_ready(self):
+        """Start the exchange of the buckets that became complete earlier.  A collective costs the host 50-100 us
+        (ProcessGroup bookkeeping).  The head of the network (readout, cortex: short kernels) leaves the GPU waiting for the
+        host as it is, so the two big early buckets' collectives issued from their hooks were ~150 us of GPU idle time per
+        step (rocprofv3, one rank over RCCL).  They are started instead when the next core block's backward has just been
+        queued (``flush_ready_all`` from ops.BlockFn.backward: ~1.5 ms of kernels ahead of the host), and at ``finish()``."""
+        ready, self._ready = self._ready, []
+        for kind, bi in ready:
+            if kind == "optional":
+                self._launch_optional()
+            else:
+                self._launch(bi)
+
     def _make_hook(self, bi: int):
         def hook(param):
             b = self.buckets[bi]
@@ -219,14 +265,16 @@ class GradBuckets:
             b["arrived"][i] = True
             b["pending"] -= 1
             if b["pending"] == 0 and not b["optional"]:
-                self._launch_optional()          # same point of backward on every rank, before the first mandatory bucket
-                self._launch(bi)
+                # same point of backward on every rank: the optional buckets go before the first mandatory one
+                self._ready.append(("optional", bi))
+                self._ready.append(("bucket", bi))
         return hook
 
     def zero_grad(self, n_backward: int = 1):
         """Drop ``.grad`` so that the next backward writes straight into the buckets (no accumulate kernels).
         ``n_backward`` = backward passes that accumulate into this step's gradients (argus ``iter_size``): a bucket is
         reduced when every parameter has been visited that many times."""
+        self._ready = []
         for b in self.buckets:
             b["pending"] = b["count"] * int(n_backward)
             b["expect"] = b["pending"]
@@ -240,7 +288,8 @@ class GradBuckets:
         """Wait for the outstanding all-reduces (call after backward, before the optimizer step); afterwards every
         ``p.grad`` is a view of its bucket and holds the rank-averaged gradient (``None`` for an optional parameter no rank
         used)."""
-        if self.world > 1:
+        self._flush_ready()
+        if self.active:
             self._launch_optional()              # a model without mandatory parameters after the readouts: nothing triggered them
             for bi, b in enumerate(self.buckets):
                 if not b["optional"] and not b["launched"] and b["pending"] not in (0, b.get("expect", b["count"])):
@@ -271,7 +320,7 @@ class GradBuckets:
             for b in sharded:
                 b["used"] = used[k:k + b["count"]]
                 k += b["count"]
-        if self.world > 1:
+        if self.active:
             for bi, b in enumerate(self.buckets):
                 if bi not in reduced:
                     continue

@@ -63,6 +63,12 @@ def _f32_products(mod, inference_readout: bool = False) -> int:
     return L.F32_NATIVE if native else L.F32_AUTO
 
 
+def _ddp_flush() -> None:
+    from . import ddp
+    if ddp._LIVE:
+        ddp.flush_ready_all()
+
+
 def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
@@ -332,6 +338,7 @@ class BlockFn(torch.autograd.Function):
         ws = _ws(L.lib.dwn_block_workspace_bytes(C.byref(a), 1), dev)
         a.ws = ws.data_ptr(); a.ws_bytes = ws.numel()
         L.check(L.lib.dwn_block_backward(C.byref(a), dev.index, _stream(dev)), "dwn_block_backward")
+        _ddp_flush()            # this block's kernels are queued: a good moment for the host to start pending gradient exchanges
         grads = (dw_pw, dg[0], db[0], dw_dws, dg[1], db[1], dw_dwt, dg[2], db[2], dse_wr, dse_br, dse_we, dse_be,
                  dw_pwl, dg[3], db[3], dg[4], db[4])
         return (dx, None, None, None, None, None, None) + grads

@@ -19,7 +19,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if backend == "nccl":
-        dist.init_process_group("nccl", device_id=dev)
+        from sensorium_amd.ddp import init_rccl
+        init_rccl(dev)
     else:
         dist.init_process_group("gloo")
     from sensorium_amd.argus_models import MouseModel
@@ -36,7 +37,8 @@ def main():
                   drop_path_rate=0.0)
         shape = (2, 8, 36, 64)
     params = {"nn_module": ("dwiseneuro", kw), "loss": ("mice_poisson", {}), "optimizer": ("AdamW", {"lr": 1e-3, "weight_decay": 0.05}),
-              "device": str(dev), "amp": False, "iter_size": 1, "ddp_shard_optimizer": shard}
+              "device": str(dev), "amp": False, "iter_size": 1, "ddp_shard_optimizer": shard,
+              "ddp_single_rank": world == 1, "ddp_comm_dtype": "bf16" if "bf16comm" in sys.argv[2:] else None}
     torch.manual_seed(100 + rank)                     # different init per rank: the rank-0 broadcast must fix it (EMA copy too)
     model = MouseModel(params)
     model.set_ema(0.9)
@@ -91,7 +93,8 @@ def main():
         ddp_g = torch.where(mask > 0, ddp_g, mean_g)
     tot = float(mean_g.norm())
     err = float((ddp_g - mean_g).norm()) / tot
-    assert err < 1e-4, f"all-reduced gradients differ from the mean of the per-rank gradients: {err:.3e}"
+    bf16comm = "bf16comm" in sys.argv[2:]            # gradients cross the wire rounded to bf16: 2^-9 relative per element
+    assert err < (1e-2 if bf16comm else 1e-4), f"all-reduced gradients differ from the mean of the per-rank gradients: {err:.3e}"
     # gradients are views of the flat buckets
     b0 = model.buckets.buckets[0]
     assert b0["params"][0].grad.data_ptr() == b0["flat"].data_ptr()
@@ -127,11 +130,11 @@ def main():
     solid = mean_g.abs() > 1e-3 * mean_g.abs().mean()
     assert float(solid.float().mean()) > 0.8
     bad = float((((flat - want).abs() > 1e-5) & solid).float().mean())
-    assert bad < 1e-3, f"parameters after the step differ from torch.optim.AdamW on the averaged gradient: {bad:.2e} of elements"
+    assert bad < (5e-2 if bf16comm else 1e-3), f"parameters after the step differ from torch.optim.AdamW on the averaged gradient: {bad:.2e} of elements"
     ema_want = 0.9 * ema0 + 0.1 * want
     eflat = torch.cat([p.detach().reshape(-1) for p in model.model_ema.ema.parameters()])
     bad_e = float((((eflat - ema_want).abs() > 1e-5) & solid).float().mean())
-    assert bad_e < 1e-3, f"EMA parameters differ from 0.9 ema + 0.1 p: {bad_e:.2e} of elements"
+    assert bad_e < (5e-2 if bf16comm else 1e-3), f"EMA parameters differ from 0.9 ema + 0.1 p: {bad_e:.2e} of elements"
     if shard:
         st = model.optimizer.state[net.readouts[0].layer[1].weight]
         a, z = model.buckets.owned_range(net.readouts[0].layer[1].weight)
@@ -160,7 +163,10 @@ def main():
     model.buckets.zero_grad(1)
     net(batch[0], rank % 2).float().sum().backward()
     model.buckets.finish()
-    assert all(p.grad is not None for p in net.parameters())
+    if world > 1:
+        assert all(p.grad is not None for p in net.parameters())
+    else:                                              # one rank: nobody used readout 1, its gradient stays None
+        assert all((p.grad is None) == n.startswith("readouts.1.") for n, p in net.named_parameters())
 
     def opt_step():
         model.optimizer.step()

@@ -23,9 +23,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(backend, *extra):
+def _run(backend, *extra, nproc=2):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(ROOT / "tests" / "ddp_gpu_worker.py"), backend, *extra]
     res = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "DDP_WORKER_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
@@ -57,3 +57,13 @@ def test_two_ranks_sharing_one_gpu_gloo_metric_architecture():
     """The same checks on the benchmarked architecture (nine blocks, expansion 7, 1024-2048-4096 cortex, two readouts) at B=2:
     ~25 M parameters in several buckets split at the 12 MB cap, the real kernels' gradients written into the bucket slices."""
     _run("gloo", "full")
+
+
+@pytest.mark.parametrize("extra", [(), ("shard",), ("full",), ("bf16comm",)], ids=["allreduce", "sharded", "metric_arch", "bf16_exchange"])
+def test_one_rank_over_rccl(extra):
+    """RCCL on the one-GPU box: a process group of ONE rank over backend "nccl" with the exchange machinery forced on
+    (``ddp_single_rank``).  Every collective is the identity, but it goes through RCCL: ``init_process_group("nccl",
+    device_id=...)``, the flat-dtype broadcast, ``all_reduce(AVG)`` on fp32 and bf16 buffers launched from autograd hooks,
+    ``reduce_scatter_tensor`` / ``all_gather_into_tensor`` in place, handle waits against the HIP kernels' stream, barrier —
+    the calls the 8-GPU bench makes, with the same worker assertions (gradients, AdamW/EMA result, optional buckets)."""
+    _run("nccl", *extra, nproc=1)
