@@ -204,7 +204,8 @@ def test_exception_reaches_callbacks_and_propagates(tmp_path):
 
 
 def test_correlation_metric_matches_direct_corr():
-    """src/metrics.py:34-82: only rows with non-zero mouse weight count; (B,N,T) -> (B*T, N); mean over neurons, then mice."""
+    """src/metrics.py:34-82: only rows with non-zero mouse weight count; (B,N,T) -> (B*T, N); mean over neurons, then mice.
+    The metric keeps running sums instead of the epoch's tensors; the expected value below is the reference's procedure."""
     rng = np.random.default_rng(3)
     metric = CorrelationMetric()
     metric.reset()
@@ -221,9 +222,10 @@ def test_correlation_metric_matches_direct_corr():
     st = engine.State(phase="val")
     metric.epoch_complete(st)
     want = [corr(np.concatenate(keep[m][0]), np.concatenate(keep[m][1]), axis=0).mean() for m in (0, 1)]
-    assert st.metrics["val_corr_mouse_0"] == pytest.approx(want[0], abs=1e-7)
-    assert st.metrics["val_corr_mouse_1"] == pytest.approx(want[1], abs=1e-7)
-    assert st.metrics["val_corr"] == pytest.approx(np.mean(want), abs=1e-7)
+    # (the streaming float64 sums against the reference's float32 two-pass corr: rounding of the latter, ~1e-7)
+    assert st.metrics["val_corr_mouse_0"] == pytest.approx(want[0], abs=1e-6)
+    assert st.metrics["val_corr_mouse_1"] == pytest.approx(want[1], abs=1e-6)
+    assert st.metrics["val_corr"] == pytest.approx(np.mean(want), abs=1e-6)
     # a mouse with no weighted rows in the epoch is left out of the mean
     metric.reset()
     w = torch.tensor([[1.0, 0.0]] * 4)
