@@ -44,3 +44,31 @@ loss.backward()
 bwd = time.perf_counter() - a
 torch.cuda.synchronize()
 print(f"host enqueue with an empty queue: forward+loss {fwd*1e3:.2f} ms, backward {bwd*1e3:.2f} ms")
+
+# per autograd Function: host time of forward / backward calls (no synchronisation inside), averaged over 5 steps
+from sensorium_amd import ops
+acc = {}
+
+
+def wrap(cls, name):
+    for which in ("forward", "backward"):
+        fn = getattr(cls, which)
+
+        def timed(*a, _fn=fn, _key=f"{name}.{which}", **k):
+            t = time.perf_counter()
+            r = _fn(*a, **k)
+            d = acc.setdefault(_key, [0.0, 0])
+            d[0] += time.perf_counter() - t
+            d[1] += 1
+            return r
+        setattr(cls, which, staticmethod(timed))
+
+
+for cls, name in ((ops.StemFn, "stem"), (ops.BlockFn, "block"), (ops.PoolFn, "pool"), (ops.CortexFn, "cortex"),
+                  (ops.ReadoutFn, "readout"), (ops.PoissonLossFn, "poisson")):
+    wrap(cls, name)
+for _ in range(5):
+    model.train_step(batch, sync_loss=False)
+torch.cuda.synchronize()
+for k, (t, n) in sorted(acc.items()):
+    print(f"{k:18s} {t / n * 1e6:8.1f} us per call  x {n // 5} calls per step = {t / 5 * 1e3:6.2f} ms per step")
