@@ -1492,13 +1492,17 @@ __global__ __launch_bounds__(256, DWT_RC_MINW) void dw_temporal_bwd_rc_kernel(co
                         for (int i = 0; i < 4; ++i) {
                             const float r = round_t<T>(dh[i]);
                             st0[i] += r;
-                            st1[i] += r * (yw[s0][i] - bm[i]) * bi[i];
+                            st1[i] = fmaf(r, yw[s0][i], st1[i]);          // raw sum(dh2 * y2): normalised once, below
                         }
                     }
                 }
             }
         }
     }
+    // sum(dh2 * (y2 - mean) * invstd) = invstd * (sum(dh2 * y2) - mean * sum(dh2)): two VALU operations per element less in
+    // a kernel that is VALU-bound (as in the spatial backward kernels and the dh3 GEMM epilogue)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st1[i] = bi[i] * fmaf(-bm[i], st0[i], st1[i]);
     DET_WAVES_BEGIN
     if (chan_ok) {
 #pragma unroll
