@@ -818,7 +818,9 @@ __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFw
             const i64 b = pos / a.HW, hw = pos % a.HW;
             const T* ip = inp + (b * a.T * a.HW + hw) * a.C + chan;      // element (t = 0)
             T* op = outp + (b * a.T * a.HW + hw) * a.C + chan;
-            float win[KT][4];                                           // win[k] = z2(t + k - P)
+            // ring of KT slots, KT frames per unrolled batch: at step u of a batch z2(t + k - P) lives in slot (u + k) % KT — compile-time
+            // indices, no register shifting (the shifting version spent 52 moves per 16 outputs)
+            float win[KT][4];
             [[maybe_unused]] float ps[4] = {0.f, 0.f, 0.f, 0.f};         // ZOUT: this position's sums over t of the stored z3
 #pragma unroll
             for (int k = 0; k < KT - 1; ++k) {
@@ -826,24 +828,25 @@ __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFw
                 if (t >= 0 && t < a.T) { ld4<T>(ip + t * tstride, win[k]); bn_silu4(win[k], bs, bt); }
                 else { win[k][0] = win[k][1] = win[k][2] = win[k][3] = 0.f; }
             }
-            for (int t0 = 0; t0 < a.T; t0 += 4) {
-                raw_t raw[4];
+            for (int t0 = 0; t0 < a.T; t0 += KT) {
+                raw_t raw[KT];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < KT; ++u) {
                     int tl = t0 + u + P;
                     raw[u] = ld4_raw<T>(ip + (tl < a.T ? tl : 0) * tstride);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < KT; ++u) {
                     int t = t0 + u;
                     if (t >= a.T) break;
-                    if (t + P < a.T) { V4<T>::unpack(raw[u], win[KT - 1]); bn_silu4(win[KT - 1], bs, bt); }
-                    else { win[KT - 1][0] = win[KT - 1][1] = win[KT - 1][2] = win[KT - 1][3] = 0.f; }
+                    const int sn = (u + KT - 1) % KT;                   // newest slot: frame t + P
+                    if (t + P < a.T) { V4<T>::unpack(raw[u], win[sn]); bn_silu4(win[sn], bs, bt); }
+                    else { win[sn][0] = win[sn][1] = win[sn][2] = win[sn][3] = 0.f; }
                     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int k = 0; k < KT; ++k)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[k][i], win[k][i], acc[i]);
+                        for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[k][i], win[(u + k) % KT][i], acc[i]);
                     if constexpr (ZOUT) {
                         float z[4];
 #pragma unroll
@@ -861,10 +864,6 @@ __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFw
                             st1[i] += r * r;
                         }
                     }
-#pragma unroll
-                    for (int k = 0; k < KT - 1; ++k)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) win[k][i] = win[k + 1][i];
                 }
             }
             if constexpr (ZOUT) {
