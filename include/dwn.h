@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DWN_ABI_VERSION 4
+#define DWN_ABI_VERSION 5
 #define DWN_F32 0
 #define DWN_BF16 1
 /* How the dtype-f32 GEMMs of a block / cortex layer / readout multiply.  NATIVE: v_mfma_f32_16x16x4_f32.  SPLIT3: each operand
@@ -47,6 +47,9 @@ extern "C" {
 #define DWN_LD_AFFINE2 3 /* v1*p + v2*q + v3                     (BatchNorm backward) */
 #define DWN_LD_DY3 4     /* v1*((p*gate[b]+gate2[b])*silu'(v4*q+v5)) + v2*q + v3 (SE + BN3 backward) */
 #define DWN_LD_GATE 5    /* p * gate[b]                          (SE gate on a materialised activation) */
+#define DWN_LD_CAT1 6    /* columns [0, cat_c1): p (row stride ld); [cat_c1, cat_c1 + cat_c2): q (row stride ld2); beyond: 1.0
+                          * — dwn_gemm_tn's P operand only: [dh1 | a0 | 1]^T a0 gives the three raw products of the conv_pw
+                          * weight gradient in one pass (dwn_block_backward; csrc/dwn_elementwise.hip k_pw_wgrad_fold) */
 
 typedef struct dwn_load_desc {
     const void* p;
@@ -67,6 +70,8 @@ typedef struct dwn_load_desc {
     const float* pe_w;
     int pT, pH, pW;
     int pe_ld;
+    long long ld2;          /* DWN_LD_CAT1: row stride of q */
+    int cat_c1, cat_c2;     /* DWN_LD_CAT1: columns taken from p / from q */
 } dwn_load_desc;
 
 #define DWN_EPI_STORE 0
@@ -390,18 +395,24 @@ int dwn_ema_lerp_multi(const dwn_tensor_entry* list, int ntensors, int max_block
                        void* stream);
 
 
-/* conv_pw backward (dwiseneuro.py:90-93 backward) of a 64-channel block in ONE pass over dh1 / y1:
- *   dy1 = abc[0]*dh1 + abc[1]*y1 + abc[2]  (BatchNorm-backward affine, per channel of E; abc is [3][E]),
- *   da0[M][Cin] = dy1 . W1,   dw[E][Cin] += dy1^T . a0   (dw fp32, accumulated: zero it first).
- * w1t = W1^T as [Cin][E] in `dtype`.  Built for dtype == DWN_BF16, Cin == 64, E == 448, M % 128 == 0
- * (dwn_pw_bwd_fused_supported); anything else returns -3 and the caller uses dwn_gemm_nn + dwn_gemm_tn. */
+/* conv_pw backward (dwiseneuro.py:90-93 backward) WITHOUT reading y1.  With the BatchNorm-1 backward affine
+ *   dy1 = abc[0]*dh1 + abc[1]*y1 + abc[2]   (per channel of E; abc is [3][E])   and   y1 = a0 . W1^T,
+ * both products fold the y1 term into Cin x Cin matrices:
+ *   da0[M][Cin] = dy1 . W1    = [dh1 | a0] . [diag(abc0) W1 ; W1^T diag(abc1) W1] + abc2 . W1
+ *   dw[E][Cin]  = dy1^T . a0  = diag(abc0) (dh1^T a0) + diag(abc1) W1 (a0^T a0) + abc2 (1^T a0)     (fp32, overwritten)
+ * so the E-wide traffic is one read of dh1 (dtype == DWN_BF16, Cin == 64, E == 448, M % 128 == 0 — see
+ * dwn_pw_bwd_fused_supported — one kernel computes both products from a single pass) or two (dwn_gemm_nn with the
+ * K-concatenated operand + dwn_gemm_tn with the DWN_LD_CAT1 loader).  w_pw = conv_pw.0.weight [E][Cin] fp32 (used as rounded
+ * to `dtype`, the values the forward multiplied with).  ws: dwn_pw_backward_workspace_bytes(E, Cin, dtype) bytes, 256-aligned. */
 typedef struct dwn_pw_bwd_args {
-    const void* dh1; const void* y1; const void* a0; const void* w1t; const float* abc;
+    const void* dh1; const void* a0; const float* w_pw; const float* abc;
     void* da0; float* dw;
     long long M; int E; int Cin;
+    void* ws; size_t ws_bytes;
 } dwn_pw_bwd_args;
 int dwn_pw_bwd_fused_supported(int dtype, long long M, int E, int Cin);
-int dwn_pw_bwd_fused(const dwn_pw_bwd_args* a, int dtype, int device, void* stream);
+size_t dwn_pw_backward_workspace_bytes(int E, int Cin, int dtype);
+int dwn_pw_backward(const dwn_pw_bwd_args* a, int dtype, int device, void* stream);
 
 /* ---- spat_covn_dw WITHOUT a materialised conv_pw output (dwiseneuro.py:90-102; bf16 storage, 3x3, stride 1 or 2,
  * Cin in {64, 128}, E % 64 == 0).  y1 = a0 . W1^T is the widest tensor at input resolution although it is a Cin-deep

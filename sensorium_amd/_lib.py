@@ -32,7 +32,7 @@ c_sz = C.c_size_t
 
 DWN_F32, DWN_BF16 = 0, 1
 DWN_NREP = 32
-LD_PLAIN, LD_PE, LD_BNACT, LD_AFFINE2, LD_DY3, LD_GATE = 0, 1, 2, 3, 4, 5
+LD_PLAIN, LD_PE, LD_BNACT, LD_AFFINE2, LD_DY3, LD_GATE, LD_CAT1 = 0, 1, 2, 3, 4, 5, 6
 EPI_STORE, EPI_READOUT, EPI_DG, EPI_STORE_CAT, EPI_DH3 = 0, 1, 2, 3, 4
 NN_AUTO, NN_XL128, NN_XL256, NN_TILE128 = 0, 1, 2, 3
 F32_AUTO, F32_NATIVE, F32_SPLIT3 = 0, 1, 2
@@ -45,7 +45,7 @@ class LoadDesc(C.Structure):
     _fields_ = [("p", c_p), ("q", c_p), ("ld", c_ll), ("v1", c_p), ("v2", c_p), ("v3", c_p), ("v4", c_p),
                 ("v5", c_p), ("gate", c_p), ("gate2", c_p), ("gate_ld", c_i), ("rows_per_sample", c_i),
                 ("act", c_i), ("pe_t", c_p), ("pe_h", c_p), ("pe_w", c_p), ("pT", c_i), ("pH", c_i),
-                ("pW", c_i), ("pe_ld", c_i)]
+                ("pW", c_i), ("pe_ld", c_i), ("ld2", c_ll), ("cat_c1", c_i), ("cat_c2", c_i)]
 
 
 class GemmNNArgs(C.Structure):
@@ -155,8 +155,8 @@ class ClipDesc(C.Structure):
 
 
 class PwBwdArgs(C.Structure):
-    _fields_ = [("dh1", c_p), ("y1", c_p), ("a0", c_p), ("w1t", c_p), ("abc", c_p), ("da0", c_p), ("dw", c_p),
-                ("M", c_ll), ("E", c_i), ("Cin", c_i)]
+    _fields_ = [("dh1", c_p), ("a0", c_p), ("w_pw", c_p), ("abc", c_p), ("da0", c_p), ("dw", c_p),
+                ("M", c_ll), ("E", c_i), ("Cin", c_i), ("ws", c_p), ("ws_bytes", c_sz)]
 
 
 class DwSpatialRcFwdArgs(C.Structure):
@@ -218,7 +218,8 @@ SYMBOLS = {
     "dwn_adamw_ema_multi": (c_i, [c_p, c_i, c_i, c_d, c_d, c_d, c_d, c_d, c_ll, c_d, c_d, c_i, c_p]),
     "dwn_ema_lerp_multi": (c_i, [c_p, c_i, c_i, c_d, c_i, c_p]),
     "dwn_pw_bwd_fused_supported": (c_i, [c_i, c_ll, c_i, c_i]),
-    "dwn_pw_bwd_fused": (c_i, [_P(PwBwdArgs), c_i, c_i, c_p]),
+    "dwn_pw_backward_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "dwn_pw_backward": (c_i, [_P(PwBwdArgs), c_i, c_i, c_p]),
     "dwn_dw_spatial_rc_blob_bytes": (c_sz, [c_i, c_i]),
     "dwn_dw_spatial_rc_prep": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_p]),
     "dwn_dw_spatial_rc_supported": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
@@ -255,7 +256,7 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.dwn_abi_version() != 4:
+    if lib.dwn_abi_version() != 5:
         raise ImportError("libdwiseneuro_hip.so ABI version mismatch")
     built, have = lib.dwn_source_hash().decode(), source_hash()
     if built != have and not os.environ.get("DWN_LIB_PATH"):        # (an explicitly chosen other build is an A/B run)

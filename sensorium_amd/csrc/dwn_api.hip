@@ -168,6 +168,7 @@ struct BlockWs {
     float *abc1, *abc2, *abc3, *abc4, *abcsc, *ident3;
     float *dgp, *dhp, *dps;
     void* bp; float* r3; float* gacc;                      // conv_pw data-gradient folding (see dwn_elementwise.hip)
+    float* tacc;                                           // conv_pw weight gradient: raw products T1 / Ga / s (k_pw_wgrad_fold)
     void* wgated;                                          // [B][Cout][Cmid] W2 . diag(gate_b) (forward only)
     void* rcblob;                                          // eval forward: slice images of the y1-recomputing stencil
     float* pb;                                             // [B][Cout][Cmid] per-sample dy4^T z3 (backward, see pwl_bwd_per_sample)
@@ -232,6 +233,7 @@ BlockWs carve_block(const dwn_block_args& a, int backward, void* base, size_t ca
         w.bp = c.take<char>((size_t)a.Cin * (a.Cmid + a.Cin) * ts);
         w.gacc = c.take<float>(pw_fold_floats(a.Cin));                  // one zeroed range: G accumulator, r3
         w.r3 = w.gacc + (size_t)a.Cin * a.Cin;
+        w.tacc = c.take<float>(pw_wgrad_tacc_floats(a.Cmid, a.Cin));
         if (pwl_bwd_per_sample(a)) w.pb = c.take<float>((size_t)a.B * a.Cout * a.Cmid);
     }
     w.bytes = c.off + 256;
@@ -502,6 +504,30 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     return 0;
 }
 
+// conv_pw backward from (dh1, a0, W1, BatchNorm-1 backward coefficients): da0 and dW1, y1 not read (see the comment at its call
+// in dwn_block_backward).  gacc (pw_fold_floats) and tacc (pw_wgrad_tacc_floats) must be zero on entry.
+static int pw_backward(int dt, const void* dh1, const void* a0, const float* w_pw, const float* abc, int E, int Cin, i64 M,
+                       void* bp, float* gacc, float* r3, float* tacc, void* da0, float* dw, hipStream_t s) {
+    TRY(k_pw_bwd_prep(w_pw, abc, E, Cin, bp, gacc, r3, dt, s));
+    if (pw_bwd_fused_supported(dt, M, E, Cin)) {
+        // 64-channel blocks: both products from ONE pass over dh1
+        PROF(DWN_FAM_PW_DGRAD, launch_pw_bwd_fused(dh1, a0, bp, r3, da0, tacc, M, E, Cin, dt, s));
+    } else {
+        {
+            GemmNN g = nn_base(ld_plain(dh1, E), LD_PLAIN, bp, (i64)E + Cin, da0, Cin, (int)M, Cin, E + Cin, 1);
+            g.epi = EPI_STORE_CAT; g.a2 = a0; g.a2_ld = Cin; g.K1 = E; g.bias = r3;
+            PROF(DWN_FAM_PW_DGRAD, launch_gemm_nn(g, dt, s));
+        }
+        {   // raw products [dh1 | a0 | 1]^T a0 -> tacc
+            LoadDesc cat = ld_plain(dh1, E);
+            cat.q = a0; cat.ld2 = Cin; cat.cat_c1 = E; cat.cat_c2 = Cin;
+            GemmTN g = tn_base(cat, LD_CAT1, ld_plain(a0, Cin), LD_PLAIN, (int)M, E + Cin + 8, Cin, tacc, Cin, 1);
+            PROF(DWN_FAM_PW_WGRAD, launch_gemm_tn(g, dt, s));
+        }
+    }
+    return k_pw_wgrad_fold(tacc, abc, w_pw, E, Cin, dw, dt, s);
+}
+
 int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     ENTER(device);
     const dwn_block_args& a = *ap;
@@ -522,15 +548,14 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
         ok = ok && pa.packdw(a.w_dwt, w.wdwt, a.Cmid, a.kt);
         ok = ok && pa.fill(w.ident3, 1.0f, a.Cmid);
         ok = ok && pa.fill(w.ident3 + a.Cmid, 0.0f, 2 * a.Cmid);
-        // the four atomically accumulated weight gradients are cleared here (callers pass uninitialised buffers)
-        ok = ok && pa.zero(a.dw_pw, (size_t)a.Cmid * a.Cin * sizeof(float));
+        // the atomically accumulated weight gradients are cleared here (callers pass uninitialised buffers); dw_pw is written
+        // whole by k_pw_wgrad_fold from the raw products accumulated in tacc
         ok = ok && pa.zero(a.dw_dws, (size_t)a.Cmid * a.ks * a.ks * sizeof(float));
         ok = ok && pa.zero(a.dw_dwt, (size_t)a.Cmid * a.kt * sizeof(float));
         ok = ok && pa.zero(a.dw_pwl, (size_t)a.Cout * a.Cmid * sizeof(float));
         if (w.pb) ok = ok && pa.zero(w.pb, (size_t)a.B * a.Cout * a.Cmid * sizeof(float));
-        const bool pw_fused = dwn_pw_bwd_fused_supported(dt, Min, a.Cmid, a.Cin) != 0;
-        if (pw_fused) ok = ok && pa.packw(a.w_pw, w.wpw, 1, a.Cmid, a.Cin, 1, a.Cin, a.Cmid);       // W1^T [Cin][Cmid]
-        else ok = ok && pa.zero(w.gacc, pw_fold_floats(a.Cin) * sizeof(float));
+        ok = ok && pa.zero(w.gacc, pw_fold_floats(a.Cin) * sizeof(float));
+        ok = ok && pa.zero(w.tacc, pw_wgrad_tacc_floats(a.Cmid, a.Cin) * sizeof(float));
         if (!ok) return dwn_set_error(-2, "block_backward: workspace arena and dw_* buffers must be 16-byte aligned");
         TRY(k_prep(pa, dt, s));
     }
@@ -608,25 +633,10 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
         PROF(DWN_FAM_DWS_BWD, launch_dw_spatial_bwd(d, dt, s));
     }
     TRY(k_bn_bwd_finalize(w.st1, (double)Min, a.bn1.coef, a.bn1.dgamma, a.bn1.dbeta, w.abc1, a.Cmid, s));
-    // conv_pw backward.  Data gradient: dy1 = A1*dh1 + A2*y1 + A3 with y1 = a0.W1^T, so the y1 term folds into a
-    // Cin x Cin matrix and the GEMM reads dh1 (+ the small a0) only:  da0 = [dh1 | a0] . [diag(A1) W1 ; G] + r3
-    if (dwn_pw_bwd_fused_supported(dt, Min, a.Cmid, a.Cin)) {
-        // 64-channel blocks: data gradient and weight gradient from one pass over (dh1, y1)
-        PROF(DWN_FAM_PW_DGRAD, launch_pw_bwd_fused(dh1, a.y1, xin.p, w.wpw, w.abc1, a.da0, a.dw_pw, Min, a.Cmid, a.Cin, dt, s));
-    } else {
-        TRY(k_pw_bwd_prep(a.w_pw, w.abc1, a.Cmid, a.Cin, w.bp, w.gacc, w.r3, dt, s));
-        {
-            GemmNN g = nn_base(ld_plain(dh1, a.Cmid), LD_PLAIN, w.bp, (i64)a.Cmid + a.Cin, a.da0, a.Cin, (int)Min, a.Cin,
-                               a.Cmid + a.Cin, 1);
-            g.epi = EPI_STORE_CAT; g.a2 = xin.p; g.a2_ld = a.Cin; g.K1 = a.Cmid; g.bias = w.r3;
-            PROF(DWN_FAM_PW_DGRAD, launch_gemm_nn(g, dt, s));
-        }
-        {   // weight gradient: dW1 = dy1^T a0 with the BatchNorm-backward affine applied while loading (dh1, y1)
-            LoadDesc dy1 = ld_affine2(dh1, a.y1, a.Cmid, w.abc1, a.Cmid);
-            GemmTN g = tn_base(dy1, LD_AFFINE2, xin, LD_PLAIN, (int)Min, a.Cmid, a.Cin, a.dw_pw, a.Cin, 1);
-            PROF(DWN_FAM_PW_WGRAD, launch_gemm_tn(g, dt, s));
-        }
-    }
+    // conv_pw backward WITHOUT y1.  dy1 = A1*dh1 + A2*y1 + A3 is linear and y1 = a0.W1^T, so the y1 terms fold into Cin x Cin
+    // matrices on either side:  da0 = [dh1 | a0] . [diag(A1) W1 ; G] + r3  (Bp, r3: k_pw_bwd_prep) and
+    // dW1 = diag(A1) (dh1^T a0) + diag(A2) W1 (a0^T a0) + A3 (1^T a0)  (raw products in tacc, folded by k_pw_wgrad_fold)
+    TRY(pw_backward(dt, dh1, xin.p, a.w_pw, w.abc1, a.Cmid, a.Cin, Min, w.bp, w.gacc, w.r3, w.tacc, a.da0, a.dw_pw, s));
     PROF(DWN_FAM_RESID_BWD, k_residual_bwd_dx(xin, a.da0, a.dout, w.abcsc, gm, a.dx, dt, s));
     return 0;
 }
@@ -866,12 +876,25 @@ int dwn_ema_lerp_multi(const dwn_tensor_entry* list, int ntensors, int max_block
 int dwn_pw_bwd_fused_supported(int dtype, long long M, int E, int Cin) {
     return pw_bwd_fused_supported(dtype, M, E, Cin) ? 1 : 0;
 }
-int dwn_pw_bwd_fused(const dwn_pw_bwd_args* a, int dtype, int device, void* stream) {
+size_t dwn_pw_backward_workspace_bytes(int E, int Cin, int dtype) {
+    return (size_t)Cin * (E + Cin) * tsize(dtype) + 256 + (pw_fold_floats(Cin) + pw_wgrad_tacc_floats(E, Cin)) * sizeof(float) + 256;
+}
+int dwn_pw_backward(const dwn_pw_bwd_args* a, int dtype, int device, void* stream) {
     ENTER(device);
-    if (!a || !a->dh1 || !a->y1 || !a->a0 || !a->w1t || !a->abc || !a->da0 || !a->dw)
-        return dwn_set_error(-1, "pw_bwd_fused: null pointer");
-    return launch_pw_bwd_fused(a->dh1, a->y1, a->a0, a->w1t, a->abc, a->da0, a->dw, a->M, a->E, a->Cin, dtype,
-                               (hipStream_t)stream);
+    if (!a || !a->dh1 || !a->a0 || !a->w_pw || !a->abc || !a->da0 || !a->dw || !a->ws)
+        return dwn_set_error(-1, "pw_backward: null pointer");
+    if (a->E <= 0 || a->Cin <= 0 || a->E % 8 || a->Cin % 8 || a->M <= 0 || a->M > 0x7fffffffLL)
+        return dwn_set_error(-2, "pw_backward: E and Cin must be positive multiples of 8, 0 < M < 2^31");
+    if (a->ws_bytes < dwn_pw_backward_workspace_bytes(a->E, a->Cin, dtype)) return dwn_set_error(-6, "pw_backward: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    Carver c(a->ws, a->ws_bytes);
+    void* bp = c.take<char>((size_t)a->Cin * (a->E + a->Cin) * tsize(dtype));
+    const size_t nz = pw_fold_floats(a->Cin) + pw_wgrad_tacc_floats(a->E, a->Cin);
+    float* gacc = c.take<float>(nz);
+    float* r3 = gacc + (size_t)a->Cin * a->Cin;
+    float* tacc = gacc + pw_fold_floats(a->Cin);
+    TRY(k_zero(gacc, nz * sizeof(float), s));
+    return pw_backward(dtype, a->dh1, a->a0, a->w_pw, a->abc, a->E, a->Cin, a->M, bp, gacc, r3, tacc, a->da0, a->dw, s);
 }
 
 int dwn_assemble_inputs(const dwn_clip_desc* descs, int B, int T, int H0, int W0, int H, int W, float pad_fill,

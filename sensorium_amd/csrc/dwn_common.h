@@ -178,7 +178,7 @@ __device__ __forceinline__ void ldc4(const float* p, float* o) {
 // ---- the operand "loader": how a kernel reads one 16-byte channel vector of an operand.
 // Fusing the producer's batch-norm / activation / gate / positional-encoding / BN-backward affine
 // into the consumer's load is what removes the elementwise HBM round trips.
-enum { LD_PLAIN = 0, LD_PE = 1, LD_BNACT = 2, LD_AFFINE2 = 3, LD_DY3 = 4, LD_GATE = 5 };
+enum { LD_PLAIN = 0, LD_PE = 1, LD_BNACT = 2, LD_AFFINE2 = 3, LD_DY3 = 4, LD_GATE = 5, LD_CAT1 = 6 };
 
 typedef dwn_load_desc LoadDesc;   // field meanings: include/dwn.h and the loader below
 

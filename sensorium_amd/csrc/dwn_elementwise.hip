@@ -2210,3 +2210,87 @@ int k_pw_bwd_prep(const float* w1, const float* abc, int E, int C, void* bp, flo
     DWN_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// conv_pw weight gradient without reading y1.  dW1 = dy1^T a0 with dy1 = A1*dh1 + A2*y1 + A3 and y1 = a0 . W1^T:
+//   dW1 = diag(A1) (dh1^T a0) + diag(A2) W1 (a0^T a0) + A3 (1^T a0)
+// The three raw products (T1, Ga, s: rows of tacc) come from one pass over dh1 and the narrow a0 — the fused kernel of the
+// 64-channel blocks, or gemm_tn with the concatenating P loader [dh1 | a0 | 1] — and this kernel folds them: one thread per
+// dW element, a C-long dot product against Ga's column (coalesced) and W1's row (one row per wave: broadcast loads).
+// ------------------------------------------------------------------------------------------------
+size_t pw_wgrad_tacc_floats(int E, int C) { return (size_t)(E + C + 8) * C; }
+template <typename T>
+__global__ __launch_bounds__(256) void pw_wgrad_fold_kernel(const float* __restrict__ tacc, const float* __restrict__ abc,
+                                                            const float* __restrict__ w1, int E, int C, float* __restrict__ dw) {
+    const i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (i64)E * C) return;
+    const int e = (int)(idx / C), c = (int)(idx % C);
+    const float* ga = tacc + (i64)E * C + c;
+    const float* wrow = w1 + (i64)e * C;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    for (int cp = 0; cp < C; cp += 4) {          // C % 8 == 0
+        g0 = fmaf(round_t<T>(wrow[cp]), ga[(i64)cp * C], g0);
+        g1 = fmaf(round_t<T>(wrow[cp + 1]), ga[(i64)(cp + 1) * C], g1);
+        g2 = fmaf(round_t<T>(wrow[cp + 2]), ga[(i64)(cp + 2) * C], g2);
+        g3 = fmaf(round_t<T>(wrow[cp + 3]), ga[(i64)(cp + 3) * C], g3);
+    }
+    const float g = (g0 + g1) + (g2 + g3);
+    dw[idx] = fmaf(abc[e], tacc[idx], fmaf(abc[E + e], g, abc[2 * E + e] * tacc[(i64)(E + C) * C + c]));
+}
+// C in {64, 128, 256}: a workgroup owns 16 * (256 / C) rows of dW; a thread one column c and 16 rows.  W1's rows are staged
+// transposed in LDS ([c'][row]: four broadcast ds_read_b128 per c'), Ga's column element is one coalesced load per c' — the
+// thread-per-element kernel above re-reads W1's row and Ga's column per element and ran at the L1 rate (30 us at E = 1792, C = 256)
+template <typename T, int CC>
+__global__ __launch_bounds__(256) void pw_wgrad_fold_tile_kernel(const float* __restrict__ tacc, const float* __restrict__ abc,
+                                                                 const float* __restrict__ w1, int E, float* __restrict__ dw) {
+    constexpr int G = 256 / CC, ROWS = 16 * G;
+    __shared__ __attribute__((aligned(16))) float sw[CC][ROWS];          // sw[c'][row] = round(W1[e0 + row][c'])
+    const int tid = threadIdx.x, e0 = blockIdx.x * ROWS;
+    for (int i = tid; i < ROWS * CC; i += 256) {
+        const int row = i / CC, cp = i % CC;
+        sw[cp][row] = e0 + row < E ? round_t<T>(w1[(i64)(e0 + row) * CC + cp]) : 0.f;
+    }
+    __syncthreads();
+    const int c = tid % CC, gq = tid / CC;
+    const float* ga = tacc + (i64)E * CC + c;
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+    for (int cp = 0; cp < CC; ++cp) {
+        const float gv = ga[(i64)cp * CC];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const float4 w4 = *reinterpret_cast<const float4*>(&sw[cp][gq * 16 + r4 * 4]);
+            acc[r4 * 4 + 0] = fmaf(w4.x, gv, acc[r4 * 4 + 0]);
+            acc[r4 * 4 + 1] = fmaf(w4.y, gv, acc[r4 * 4 + 1]);
+            acc[r4 * 4 + 2] = fmaf(w4.z, gv, acc[r4 * 4 + 2]);
+            acc[r4 * 4 + 3] = fmaf(w4.w, gv, acc[r4 * 4 + 3]);
+        }
+    }
+    const float sc = tacc[(i64)(E + CC) * CC + c];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int e = e0 + gq * 16 + r;
+        if (e < E) dw[(i64)e * CC + c] = fmaf(abc[e], tacc[(i64)e * CC + c], fmaf(abc[E + e], acc[r], abc[2 * E + e] * sc));
+    }
+}
+int k_pw_wgrad_fold(const float* tacc, const float* abc, const float* w1, int E, int C, float* dw, int dtype, hipStream_t s) {
+#define FOLD_TILE(CC_) do { \
+        dim3 grid((unsigned)((E + 16 * (256 / CC_) - 1) / (16 * (256 / CC_)))); \
+        DISPATCH_T(dtype, \
+            hipLaunchKernelGGL((pw_wgrad_fold_tile_kernel<bf16_t, CC_>), grid, dim3(256), 0, s, tacc, abc, w1, E, dw), \
+            hipLaunchKernelGGL((pw_wgrad_fold_tile_kernel<float, CC_>), grid, dim3(256), 0, s, tacc, abc, w1, E, dw)); \
+        DWN_CHECK_LAUNCH(); \
+        return 0; } while (0)
+    if (C == 64) FOLD_TILE(64);
+    if (C == 128) FOLD_TILE(128);
+    if (C == 256) FOLD_TILE(256);
+#undef FOLD_TILE
+    dim3 grid((unsigned)(((i64)E * C + 255) / 256));
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL((pw_wgrad_fold_kernel<bf16_t>), grid, dim3(256), 0, s, tacc, abc, w1, E, C, dw),
+        hipLaunchKernelGGL((pw_wgrad_fold_kernel<float>), grid, dim3(256), 0, s, tacc, abc, w1, E, C, dw));
+    DWN_CHECK_LAUNCH();
+    return 0;
+}

@@ -883,6 +883,9 @@ int launch_gemm_nn(const GemmNN& g, int dtype, hipStream_t s) {
 #ifndef TN_MINW_PLAIN
 #define TN_MINW_PLAIN 3
 #endif
+template <typename T> static __device__ __forceinline__ uint4 ones_vec();      // one 16-byte vector of 1.0
+template <> __device__ __forceinline__ uint4 ones_vec<bf16_t>() { return make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u); }
+template <> __device__ __forceinline__ uint4 ones_vec<float>() { return make_uint4(0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u); }
 template <typename T> struct TnCfg;
 template <> struct TnCfg<bf16_t> { static constexpr int PAD = 32; };   // 8 rows x 32 B shift -> conflict-free tr reads
 template <> struct TnCfg<float>  { static constexpr int PAD = 64; };   // 16-bank shift between the two rows of a half-wave
@@ -952,7 +955,7 @@ __global__ __launch_bounds__(256, (TnOcc<PLD, QLD>::value)) void gemm_tn_kernel(
     const int chq = tid % CPR;
     const int rcol = r0 + chq * KC, ccol = c0 + chq * KC;
     const bool rok = rcol < Rl, cok = ccol < g.Cc;
-    ColCoef<PLD == LD_PE ? LD_PLAIN : PLD, T> cfp;
+    ColCoef<(PLD == LD_PE || PLD == LD_CAT1) ? LD_PLAIN : PLD, T> cfp;
     ColCoef<QLD == LD_PE ? LD_PLAIN : QLD, T> cfq;
     if (rok) cfp.load(g.p, pcol0 + rcol);
     if (cok) cfq.load(g.q, qcol0 + ccol);
@@ -960,13 +963,23 @@ __global__ __launch_bounds__(256, (TnOcc<PLD, QLD>::value)) void gemm_tn_kernel(
     const T* Pq = reinterpret_cast<const T*>(g.p.q);
     const T* Qp = reinterpret_cast<const T*>(g.q.p);
     const T* Qq = reinterpret_cast<const T*>(g.q.q);
+    // LD_CAT1: P = [p | q | 1] side by side; this thread's column chunk lies in one segment for the whole kernel
+    // (cat_c1, cat_c2 are multiples of the 16-byte vector), so the segment only selects its base pointer and row stride
+    i64 pld = g.p.ld;
+    int pcol = pcol0 + rcol;
+    [[maybe_unused]] bool p_ones = false;
+    if constexpr (PLD == LD_CAT1) {
+        if (rcol >= g.p.cat_c1 + g.p.cat_c2) p_ones = true;
+        else if (rcol >= g.p.cat_c1) { Pp = Pq; pld = g.p.ld2; pcol = rcol - g.p.cat_c1; }
+    }
     auto load_tiles = [&](i64 mb) {
         ld_mb = mb;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             i64 m = mb + tid / CPR + (256 / CPR) * i;
             const bool mok = m < mend;
-            const i64 offp = (mok && rok) ? m * g.p.ld + pcol0 + rcol : 0;
+            i64 offp = (mok && rok) ? m * pld + pcol : 0;
+            if constexpr (PLD == LD_CAT1) { if (p_ones) offp = 0; }
             const i64 offq = (mok && cok) ? m * g.q.ld + qcol0 + ccol : 0;
             if constexpr (PLD != LD_PE) {
                 p1[i] = *reinterpret_cast<const uint4*>(Pp + offp);
@@ -991,6 +1004,7 @@ __global__ __launch_bounds__(256, (TnOcc<PLD, QLD>::value)) void gemm_tn_kernel(
             const bool mok = m < mend;
             uint4 vp, vq;
             if constexpr (PLD == LD_PE) vp = p1[i];
+            else if constexpr (PLD == LD_CAT1) vp = !(mok && rok) ? z4 : p_ones ? ones_vec<T>() : p1[i];
             else if constexpr (decltype(cfp)::two_tensors) vp = (mok && rok) ? cfp.apply(g.p, (unsigned)m, p1[i], p2[i]) : z4;
             else vp = (mok && rok) ? cfp.apply(g.p, (unsigned)m, p1[i], z4) : z4;
             if constexpr (QLD == LD_PE) vq = q1[i];
@@ -1156,6 +1170,12 @@ static int launch_tn_d(const GemmTN& g, hipStream_t s) {
     if (pk == LD_PLAIN && qk == LD_GATE) return launch_tn_t<T, LD_PLAIN, LD_GATE>(g, s);
     if (pk == LD_PLAIN && qk == LD_PLAIN) return launch_tn_t<T, LD_PLAIN, LD_PLAIN>(g, s);
     if (pk == LD_AFFINE2 && qk == LD_PLAIN) return launch_tn_t<T, LD_AFFINE2, LD_PLAIN>(g, s);
+    if (pk == LD_CAT1 && qk == LD_PLAIN) {
+        if (g.p.cat_c1 <= 0 || g.p.cat_c2 < 0 || g.p.cat_c1 % TT<T>::KC || g.p.cat_c2 % TT<T>::KC || g.groups != 1 ||
+            g.R < g.p.cat_c1 + g.p.cat_c2 || (g.p.cat_c2 > 0 && !g.p.q))
+            return dwn_set_error(-2, "gemm_tn: LD_CAT1 needs groups == 1, segment widths in 16-byte vectors and R >= cat_c1 + cat_c2");
+        return launch_tn_t<T, LD_CAT1, LD_PLAIN>(g, s);
+    }
     return dwn_set_error(-3, "gemm_tn: unsupported loader combination");
 }
 
@@ -1166,101 +1186,94 @@ int launch_gemm_tn(const GemmTN& g_in, int dtype, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv_pw backward of the 64-channel blocks (Cin = 64, E = 448) reading dh1 / y1 ONCE: per 128-row tile and 64-column chunk
-// of E the BatchNorm-backward affine dy1 = A1*dh1 + A2*y1 + A3 is built in LDS (rounded to bf16 like the TN loader does)
-// and feeds both products — da0 += dy1 . W1 (row-major fragments, W1^T resident in LDS) and dW1[chunk] += dy1^T . a0
-// (ds_read_tr16_b64 fragments; 7 x 8 accumulator registers per thread) — with one fp32 atomic flush of dW1 per workgroup.
-// 512 threads, one workgroup per CU (143 KB of LDS), persistent over the tiles.  Replaces gemm_nn (K-concat folding) +
-// gemm_tn (affine2), which each streamed dh1: 1083 us instead of 645 + 875 us at M = 2.36 M rows (4.4 TB/s).
+// conv_pw backward of the 64-channel blocks (Cin = 64, E = 448): ONE pass over dh1, and y1 is not read at all.
+// dy1 = A1*dh1 + A2*y1 + A3 (BatchNorm-1 backward) is linear and y1 = a0 . W1^T, so both products fold (reference math:
+// backward of dwiseneuro.py:90-93):
+//   da0 = dy1 . W1    = [dh1 | a0] . [diag(A1) W1 ; G] + r3,   G = W1^T diag(A2) W1, r3 = A3 . W1   (Bp / r3: k_pw_bwd_prep)
+//   dW1 = dy1^T . a0  = diag(A1) (dh1^T a0) + diag(A2) W1 (a0^T a0) + A3 (1^T a0)                    (k_pw_wgrad_fold)
+// The kernel therefore multiplies RAW tiles — no per-element BatchNorm arithmetic, no second E-wide tensor: per 128-row tile
+// it streams the seven 64-column chunks of dh1 through LDS, da0 += chunk . Bp (row-major fragments, Bp resident in LDS) and
+// T1[chunk] += chunk^T . a0 (ds_read_tr16_b64 fragments), plus once per tile da0 += a0 . G, Ga += a0^T a0 and s += 1^T a0.
+// T1 / Ga / s leave as fp32 atomics into tacc [(E + Cin + 8)][Cin] (rows: T1, Ga, s), one flush per workgroup.
+// 512 threads, one workgroup per CU (145 KB of LDS), persistent over the tiles; the NEXT tile's seven chunks are already in
+// flight in registers while this tile multiplies (112 KB per CU: the version that fetched one chunk ahead ran at the pace of
+// one memory latency per chunk and gained 20 % from halving its bytes).
 // ------------------------------------------------------------------------------------------------
 static __device__ __forceinline__ unsigned pwb_pack2(float a, float b) { return pk_bf16(a, b); }
 namespace pwb {
-constexpr int E = 448, CIN = 64, BM = 128, NKC = E / 64;
+constexpr int E = 448, CIN = 64, BM = 128, NKC = E / 64, KCAT = E + CIN;
 constexpr int RS = 160;                       // LDS row stride of the [128][64] bf16 tiles (128 B + 32 B shift)
-constexpr int WRS = E * 2 + 16;               // row stride of the resident W1^T [64][448]
+constexpr int WRS = KCAT * 2 + 16;            // row stride of the resident Bp [64][512]
 constexpr int SW_BYTES = CIN * WRS, SD_BYTES = BM * RS, SX_BYTES = BM * RS;
-constexpr int SABC_BYTES = 3 * E * 4;          // the affine coefficients live in LDS: read per chunk, not hoisted into 168 registers
-constexpr int LDS_BYTES = SW_BYTES + 2 * SD_BYTES + 2 * SX_BYTES + SABC_BYTES;
-
+constexpr int LDS_BYTES = SW_BYTES + 2 * SD_BYTES + 2 * SX_BYTES + CIN * 4;
 }  // namespace pwb
-__global__ __launch_bounds__(512, 2) void pw_bwd_fused_kernel(const bf16_t* __restrict__ dh1, const bf16_t* __restrict__ y1,
-                                                       const bf16_t* __restrict__ a0, const bf16_t* __restrict__ w1t,
-                                                       const float* __restrict__ abc, bf16_t* __restrict__ da0,
-                                                       float* __restrict__ dW, int M) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pw_bwd_fused_kernel(const bf16_t* __restrict__ dh1, const bf16_t* __restrict__ a0,
+                                                       const bf16_t* __restrict__ bp, const float* __restrict__ r3,
+                                                       bf16_t* __restrict__ da0, float* __restrict__ tacc, int M) {
     using namespace pwb;
     extern __shared__ __attribute__((aligned(16))) unsigned char pwb_smem[];
     unsigned char* const smem = pwb_smem;
     unsigned char* sW = smem;
     unsigned char* sD = smem + SW_BYTES;
     unsigned char* sX = sD + 2 * SD_BYTES;
-    float* sABC = reinterpret_cast<float*>(sX + 2 * SX_BYTES);
+    float* sR3 = reinterpret_cast<float*>(sX + 2 * SX_BYTES);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lg = lane >> 4;
     const int wm = wave & 3, wn = wave >> 2;
-    for (int c = tid; c < 3 * E; c += 512) sABC[c] = abc[c];
-    // resident W1^T: [n][k], 16-byte chunks
-    for (int c = tid; c < CIN * (E / 8); c += 512) {
-        const int n = c / (E / 8), kc8 = c % (E / 8);
-        *reinterpret_cast<uint4*>(sW + n * WRS + kc8 * 16) = *reinterpret_cast<const uint4*>(w1t + (size_t)n * E + kc8 * 8);
+    if (tid < CIN) sR3[tid] = r3[tid];
+    // resident Bp: [n][k], 16-byte chunks
+    for (int c = tid; c < CIN * (KCAT / 8); c += 512) {
+        const int n = c / (KCAT / 8), kc8 = c % (KCAT / 8);
+        *reinterpret_cast<uint4*>(sW + n * WRS + kc8 * 16) = *reinterpret_cast<const uint4*>(bp + (size_t)n * KCAT + kc8 * 8);
     }
-    __syncthreads();
-    f32x4_t acc_dw[NKC][2];
+    f32x4_t acc_dw[NKC][2], acc_ga[2], acc_s[2];
 #pragma unroll
     for (int k = 0; k < NKC; ++k) { acc_dw[k][0] = f32x4_t{0, 0, 0, 0}; acc_dw[k][1] = f32x4_t{0, 0, 0, 0}; }
+    acc_ga[0] = acc_ga[1] = acc_s[0] = acc_s[1] = f32x4_t{0, 0, 0, 0};
     const int ntiles = M / BM;
     const int ch = tid & 7;                   // this thread's 16-byte column chunk inside a 64-column chunk (fixed)
     const int row_a = tid >> 3;               // rows row_a and row_a + 64
-    uint4 rd[2], ry[2], rx[2];
+    struct Pair { uint4 lo, hi; };            // rows row_a and row_a + 64 of one 64-column chunk (values, never addressed: registers)
+    Pair rd[NKC], rx;
+    auto fetch_a0 = [&](int tile) {
+        const bf16_t* src = a0 + ((size_t)tile * BM + row_a) * CIN + ch * 8;
+        return Pair{*reinterpret_cast<const uint4*>(src), *reinterpret_cast<const uint4*>(src + (size_t)64 * CIN)};
+    };
+    auto fetch_chunk = [&](int tile, int kc) {
+        const bf16_t* src = dh1 + ((size_t)tile * BM + row_a) * E + kc * 64 + ch * 8;
+        return Pair{*reinterpret_cast<const uint4*>(src), *reinterpret_cast<const uint4*>(src + (size_t)64 * E)};
+    };
+    int tile = blockIdx.x;
+    {
+        const int t0 = tile < ntiles ? tile : 0;          // ntiles >= 1 (launcher): unconditional loads
+        rx = fetch_a0(t0);
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) rd[kc] = fetch_chunk(t0, kc);
+    }
+    __syncthreads();
+    const int q = lr >> 2, p = lr & 3;         // transposed-fragment lane roles (ds_read_tr16_b64)
+    const bf16x8_t ones = {(short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80};
     int tpar = 0, step = 0;                  // step: running chunk counter (LDS buffer parity continues across tiles)
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, tpar ^= 1) {
+    for (; tile < ntiles; tile += gridDim.x, tpar ^= 1) {
         const size_t m0 = (size_t)tile * BM;
+        // the prefetch target: the next tile of this workgroup, or (last round) this tile again — unconditional loads, so that
+        // the values land in the ring registers themselves (a conditional load is waited for and copied at once)
+        const int ntile = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
         unsigned char* sXt = sX + tpar * SX_BYTES;
-        // a0 tile + first chunk of dh1 / y1
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const size_t m = m0 + row_a + 64 * u;
-            rx[u] = *reinterpret_cast<const uint4*>(a0 + m * CIN + ch * 8);
-            rd[u] = *reinterpret_cast<const uint4*>(dh1 + m * E + ch * 8);
-            ry[u] = *reinterpret_cast<const uint4*>(y1 + m * E + ch * 8);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) *reinterpret_cast<uint4*>(sXt + (row_a + 64 * u) * RS + ch * 16) = rx[u];
+        *reinterpret_cast<uint4*>(sXt + row_a * RS + ch * 16) = rx.lo;
+        *reinterpret_cast<uint4*>(sXt + (row_a + 64) * RS + ch * 16) = rx.hi;
+        rx = fetch_a0(ntile);
         f32x4_t acc_da[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) { acc_da[i][0] = f32x4_t{0, 0, 0, 0}; acc_da[i][1] = f32x4_t{0, 0, 0, 0}; }
 #pragma unroll
         for (int kc = 0; kc < NKC; ++kc) {
             unsigned char* sDk = sD + ((step + kc) & 1) * SD_BYTES;
-            // BatchNorm-backward affine of this chunk -> LDS (bf16, as the library's loader rounds it)
-            {
-                float A1[8], A2[8], A3[8];
-                const int e0 = kc * 64 + ch * 8;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { A1[q] = sABC[e0 + q]; A2[q] = sABC[E + e0 + q]; A3[q] = sABC[2 * E + e0 + q]; }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const unsigned d4[4] = {rd[u].x, rd[u].y, rd[u].z, rd[u].w}, y4[4] = {ry[u].x, ry[u].y, ry[u].z, ry[u].w};
-                    unsigned o[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float dl = __uint_as_float(d4[q] << 16), dhi = __uint_as_float(d4[q] & 0xffff0000u);
-                        const float yl = __uint_as_float(y4[q] << 16), yh = __uint_as_float(y4[q] & 0xffff0000u);
-                        o[q] = pwb_pack2(fmaf(A1[2 * q], dl, fmaf(A2[2 * q], yl, A3[2 * q])),
-                                     fmaf(A1[2 * q + 1], dhi, fmaf(A2[2 * q + 1], yh, A3[2 * q + 1])));
-                    }
-                    *reinterpret_cast<uint4*>(sDk + (row_a + 64 * u) * RS + ch * 16) = make_uint4(o[0], o[1], o[2], o[3]);
-                }
-            }
-            __syncthreads();
-            if (kc + 1 < NKC) {               // next chunk in flight under the MFMAs
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const size_t m = m0 + row_a + 64 * u;
-                    rd[u] = *reinterpret_cast<const uint4*>(dh1 + m * E + (kc + 1) * 64 + ch * 8);
-                    ry[u] = *reinterpret_cast<const uint4*>(y1 + m * E + (kc + 1) * 64 + ch * 8);
-                }
-            }
-            // ---- data gradient: acc_da[m][n] += sum_k dy1[m][k] W1t[n][k]   (swapped roles: lanes own 4 consecutive n)
+            *reinterpret_cast<uint4*>(sDk + row_a * RS + ch * 16) = rd[kc].lo;
+            *reinterpret_cast<uint4*>(sDk + (row_a + 64) * RS + ch * 16) = rd[kc].hi;
+            nn_lds_barrier();      // LDS hand-off only: __syncthreads() would drain the next tile's loads (vmcnt(0)) at every chunk
+            rd[kc] = fetch_chunk(ntile, kc);                     // this chunk of the NEXT tile: a whole tile of loads in flight
+            // ---- data gradient: acc_da[m][n] += sum_k dh1[m][k] Bp[n][k]   (swapped roles: lanes own 4 consecutive n)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 bf16x8_t af[2], wf[2];
@@ -1276,17 +1289,53 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_fused_kernel(const bf16_t* __re
                     for (int j = 0; j < 2; ++j)
                         acc_da[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc_da[i][j], 0, 0, 0);
             }
-            // ---- weight gradient: acc_dw[kc][e][c] += sum_rows dy1[row][e] a0[row][c]   (transposed fragments)
-            {
-                const int q = lr >> 2, p = lr & 3;
+            // ---- T1[kc][e][c] += sum_rows dh1[row][e] a0[row][c]   (transposed fragments)
+#pragma unroll
+            for (int kb = 0; kb < BM / 32; ++kb) {
+                const int rb = kb * 32 + 8 * lg + q;
+                bf16x8_t ef, cf[2];
+                {
+                    const int colb = (wm * 16 + 4 * p) * 2;
+                    auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(sDk + rb * RS + colb));
+                    auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(sDk + (rb + 4) * RS + colb));
+                    ef = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int colb = (wn * 32 + j * 16 + 4 * p) * 2;
+                    auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(sXt + rb * RS + colb));
+                    auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(sXt + (rb + 4) * RS + colb));
+                    cf[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc_dw[kc][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, cf[j], acc_dw[kc][j], 0, 0, 0);
+            }
+            if (kc == 0) {
+                // ---- once per tile, on the a0 tile alone (complete since the barrier above): da0 += a0 . G, Ga += a0^T a0, s += 1^T a0
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    bf16x8_t af[2], wf[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        af[i] = *reinterpret_cast<const bf16x8_t*>(sXt + (wm * 32 + i * 16 + lr) * RS + (kb * 4 + lg) * 16);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        wf[j] = *reinterpret_cast<const bf16x8_t*>(sW + (wn * 32 + j * 16 + lr) * WRS + (E + kb * 32 + lg * 8) * 2);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc_da[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc_da[i][j], 0, 0, 0);
+                }
 #pragma unroll
                 for (int kb = 0; kb < BM / 32; ++kb) {
                     const int rb = kb * 32 + 8 * lg + q;
                     bf16x8_t ef, cf[2];
                     {
                         const int colb = (wm * 16 + 4 * p) * 2;
-                        auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(sDk + rb * RS + colb));
-                        auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(sDk + (rb + 4) * RS + colb));
+                        auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(sXt + rb * RS + colb));
+                        auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(sXt + (rb + 4) * RS + colb));
                         ef = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     }
 #pragma unroll
@@ -1297,8 +1346,10 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_fused_kernel(const bf16_t* __re
                         cf[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     }
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc_dw[kc][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, cf[j], acc_dw[kc][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) {
+                        acc_ga[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef, cf[j], acc_ga[j], 0, 0, 0);
+                        if (wm == 0) acc_s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, cf[j], acc_s[j], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -1310,11 +1361,13 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_fused_kernel(const bf16_t* __re
             for (int j = 0; j < 2; ++j) {
                 const size_t m = m0 + wm * 32 + i * 16 + lr;
                 const int n = wn * 32 + j * 16 + 4 * lg;
-                uint2 v = make_uint2(pwb_pack2(acc_da[i][j][0], acc_da[i][j][1]), pwb_pack2(acc_da[i][j][2], acc_da[i][j][3]));
+                const float4 b4 = *reinterpret_cast<const float4*>(sR3 + n);
+                uint2 v = make_uint2(pwb_pack2(acc_da[i][j][0] + b4.x, acc_da[i][j][1] + b4.y),
+                                     pwb_pack2(acc_da[i][j][2] + b4.z, acc_da[i][j][3] + b4.w));
                 *reinterpret_cast<uint2*>(da0 + m * CIN + n) = v;
             }
     }
-    // acc_dw[kc][j][r] = dW[e = kc*64 + wm*16 + 4*lg + r][c = wn*32 + j*16 + lr]
+    // acc_dw[kc][j][r] = T1[e = kc*64 + wm*16 + 4*lg + r][c = wn*32 + j*16 + lr]; Ga likewise at rows E + ...; s at row E + CIN
     DET_ENTER();
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc)
@@ -1322,7 +1375,14 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_fused_kernel(const bf16_t* __re
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                atomicAdd(dW + (size_t)(kc * 64 + wm * 16 + 4 * lg + r) * CIN + wn * 32 + j * 16 + lr, acc_dw[kc][j][r]);
+                atomicAdd(tacc + (size_t)(kc * 64 + wm * 16 + 4 * lg + r) * CIN + wn * 32 + j * 16 + lr, acc_dw[kc][j][r]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            atomicAdd(tacc + (size_t)(E + wm * 16 + 4 * lg + r) * CIN + wn * 32 + j * 16 + lr, acc_ga[j][r]);
+        if (wm == 0 && lg == 0) atomicAdd(tacc + (size_t)KCAT * CIN + wn * 32 + j * 16 + lr, acc_s[j][0]);
+    }
     DET_EXIT();
 }
 
@@ -1330,8 +1390,8 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_fused_kernel(const bf16_t* __re
 bool pw_bwd_fused_supported(int dtype, long long M, int E, int Cin) {
     return dtype == DWN_BF16 && E == pwb::E && Cin == pwb::CIN && M > 0 && M % pwb::BM == 0 && M <= 0x7fffffffLL;
 }
-int launch_pw_bwd_fused(const void* dh1, const void* y1, const void* a0, const void* w1t, const float* abc, void* da0,
-                        float* dw, long long M, int E, int Cin, int dtype, hipStream_t s) {
+int launch_pw_bwd_fused(const void* dh1, const void* a0, const void* bp, const float* r3, void* da0, float* tacc,
+                        long long M, int E, int Cin, int dtype, hipStream_t s) {
     if (!pw_bwd_fused_supported(dtype, M, E, Cin))
         return dwn_set_error(-3, "pw_bwd_fused: built for bf16, Cin = 64, E = 448, M % 128 == 0 only");
     {   // > 64 KB of dynamic LDS needs the opt-in; per device, so it is (cheaply) repeated on every call
@@ -1340,8 +1400,8 @@ int launch_pw_bwd_fused(const void* dh1, const void* y1, const void* a0, const v
     }
     int grid = 256;
     if (grid > (int)(M / pwb::BM)) grid = (int)(M / pwb::BM);
-    hipLaunchKernelGGL(pw_bwd_fused_kernel, dim3(grid), dim3(512), pwb::LDS_BYTES, s, (const bf16_t*)dh1, (const bf16_t*)y1,
-                       (const bf16_t*)a0, (const bf16_t*)w1t, abc, (bf16_t*)da0, dw, (int)M);
+    hipLaunchKernelGGL(pw_bwd_fused_kernel, dim3(grid), dim3(512), pwb::LDS_BYTES, s, (const bf16_t*)dh1, (const bf16_t*)a0,
+                       (const bf16_t*)bp, r3, (bf16_t*)da0, tacc, (int)M);
     DWN_CHECK_LAUNCH();
     return 0;
 }

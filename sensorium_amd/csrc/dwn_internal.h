@@ -20,5 +20,5 @@ int launch_dw_spatial_bwd(const DwSpatialBwd& a, int dtype, hipStream_t s);
 int launch_dw_temporal_fwd(const DwTemporalFwd& a, int dtype, hipStream_t s);
 int launch_dw_temporal_bwd(const DwTemporalBwd& a, int dtype, hipStream_t s);
 bool pw_bwd_fused_supported(int dtype, long long M, int E, int Cin);
-int launch_pw_bwd_fused(const void* dh1, const void* y1, const void* a0, const void* w1t, const float* abc, void* da0,
-                        float* dw, long long M, int E, int Cin, int dtype, hipStream_t s);
+int launch_pw_bwd_fused(const void* dh1, const void* a0, const void* bp, const float* r3, void* da0, float* tacc,
+                        long long M, int E, int Cin, int dtype, hipStream_t s);

@@ -317,48 +317,50 @@ def test_gemm_nn_dh3_epilogue(L, dtype, B, S, N, K):
     assert L.lib.dwn_gemm_nn(C.byref(g), _dt(L, dtype), 0, stream()) < 0
 
 
-@pytest.mark.parametrize("M", [128, 128 * 37, 128 * 513])
-def test_pw_bwd_fused_matches_two_products(L, M):
-    """dwn_pw_bwd_fused (conv_pw backward of the 64-channel blocks in one pass over dh1 / y1): exact on small-integer data,
-    and within bf16 tolerance on random data, against dy1 = round(A1*dh1 + A2*y1 + A3); da0 = dy1 @ W1; dW += dy1^T @ a0."""
-    E, Cin = 448, 64
-    assert L.lib.dwn_pw_bwd_fused_supported(L.DWN_BF16, M, E, Cin) == 1
-    for integer in (True, False):
-        g = torch.Generator(device="cuda").manual_seed(M + integer)
-        if integer:
-            dh1 = torch.randint(-2, 3, (M, E), generator=g, device=dev()).float()
-            y1 = torch.randint(-1, 2, (M, E), generator=g, device=dev()).float()
-            a0 = torch.randint(-1, 2, (M, Cin), generator=g, device=dev()).float()
-            w1 = torch.randint(-2, 3, (E, Cin), generator=g, device=dev()).float() * 0.25
-            abc = torch.stack([torch.arange(E, device=dev()) % 2 + 1.0, torch.arange(E, device=dev()) % 3 - 1.0,
-                               torch.arange(E, device=dev()) % 2 + 0.0]).float().contiguous()
-        else:
-            dh1 = torch.randn(M, E, generator=g, device=dev())
-            y1 = torch.randn(M, E, generator=g, device=dev())
-            a0 = torch.randn(M, Cin, generator=g, device=dev())
-            w1 = torch.randn(E, Cin, generator=g, device=dev()) * 0.1
-            abc = torch.randn(3, E, generator=g, device=dev()).contiguous()
-        bf = torch.bfloat16
-        dh1b, y1b, a0b, w1t = dh1.to(bf), y1.to(bf), a0.to(bf), w1.t().contiguous().to(bf)
-        da0 = torch.full((M, Cin), float("nan"), device=dev()).to(bf)
-        dw = torch.full((E, Cin), 0.5, device=dev())                      # accumulated into, not overwritten
-        a = L.PwBwdArgs()
-        a.dh1, a.y1, a.a0, a.w1t, a.abc = dh1b.data_ptr(), y1b.data_ptr(), a0b.data_ptr(), w1t.data_ptr(), abc.data_ptr()
-        a.da0, a.dw, a.M, a.E, a.Cin = da0.data_ptr(), dw.data_ptr(), M, E, Cin
-        L.check(L.lib.dwn_pw_bwd_fused(C.byref(a), L.DWN_BF16, 0, stream()), "pw_bwd_fused")
+@pytest.mark.parametrize("M,E,Cin,dtype", [(128, 448, 64, torch.bfloat16), (128 * 37, 448, 64, torch.bfloat16),
+                                           (128 * 513, 448, 64, torch.bfloat16),        # one-pass kernel (64-channel blocks)
+                                           (128 * 37 + 64, 448, 64, torch.bfloat16),    # same widths, ragged M: two GEMMs
+                                           (5000, 896, 128, torch.bfloat16), (3000, 1792, 256, torch.bfloat16),
+                                           (5000, 384, 64, torch.bfloat16),             # E not a multiple of the 128-row tile
+                                           (5000, 448, 64, torch.float32), (3000, 896, 128, torch.float32)])
+def test_pw_backward_without_y1(L, M, E, Cin, dtype):
+    """dwn_pw_backward: conv_pw data and weight gradient from (dh1, a0, W1, abc) alone — y1 = a0 . W1^T is never read, its
+    terms are folded into Cin x Cin matrices (include/dwn.h).  Against float64: dy1 = A1*dh1 + A2*(a0 W1^T) + A3;
+    da0 = dy1 W1; dW = dy1^T a0, with W1 as rounded to the storage dtype."""
+    fused = L.lib.dwn_pw_bwd_fused_supported(_dt(L, dtype), M, E, Cin)
+    assert fused == (1 if (dtype == torch.bfloat16 and E == 448 and Cin == 64 and M % 128 == 0) else 0)
+    g = torch.Generator(device="cuda").manual_seed(M + E)
+    dh1 = torch.randn(M, E, generator=g, device=dev()).to(dtype)
+    a0 = (torch.randn(M, Cin, generator=g, device=dev()) + 0.3).to(dtype)           # a non-zero column mean: the A3 term counts
+    w1 = (torch.randn(E, Cin, generator=g, device=dev()) * 0.1).contiguous()
+    abc = torch.randn(3, E, generator=g, device=dev()).contiguous()
+    da0 = torch.full((M, Cin), float("nan"), device=dev()).to(dtype)
+    dw = torch.full((E, Cin), float("nan"), device=dev())                            # overwritten
+    nws = L.lib.dwn_pw_backward_workspace_bytes(E, Cin, _dt(L, dtype))
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev())
+    a = L.PwBwdArgs()
+    a.dh1, a.a0, a.w_pw, a.abc = dh1.data_ptr(), a0.data_ptr(), w1.data_ptr(), abc.data_ptr()
+    a.da0, a.dw, a.M, a.E, a.Cin, a.ws, a.ws_bytes = da0.data_ptr(), dw.data_ptr(), M, E, Cin, ws.data_ptr(), nws
+    L.check(L.lib.dwn_pw_backward(C.byref(a), _dt(L, dtype), 0, stream()), "pw_backward")
+    torch.cuda.synchronize()
+    w1r = w1.to(dtype).double()
+    y1 = a0.double() @ w1r.t()
+    dy = abc[0].double() * dh1.double() + abc[1].double() * y1 + abc[2].double()
+    want_da = dy @ w1r
+    want_dw = dy.t() @ a0.double()
+    assert torch.isfinite(da0.float()).all() and torch.isfinite(dw).all()
+    assert rel(da0, want_da) < (8e-3 if dtype == torch.bfloat16 else 2e-5)         # bf16: output rounding + G kept in bf16
+    assert rel(dw, want_dw) < (2e-4 if dtype == torch.bfloat16 else 2e-5)           # bf16: only W1's Gram row is rounded
+    # the three terms separately: each column of dW
+    for sel in range(3):
+        ab = torch.zeros_like(abc); ab[sel] = abc[sel]
+        a.abc = ab.data_ptr()
+        L.check(L.lib.dwn_pw_backward(C.byref(a), _dt(L, dtype), 0, stream()), "pw_backward")
         torch.cuda.synchronize()
-        dy = (abc[0] * dh1b.float() + (abc[1] * y1b.float() + abc[2])).to(bf)      # fma(A1, dh, fma(A2, y, A3)) rounded
-        want_da = dy.double() @ w1t.double().t()
-        want_dw = dy.double().t() @ a0b.double() + 0.5
-        if integer:
-            assert torch.equal(da0.double(), want_da.to(bf).double())
-            assert torch.equal(dw.double(), want_dw)
-        else:
-            assert rel(da0, want_da) < 6e-3
-            assert rel(dw, want_dw) < 2e-4
-    assert L.lib.dwn_pw_bwd_fused_supported(L.DWN_BF16, M + 64, E, Cin) == 0
-    assert L.lib.dwn_pw_bwd_fused_supported(L.DWN_F32, M, E, Cin) == 0
-    a.E = 896
-    assert L.lib.dwn_pw_bwd_fused(C.byref(a), L.DWN_BF16, 0, stream()) == -3
-    a.E, a.dw = E, None
-    assert L.lib.dwn_pw_bwd_fused(C.byref(a), L.DWN_BF16, 0, stream()) < 0
+        dy = ab[0].double() * dh1.double() + ab[1].double() * y1 + ab[2].double()
+        assert rel(dw, dy.t() @ a0.double()) < (2e-3 if dtype == torch.bfloat16 else 2e-5), sel
+    a.abc = abc.data_ptr()
+    a.ws_bytes = nws - 1
+    assert L.lib.dwn_pw_backward(C.byref(a), _dt(L, dtype), 0, stream()) == -6
+    a.ws_bytes, a.dw = nws, None
+    assert L.lib.dwn_pw_backward(C.byref(a), _dt(L, dtype), 0, stream()) < 0
