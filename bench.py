@@ -100,10 +100,12 @@ def block_work(batch, frames, height, width, expansion, fused_pw_blocks, esize):
             "pwl_wgrad": (mo * e_ + mo * cout, 2 * mo * e_ * cout),
         }
         if i in fused_pw_blocks:
-            d["pw_dgrad"] = (2 * mi * e_ + 2 * mi * cin, 4 * mi * cin * e_)                       # dh1, y1, a0 in; da0 out
+            # one pass over dh1 for both gradients; y1 is not read (its BatchNorm-backward terms fold into Cin x Cin matrices):
+            # dh1, a0 in; da0 out — the bytes this algorithm has to move, not the (dh1, y1) pair autograd would read
+            d["pw_dgrad"] = (mi * e_ + 2 * mi * cin, 4 * mi * cin * e_ + 4 * mi * cin * cin)
         else:
             d["pw_dgrad"] = (mi * e_ + 2 * mi * cin, 2 * mi * (cin + e_) * cin)                   # K-concat fold
-            d["pw_wgrad"] = (2 * mi * e_ + mi * cin, 2 * mi * cin * e_)
+            d["pw_wgrad"] = (mi * e_ + 2 * mi * cin, 2 * mi * cin * (e_ + cin))                   # [dh1 | a0 | 1]^T a0
         out.append({"block": i, "stride": st, "cin": cin, "cmid": e_, "cout": cout, "in_hw": (h, w), "out_hw": (ho, wo),
                     "m_in": mi, "m_out": mo, "work": {k: (v[0] * esize, v[1]) for k, v in d.items()}})
         h, w = ho, wo

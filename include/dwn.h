@@ -400,7 +400,7 @@ int dwn_ema_lerp_multi(const dwn_tensor_entry* list, int ntensors, int max_block
  * both products fold the y1 term into Cin x Cin matrices:
  *   da0[M][Cin] = dy1 . W1    = [dh1 | a0] . [diag(abc0) W1 ; W1^T diag(abc1) W1] + abc2 . W1
  *   dw[E][Cin]  = dy1^T . a0  = diag(abc0) (dh1^T a0) + diag(abc1) W1 (a0^T a0) + abc2 (1^T a0)     (fp32, overwritten)
- * so the E-wide traffic is one read of dh1 (dtype == DWN_BF16, Cin == 64, E == 448, M % 128 == 0 — see
+ * so the E-wide traffic is one read of dh1 (dtype == DWN_BF16, Cin == 64, E == 448 or 384, M % 128 == 0 — see
  * dwn_pw_bwd_fused_supported — one kernel computes both products from a single pass) or two (dwn_gemm_nn with the
  * K-concatenated operand + dwn_gemm_tn with the DWN_LD_CAT1 loader).  w_pw = conv_pw.0.weight [E][Cin] fp32 (used as rounded
  * to `dtype`, the values the forward multiplied with).  ws: dwn_pw_backward_workspace_bytes(E, Cin, dtype) bytes, 256-aligned. */

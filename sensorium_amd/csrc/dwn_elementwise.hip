@@ -2237,13 +2237,14 @@ __global__ __launch_bounds__(256) void pw_wgrad_fold_kernel(const float* __restr
     const float g = (g0 + g1) + (g2 + g3);
     dw[idx] = fmaf(abc[e], tacc[idx], fmaf(abc[E + e], g, abc[2 * E + e] * tacc[(i64)(E + C) * C + c]));
 }
-// C in {64, 128, 256}: a workgroup owns 16 * (256 / C) rows of dW; a thread one column c and 16 rows.  W1's rows are staged
-// transposed in LDS ([c'][row]: four broadcast ds_read_b128 per c'), Ga's column element is one coalesced load per c' — the
-// thread-per-element kernel above re-reads W1's row and Ga's column per element and ran at the L1 rate (30 us at E = 1792, C = 256)
+// C in {64, 128, 256}: a workgroup owns 4 * (256 / C) rows of dW; a thread one column c and 4 rows.  W1's rows are staged
+// transposed in LDS ([c'][row]: one broadcast ds_read_b128 per c'), Ga's column element is one coalesced load per c', 16 of
+// them in flight — the thread-per-element kernel above re-reads W1's row and Ga's column per element and ran at the L1 rate
+// (30 us at E = 1792, C = 256); 16 rows per thread left 7 workgroups at C = 64 walking 64 dependent loads (20 us)
 template <typename T, int CC>
 __global__ __launch_bounds__(256) void pw_wgrad_fold_tile_kernel(const float* __restrict__ tacc, const float* __restrict__ abc,
                                                                  const float* __restrict__ w1, int E, float* __restrict__ dw) {
-    constexpr int G = 256 / CC, ROWS = 16 * G;
+    constexpr int G = 256 / CC, ROWS = 4 * G;
     __shared__ __attribute__((aligned(16))) float sw[CC][ROWS];          // sw[c'][row] = round(W1[e0 + row][c'])
     const int tid = threadIdx.x, e0 = blockIdx.x * ROWS;
     for (int i = tid; i < ROWS * CC; i += 256) {
@@ -2253,31 +2254,31 @@ __global__ __launch_bounds__(256) void pw_wgrad_fold_tile_kernel(const float* __
     __syncthreads();
     const int c = tid % CC, gq = tid / CC;
     const float* ga = tacc + (i64)E * CC + c;
-    float acc[16];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int cp0 = 0; cp0 < CC; cp0 += 16) {          // not unrolled: all C loads hoisted at once cost 256 registers + scratch
+        float gv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 4
-    for (int cp = 0; cp < CC; ++cp) {
-        const float gv = ga[(i64)cp * CC];
+        for (int u = 0; u < 16; ++u) gv[u] = ga[(i64)(cp0 + u) * CC];
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const float4 w4 = *reinterpret_cast<const float4*>(&sw[cp][gq * 16 + r4 * 4]);
-            acc[r4 * 4 + 0] = fmaf(w4.x, gv, acc[r4 * 4 + 0]);
-            acc[r4 * 4 + 1] = fmaf(w4.y, gv, acc[r4 * 4 + 1]);
-            acc[r4 * 4 + 2] = fmaf(w4.z, gv, acc[r4 * 4 + 2]);
-            acc[r4 * 4 + 3] = fmaf(w4.w, gv, acc[r4 * 4 + 3]);
+        for (int u = 0; u < 16; ++u) {
+            const float4 w4 = *reinterpret_cast<const float4*>(&sw[cp0 + u][gq * 4]);
+            acc[0] = fmaf(w4.x, gv[u], acc[0]);
+            acc[1] = fmaf(w4.y, gv[u], acc[1]);
+            acc[2] = fmaf(w4.z, gv[u], acc[2]);
+            acc[3] = fmaf(w4.w, gv[u], acc[3]);
         }
     }
     const float sc = tacc[(i64)(E + CC) * CC + c];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int e = e0 + gq * 16 + r;
+    for (int r = 0; r < 4; ++r) {
+        const int e = e0 + gq * 4 + r;
         if (e < E) dw[(i64)e * CC + c] = fmaf(abc[e], tacc[(i64)e * CC + c], fmaf(abc[E + e], acc[r], abc[2 * E + e] * sc));
     }
 }
 int k_pw_wgrad_fold(const float* tacc, const float* abc, const float* w1, int E, int C, float* dw, int dtype, hipStream_t s) {
 #define FOLD_TILE(CC_) do { \
-        dim3 grid((unsigned)((E + 16 * (256 / CC_) - 1) / (16 * (256 / CC_)))); \
+        dim3 grid((unsigned)((E + 4 * (256 / CC_) - 1) / (4 * (256 / CC_)))); \
         DISPATCH_T(dtype, \
             hipLaunchKernelGGL((pw_wgrad_fold_tile_kernel<bf16_t, CC_>), grid, dim3(256), 0, s, tacc, abc, w1, E, dw), \
             hipLaunchKernelGGL((pw_wgrad_fold_tile_kernel<float, CC_>), grid, dim3(256), 0, s, tacc, abc, w1, E, dw)); \

@@ -1201,16 +1201,22 @@ int launch_gemm_tn(const GemmTN& g_in, int dtype, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 static __device__ __forceinline__ unsigned pwb_pack2(float a, float b) { return pk_bf16(a, b); }
 namespace pwb {
-constexpr int E = 448, CIN = 64, BM = 128, NKC = E / 64, KCAT = E + CIN;
+constexpr int CIN = 64, BM = 128;
 constexpr int RS = 160;                       // LDS row stride of the [128][64] bf16 tiles (128 B + 32 B shift)
-constexpr int WRS = KCAT * 2 + 16;            // row stride of the resident Bp [64][512]
-constexpr int SW_BYTES = CIN * WRS, SD_BYTES = BM * RS, SX_BYTES = BM * RS;
-constexpr int LDS_BYTES = SW_BYTES + 2 * SD_BYTES + 2 * SX_BYTES + CIN * 4;
+template <int NKC> struct Cfg {               // NKC = E / 64: 7 (expansion 7) or 6 (the distillation student's expansion 6)
+    static constexpr int E = NKC * 64, KCAT = E + CIN;
+    static constexpr int WRS = KCAT * 2 + 16;            // row stride of the resident Bp [64][E + 64]
+    static constexpr int SW_BYTES = CIN * WRS, SD_BYTES = BM * RS, SX_BYTES = BM * RS;
+    static constexpr int LDS_BYTES = SW_BYTES + 2 * SD_BYTES + 2 * SX_BYTES + CIN * 4;
+};
 }  // namespace pwb
+template <int NKC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pw_bwd_fused_kernel(const bf16_t* __restrict__ dh1, const bf16_t* __restrict__ a0,
                                                        const bf16_t* __restrict__ bp, const float* __restrict__ r3,
                                                        bf16_t* __restrict__ da0, float* __restrict__ tacc, int M) {
     using namespace pwb;
+    constexpr int E = Cfg<NKC>::E, KCAT = Cfg<NKC>::KCAT, WRS = Cfg<NKC>::WRS;
+    constexpr int SW_BYTES = Cfg<NKC>::SW_BYTES, SD_BYTES = Cfg<NKC>::SD_BYTES, SX_BYTES = Cfg<NKC>::SX_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char pwb_smem[];
     unsigned char* const smem = pwb_smem;
     unsigned char* sW = smem;
@@ -1388,20 +1394,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 
 bool pw_bwd_fused_supported(int dtype, long long M, int E, int Cin) {
-    return dtype == DWN_BF16 && E == pwb::E && Cin == pwb::CIN && M > 0 && M % pwb::BM == 0 && M <= 0x7fffffffLL;
+    return dtype == DWN_BF16 && (E == 448 || E == 384) && Cin == pwb::CIN && M > 0 && M % pwb::BM == 0 && M <= 0x7fffffffLL;
 }
-int launch_pw_bwd_fused(const void* dh1, const void* a0, const void* bp, const float* r3, void* da0, float* tacc,
-                        long long M, int E, int Cin, int dtype, hipStream_t s) {
-    if (!pw_bwd_fused_supported(dtype, M, E, Cin))
-        return dwn_set_error(-3, "pw_bwd_fused: built for bf16, Cin = 64, E = 448, M % 128 == 0 only");
+template <int NKC>
+static int launch_pw_bwd_fused_t(const void* dh1, const void* a0, const void* bp, const float* r3, void* da0, float* tacc,
+                                 long long M, hipStream_t s) {
+    auto kern = pw_bwd_fused_kernel<NKC>;
     {   // > 64 KB of dynamic LDS needs the opt-in; per device, so it is (cheaply) repeated on every call
-        hipError_t e = hipFuncSetAttribute((const void*)pw_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pwb::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pwb::Cfg<NKC>::LDS_BYTES);
         if (e != hipSuccess) return dwn_set_error((int)e, hipGetErrorString(e));
     }
     int grid = 256;
     if (grid > (int)(M / pwb::BM)) grid = (int)(M / pwb::BM);
-    hipLaunchKernelGGL(pw_bwd_fused_kernel, dim3(grid), dim3(512), pwb::LDS_BYTES, s, (const bf16_t*)dh1, (const bf16_t*)a0,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pwb::Cfg<NKC>::LDS_BYTES, s, (const bf16_t*)dh1, (const bf16_t*)a0,
                        (const bf16_t*)bp, r3, (bf16_t*)da0, tacc, (int)M);
     DWN_CHECK_LAUNCH();
     return 0;
+}
+int launch_pw_bwd_fused(const void* dh1, const void* a0, const void* bp, const float* r3, void* da0, float* tacc,
+                        long long M, int E, int Cin, int dtype, hipStream_t s) {
+    if (!pw_bwd_fused_supported(dtype, M, E, Cin))
+        return dwn_set_error(-3, "pw_bwd_fused: built for bf16, Cin = 64, E = 448 or 384, M % 128 == 0 only");
+    return E == 448 ? launch_pw_bwd_fused_t<7>(dh1, a0, bp, r3, da0, tacc, M, s) : launch_pw_bwd_fused_t<6>(dh1, a0, bp, r3, da0, tacc, M, s);
 }

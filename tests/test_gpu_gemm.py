@@ -319,6 +319,7 @@ def test_gemm_nn_dh3_epilogue(L, dtype, B, S, N, K):
 
 @pytest.mark.parametrize("M,E,Cin,dtype", [(128, 448, 64, torch.bfloat16), (128 * 37, 448, 64, torch.bfloat16),
                                            (128 * 513, 448, 64, torch.bfloat16),        # one-pass kernel (64-channel blocks)
+                                           (128 * 40, 384, 64, torch.bfloat16),         # ... of the expansion-6 student
                                            (128 * 37 + 64, 448, 64, torch.bfloat16),    # same widths, ragged M: two GEMMs
                                            (5000, 896, 128, torch.bfloat16), (3000, 1792, 256, torch.bfloat16),
                                            (5000, 384, 64, torch.bfloat16),             # E not a multiple of the 128-row tile
@@ -328,7 +329,7 @@ def test_pw_backward_without_y1(L, M, E, Cin, dtype):
     terms are folded into Cin x Cin matrices (include/dwn.h).  Against float64: dy1 = A1*dh1 + A2*(a0 W1^T) + A3;
     da0 = dy1 W1; dW = dy1^T a0, with W1 as rounded to the storage dtype."""
     fused = L.lib.dwn_pw_bwd_fused_supported(_dt(L, dtype), M, E, Cin)
-    assert fused == (1 if (dtype == torch.bfloat16 and E == 448 and Cin == 64 and M % 128 == 0) else 0)
+    assert fused == (1 if (dtype == torch.bfloat16 and E in (448, 384) and Cin == 64 and M % 128 == 0) else 0)
     g = torch.Generator(device="cuda").manual_seed(M + E)
     dh1 = torch.randn(M, E, generator=g, device=dev()).to(dtype)
     a0 = (torch.randn(M, Cin, generator=g, device=dev()) + 0.3).to(dtype)           # a non-zero column mean: the A3 term counts
