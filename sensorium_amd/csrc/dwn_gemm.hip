@@ -1197,7 +1197,8 @@ int launch_gemm_tn(const GemmTN& g_in, int dtype, hipStream_t s) {
 // T1 / Ga / s leave as fp32 atomics into tacc [(E + Cin + 8)][Cin] (rows: T1, Ga, s), one flush per workgroup.
 // 512 threads, one workgroup per CU (145 KB of LDS), persistent over the tiles; the NEXT tile's seven chunks are already in
 // flight in registers while this tile multiplies (112 KB per CU: the version that fetched one chunk ahead ran at the pace of
-// one memory latency per chunk and gained 20 % from halving its bytes).
+// one memory latency per chunk and gained 20 % from halving its bytes).  The prefetch loads are unconditional and returned by
+// value: a conditional load is waited for and copied at once, a pointer-filled array went to scratch.
 // ------------------------------------------------------------------------------------------------
 static __device__ __forceinline__ unsigned pwb_pack2(float a, float b) { return pk_bf16(a, b); }
 namespace pwb {
@@ -1277,7 +1278,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             unsigned char* sDk = sD + ((step + kc) & 1) * SD_BYTES;
             *reinterpret_cast<uint4*>(sDk + row_a * RS + ch * 16) = rd[kc].lo;
             *reinterpret_cast<uint4*>(sDk + (row_a + 64) * RS + ch * 16) = rd[kc].hi;
-            nn_lds_barrier();      // LDS hand-off only: __syncthreads() would drain the next tile's loads (vmcnt(0)) at every chunk
+            nn_lds_barrier();      // LDS hand-off only: the next tile's loads stay in flight across it
             rd[kc] = fetch_chunk(ntile, kc);                     // this chunk of the NEXT tile: a whole tile of loads in flight
             // ---- data gradient: acc_da[m][n] += sum_k dh1[m][k] Bp[n][k]   (swapped roles: lanes own 4 consecutive n)
 #pragma unroll
