@@ -85,6 +85,13 @@ g = L.GemmNNArgs(); g.M = 128; g.N = 64; g.K = 64; g.groups = 1
 expect_error(lib.dwn_gemm_nn(C.byref(g), L.DWN_BF16, 0, None))
 t = L.GemmTNArgs(); t.M = 128; t.R = 64; t.Cc = 64; t.groups = 1
 expect_error(lib.dwn_gemm_tn(C.byref(t), L.DWN_BF16, 0, None))
+# conv_pw backward without y1: workspace sizes over the architecture's widths and ragged ones, then the error path
+for dtype in (L.DWN_F32, L.DWN_BF16):
+    for (e_, cin_) in ((448, 64), (384, 64), (896, 128), (1792, 256), (24, 8), (200, 72)):
+        assert lib.dwn_pw_backward_workspace_bytes(e_, cin_, dtype) > 0
+        calls += 1
+pw = L.PwBwdArgs(); pw.M = 1024; pw.E = 448; pw.Cin = 64
+expect_error(lib.dwn_pw_backward(C.byref(pw), L.DWN_BF16, 0, None))
 expect_error(lib.dwn_adamw_ema_multi(None, 1, 16, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, 0.999, 1.0, 0, None))
 expect_error(lib.dwn_ema_lerp_multi(None, 1, 16, 0.999, 0, None))
 expect_error(lib.dwn_poisson_loss_forward(None, None, None, 1, 1, 1e-8, None, 0, None))
