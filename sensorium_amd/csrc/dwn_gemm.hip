@@ -1097,6 +1097,12 @@ __global__ __launch_bounds__(256, (TnOcc<PLD, QLD>::value)) void gemm_tn_kernel(
 }
 
 #define TRY_(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
+// M-splits are sized for at most TN_SLOTS workgroups per CU: every split adds a 64 KB fp32 atomic flush per output tile, and the
+// third resident workgroup's extra steps in flight buy less than its flushes cost (training step, A/B on one box: weight-gradient
+// families 1.953 -> 1.912 ms with 2; 2.80 ms with 1)
+#ifndef TN_SLOTS
+#define TN_SLOTS 2
+#endif
 template <typename T, int PLD, int QLD>
 static int launch_tn_t(const GemmTN& g_in, hipStream_t s) {
     GemmTN g = g_in;
@@ -1109,6 +1115,7 @@ static int launch_tn_t(const GemmTN& g_in, hipStream_t s) {
         }
         const int nb = g.M / g.rows_per_sample;
         const int tiles = ((g.R + 127) / 128) * ((g.Cc + 127) / 128);
+        if (bpc > TN_SLOTS) bpc = TN_SLOTS;
         int J = (256 * bpc) / (tiles * nb);
         const int maxj = (g.rows_per_sample + 511) / 512;
         if (J > maxj) J = maxj;
@@ -1126,6 +1133,7 @@ static int launch_tn_t(const GemmTN& g_in, hipStream_t s) {
             (void)hipGetLastError();
             bpc = 1;
         }
+        if (bpc > TN_SLOTS) bpc = TN_SLOTS;
         const int tiles = ((g.R + 127) / 128) * ((g.Cc + 127) / 128) * g.groups;
         int want = (256 * bpc) / tiles;
         const int maxsplit = (int)((g.M + 511) / 512);
