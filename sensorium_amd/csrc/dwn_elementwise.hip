@@ -869,7 +869,9 @@ __global__ __launch_bounds__(256) void residual_bwd_dx_kernel(LoadDesc xin, cons
             const int ho = ht_[hi], wo = wt_[wi];
             routv[u] = (ho >= 0 && wo >= 0) ? ((i64)bt * gm.Hout + ho) * gm.Wout + wo : -1;
             ra[u] = *reinterpret_cast<const uint4*>(da0 + (i64)row * gm.Cin + chan);
-            rx[u] = *reinterpret_cast<const uint4*>(xp + (i64)row * xin.ld + chan);
+            // x only feeds the shortcut's BatchNorm backward: rows the nearest map skips (3 of 4 on a stride-2 block) do not read it
+            rx[u] = make_uint4(0, 0, 0, 0);
+            if (routv[u] >= 0) rx[u] = *reinterpret_cast<const uint4*>(xp + (i64)row * xin.ld + chan);
         }
 #pragma unroll
         for (int u = 0; u < RES_RU; ++u) {
