@@ -409,6 +409,13 @@ typedef struct dwn_pw_bwd_args {
     void* da0; float* dw;
     long long M; int E; int Cin;
     void* ws; size_t ws_bytes;
+    /* optional: the gradient of a stride-1 block's shortcut branch (BatchNorm of the channel-tiled block input, dwiseneuro.py:125-134)
+     * folded in, so that da0 becomes the block's input gradient:
+     *   da0[m][c] += sum_{c' = c + j*Cin < res_C} (res_abc[0][c']*res[m][c'] + res_abc[1][c']*a0[m][c] + res_abc[2][c'])
+     * res = the block's output gradient [M][res_C] (`dtype`), res_abc = [3][res_C]; res_C in {Cin, 2*Cin}.  Only where
+     * dwn_pw_bwd_fused_supported (the one-pass kernel's epilogue adds it; on the two-GEMM path it measured slower than the
+     * separate pass it replaces: -3 there).  NULL = off. */
+    const void* res; const float* res_abc; int res_C;
 } dwn_pw_bwd_args;
 int dwn_pw_bwd_fused_supported(int dtype, long long M, int E, int Cin);
 size_t dwn_pw_backward_workspace_bytes(int E, int Cin, int dtype);

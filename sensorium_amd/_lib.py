@@ -156,7 +156,8 @@ class ClipDesc(C.Structure):
 
 class PwBwdArgs(C.Structure):
     _fields_ = [("dh1", c_p), ("a0", c_p), ("w_pw", c_p), ("abc", c_p), ("da0", c_p), ("dw", c_p),
-                ("M", c_ll), ("E", c_i), ("Cin", c_i), ("ws", c_p), ("ws_bytes", c_sz)]
+                ("M", c_ll), ("E", c_i), ("Cin", c_i), ("ws", c_p), ("ws_bytes", c_sz), ("res", c_p), ("res_abc", c_p),
+                ("res_C", c_i)]
 
 
 class DwSpatialRcFwdArgs(C.Structure):

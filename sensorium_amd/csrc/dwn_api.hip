@@ -506,12 +506,20 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
 
 // conv_pw backward from (dh1, a0, W1, BatchNorm-1 backward coefficients): da0 and dW1, y1 not read (see the comment at its call
 // in dwn_block_backward).  gacc (pw_fold_floats) and tacc (pw_wgrad_tacc_floats) must be zero on entry.
+// res / res_abc / res_C (optional, dwn.h dwn_pw_bwd_args): the stride-1 shortcut branch's gradient folded in — the A2 * a0 and A3
+// terms into G / r3, the A1 * dout term as the data-gradient GEMM's residual epilogue — so that da0 is the block's input gradient.
 static int pw_backward(int dt, const void* dh1, const void* a0, const float* w_pw, const float* abc, int E, int Cin, i64 M,
-                       void* bp, float* gacc, float* r3, float* tacc, void* da0, float* dw, hipStream_t s) {
-    TRY(k_pw_bwd_prep(w_pw, abc, E, Cin, bp, gacc, r3, dt, s));
+                       void* bp, float* gacc, float* r3, float* tacc, void* da0, float* dw, const void* res,
+                       const float* res_abc, int res_C, hipStream_t s) {
+    const int res_n = res ? res_C / Cin : 0;
+    if (res && (!res_abc || res_C % Cin || res_n < 1 || res_n > 2))
+        return dwn_set_error(-2, "pw_backward: the shortcut term needs res_abc and res_C in {Cin, 2 Cin}");
+    if (res && !pw_bwd_fused_supported(dt, M, E, Cin))
+        return dwn_set_error(-3, "pw_backward: the shortcut term is built into the one-pass kernel only (dwn_pw_bwd_fused_supported)");
+    TRY(k_pw_bwd_prep(w_pw, abc, E, Cin, bp, gacc, r3, dt, res ? res_abc : nullptr, res_C, s));
     if (pw_bwd_fused_supported(dt, M, E, Cin)) {
         // 64-channel blocks: both products from ONE pass over dh1
-        PROF(DWN_FAM_PW_DGRAD, launch_pw_bwd_fused(dh1, a0, bp, r3, da0, tacc, M, E, Cin, dt, s));
+        PROF(DWN_FAM_PW_DGRAD, launch_pw_bwd_fused(dh1, a0, bp, r3, da0, tacc, M, E, Cin, dt, res, res_abc, res_n, s));
     } else {
         {
             GemmNN g = nn_base(ld_plain(dh1, E), LD_PLAIN, bp, (i64)E + Cin, da0, Cin, (int)M, Cin, E + Cin, 1);
@@ -636,7 +644,15 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     // conv_pw backward WITHOUT y1.  dy1 = A1*dh1 + A2*y1 + A3 is linear and y1 = a0.W1^T, so the y1 terms fold into Cin x Cin
     // matrices on either side:  da0 = [dh1 | a0] . [diag(A1) W1 ; G] + r3  (Bp, r3: k_pw_bwd_prep) and
     // dW1 = diag(A1) (dh1^T a0) + diag(A2) W1 (a0^T a0) + A3 (1^T a0)  (raw products in tacc, folded by k_pw_wgrad_fold)
-    TRY(pw_backward(dt, dh1, xin.p, a.w_pw, w.abc1, a.Cmid, a.Cin, Min, w.bp, w.gacc, w.r3, w.tacc, a.da0, a.dw_pw, s));
+    // On a stride-1 block (identity shortcut map, output channels = input channels tiled once or twice) the shortcut branch's
+    // gradient is folded into this GEMM and its result IS dx: no pass over (da0, x, dout) -> dx.
+    // (one-pass kernel only: as an epilogue of the two-GEMM path's data-gradient GEMM it cost 30-60 us where the pass it replaces
+    // takes 20-35)
+    const bool dx_folded = a.stride == 1 && a.Hin == a.Hout && a.Win == a.Wout && a.Cout % a.Cin == 0 && a.Cout / a.Cin <= 2 &&
+                           dwn_pw_bwd_fused_supported(dt, Min, a.Cmid, a.Cin);
+    TRY(pw_backward(dt, dh1, xin.p, a.w_pw, w.abc1, a.Cmid, a.Cin, Min, w.bp, w.gacc, w.r3, w.tacc, dx_folded ? a.dx : a.da0, a.dw_pw,
+                    dx_folded ? a.dout : nullptr, w.abcsc, a.Cout, s));
+    if (dx_folded) return 0;
     PROF(DWN_FAM_RESID_BWD, k_residual_bwd_dx(xin, a.da0, a.dout, w.abcsc, gm, a.dx, dt, s));
     return 0;
 }
@@ -894,7 +910,8 @@ int dwn_pw_backward(const dwn_pw_bwd_args* a, int dtype, int device, void* strea
     float* r3 = gacc + (size_t)a->Cin * a->Cin;
     float* tacc = gacc + pw_fold_floats(a->Cin);
     TRY(k_zero(gacc, nz * sizeof(float), s));
-    return pw_backward(dtype, a->dh1, a->a0, a->w_pw, a->abc, a->E, a->Cin, a->M, bp, gacc, r3, tacc, a->da0, a->dw, s);
+    return pw_backward(dtype, a->dh1, a->a0, a->w_pw, a->abc, a->E, a->Cin, a->M, bp, gacc, r3, tacc, a->da0, a->dw, a->res,
+                       a->res_abc, a->res_C, s);
 }
 
 int dwn_assemble_inputs(const dwn_clip_desc* descs, int B, int T, int H0, int W0, int H, int W, float pad_fill,

@@ -2188,16 +2188,27 @@ __global__ __launch_bounds__(256) void pw_bwd_prep_kernel(const float* w1, const
 }
 // (a "last block converts G" tail instead of this second launch was measured 4x slower than the whole chain it replaced:
 // an agent-scope release fence per block means an L2 write-back on this 8-XCD part)
+// res_abc / res_C (optional): the stride-1 shortcut branch's BatchNorm backward, whose x terms are linear in a0 too —
+//   da0[m][c] += sum_{c' = c + j*C < res_C} (A2sc[c'] * a0[m][c] + A3sc[c'])  ->  G[c][c] += sum_j A2sc[c'], r3[c] += sum_j A3sc[c']
+// (the res_abc[0] * dout term is the GEMM's residual epilogue: dwn.h dwn_gemm_nn_args.res)
 template <typename T>
-__global__ __launch_bounds__(256) void pw_bwd_gram_store_kernel(const float* gacc, int E, int C, T* bp) {
+__global__ __launch_bounds__(256) void pw_bwd_gram_store_kernel(const float* gacc, int E, int C, T* bp, const float* res_abc, int res_C,
+                                                                float* r3) {
     const i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (i64)C * C) return;
     const int cp = (int)(idx / C), c = (int)(idx % C);
-    bp[(i64)c * ((i64)E + C) + E + cp] = from_f<T>(gacc[idx]);       // Bp[n = c][E + c'] = G[c'][c]
+    float g = gacc[idx];
+    if (res_abc && cp == c) {
+        float d2 = 0.f, d3 = 0.f;
+        for (int cc = c; cc < res_C; cc += C) { d2 += res_abc[res_C + cc]; d3 += res_abc[2 * res_C + cc]; }
+        g += d2;
+        r3[c] += d3;          // one thread per c; the prep kernel's atomics on r3 are complete (previous launch)
+    }
+    bp[(i64)c * ((i64)E + C) + E + cp] = from_f<T>(g);       // Bp[n = c][E + c'] = G[c'][c]
 }
 // gacc [C*C] fp32 and r3 [C] fp32 must be zero on entry (the block backward's prep launch clears them)
 int k_pw_bwd_prep(const float* w1, const float* abc, int E, int C, void* bp, float* gacc, float* r3, int dtype,
-                  hipStream_t s) {
+                  const float* res_abc, int res_C, hipStream_t s) {
     const int nscale = ((E + 63) / 64) * ((C + 63) / 64);
     const int gx = (C + 63) / 64, gy = (C + 63) / 64, gz = (E + 63) / 64;
     const int ngram = gx * gy * gz;
@@ -2207,8 +2218,8 @@ int k_pw_bwd_prep(const float* w1, const float* abc, int E, int C, void* bp, flo
     DWN_CHECK_LAUNCH();
     dim3 g3((unsigned)(((i64)C * C + 255) / 256));
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL((pw_bwd_gram_store_kernel<bf16_t>), g3, dim3(256), 0, s, gacc, E, C, (bf16_t*)bp),
-        hipLaunchKernelGGL((pw_bwd_gram_store_kernel<float>), g3, dim3(256), 0, s, gacc, E, C, (float*)bp));
+        hipLaunchKernelGGL((pw_bwd_gram_store_kernel<bf16_t>), g3, dim3(256), 0, s, gacc, E, C, (bf16_t*)bp, res_abc, res_C, r3),
+        hipLaunchKernelGGL((pw_bwd_gram_store_kernel<float>), g3, dim3(256), 0, s, gacc, E, C, (float*)bp, res_abc, res_C, r3));
     DWN_CHECK_LAUNCH();
     return 0;
 }

@@ -1216,13 +1216,14 @@ template <int NKC> struct Cfg {               // NKC = E / 64: 7 (expansion 7) o
     static constexpr int E = NKC * 64, KCAT = E + CIN;
     static constexpr int WRS = KCAT * 2 + 16;            // row stride of the resident Bp [64][E + 64]
     static constexpr int SW_BYTES = CIN * WRS, SD_BYTES = BM * RS, SX_BYTES = BM * RS;
-    static constexpr int LDS_BYTES = SW_BYTES + 2 * SD_BYTES + 2 * SX_BYTES + CIN * 4;
+    static constexpr int LDS_BYTES = SW_BYTES + 2 * SD_BYTES + 2 * SX_BYTES + 3 * CIN * 4;     // + r3, residual coefficients
 };
 }  // namespace pwb
 template <int NKC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pw_bwd_fused_kernel(const bf16_t* __restrict__ dh1, const bf16_t* __restrict__ a0,
                                                        const bf16_t* __restrict__ bp, const float* __restrict__ r3,
-                                                       bf16_t* __restrict__ da0, float* __restrict__ tacc, int M) {
+                                                       bf16_t* __restrict__ da0, float* __restrict__ tacc, int M,
+                                                       const bf16_t* __restrict__ res, const float* __restrict__ res_coef, int res_n) {
     using namespace pwb;
     constexpr int E = Cfg<NKC>::E, KCAT = Cfg<NKC>::KCAT, WRS = Cfg<NKC>::WRS;
     constexpr int SW_BYTES = Cfg<NKC>::SW_BYTES, SD_BYTES = Cfg<NKC>::SD_BYTES, SX_BYTES = Cfg<NKC>::SX_BYTES;
@@ -1231,11 +1232,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned char* sW = smem;
     unsigned char* sD = smem + SW_BYTES;
     unsigned char* sX = sD + 2 * SD_BYTES;
-    float* sR3 = reinterpret_cast<float*>(sX + 2 * SX_BYTES);
+    float* sR3 = reinterpret_cast<float*>(sX + 2 * SX_BYTES);      // r3 [64], then the residual coefficients [res_n * 64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lg = lane >> 4;
     const int wm = wave & 3, wn = wave >> 2;
     if (tid < CIN) sR3[tid] = r3[tid];
+    if (res && tid < res_n * CIN) sR3[CIN + tid] = res_coef[tid];
     // resident Bp: [n][k], 16-byte chunks
     for (int c = tid; c < CIN * (KCAT / 8); c += 512) {
         const int n = c / (KCAT / 8), kc8 = c % (KCAT / 8);
@@ -1279,6 +1281,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         *reinterpret_cast<uint4*>(sXt + (row_a + 64) * RS + ch * 16) = rx.hi;
         rx = fetch_a0(ntile);
         f32x4_t acc_da[2][2];
+        uint2 rres[2][2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) { acc_da[i][0] = f32x4_t{0, 0, 0, 0}; acc_da[i][1] = f32x4_t{0, 0, 0, 0}; }
 #pragma unroll
@@ -1288,6 +1291,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             *reinterpret_cast<uint4*>(sDk + (row_a + 64) * RS + ch * 16) = rd[kc].hi;
             nn_lds_barrier();      // LDS hand-off only: the next tile's loads stay in flight across it
             rd[kc] = fetch_chunk(ntile, kc);                     // this chunk of the NEXT tile: a whole tile of loads in flight
+            if (kc == NKC - 2 && res) {                          // the epilogue's residual values: in flight under the last two chunks
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const bf16_t* rp_ = res + (m0 + wm * 32 + i * 16 + lr) * (size_t)(res_n * CIN) + wn * 32 + j * 16 + 4 * lg;
+                        rres[i][j][0] = *reinterpret_cast<const uint2*>(rp_);
+                        rres[i][j][1] = *reinterpret_cast<const uint2*>(rp_ + (res_n > 1 ? CIN : 0));
+                    }
+            }
             // ---- data gradient: acc_da[m][n] += sum_k dh1[m][k] Bp[n][k]   (swapped roles: lanes own 4 consecutive n)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -1377,8 +1390,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const size_t m = m0 + wm * 32 + i * 16 + lr;
                 const int n = wn * 32 + j * 16 + 4 * lg;
                 const float4 b4 = *reinterpret_cast<const float4*>(sR3 + n);
-                uint2 v = make_uint2(pwb_pack2(acc_da[i][j][0] + b4.x, acc_da[i][j][1] + b4.y),
-                                     pwb_pack2(acc_da[i][j][2] + b4.z, acc_da[i][j][3] + b4.w));
+                float o[4] = {acc_da[i][j][0] + b4.x, acc_da[i][j][1] + b4.y, acc_da[i][j][2] + b4.z, acc_da[i][j][3] + b4.w};
+                if (res) {       // + the shortcut branch's gradient: sum_j coef[n + 64 j] * res[m][n + 64 j]   (dwn.h)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        if (jj >= res_n) break;
+                        const uint2 rv = rres[i][j][jj];
+                        const float4 c4 = *reinterpret_cast<const float4*>(sR3 + CIN + jj * CIN + n);
+                        o[0] = fmaf(c4.x, __uint_as_float(rv.x << 16), o[0]);
+                        o[1] = fmaf(c4.y, __uint_as_float(rv.x & 0xffff0000u), o[1]);
+                        o[2] = fmaf(c4.z, __uint_as_float(rv.y << 16), o[2]);
+                        o[3] = fmaf(c4.w, __uint_as_float(rv.y & 0xffff0000u), o[3]);
+                    }
+                }
+                uint2 v = make_uint2(pwb_pack2(o[0], o[1]), pwb_pack2(o[2], o[3]));
                 *reinterpret_cast<uint2*>(da0 + m * CIN + n) = v;
             }
     }
@@ -1407,7 +1432,7 @@ bool pw_bwd_fused_supported(int dtype, long long M, int E, int Cin) {
 }
 template <int NKC>
 static int launch_pw_bwd_fused_t(const void* dh1, const void* a0, const void* bp, const float* r3, void* da0, float* tacc,
-                                 long long M, hipStream_t s) {
+                                 long long M, const void* res, const float* res_coef, int res_n, hipStream_t s) {
     auto kern = pw_bwd_fused_kernel<NKC>;
     {   // > 64 KB of dynamic LDS needs the opt-in; per device, so it is (cheaply) repeated on every call
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pwb::Cfg<NKC>::LDS_BYTES);
@@ -1416,13 +1441,16 @@ static int launch_pw_bwd_fused_t(const void* dh1, const void* a0, const void* bp
     int grid = 256;
     if (grid > (int)(M / pwb::BM)) grid = (int)(M / pwb::BM);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pwb::Cfg<NKC>::LDS_BYTES, s, (const bf16_t*)dh1, (const bf16_t*)a0,
-                       (const bf16_t*)bp, r3, (bf16_t*)da0, tacc, (int)M);
+                       (const bf16_t*)bp, r3, (bf16_t*)da0, tacc, (int)M, (const bf16_t*)res, res_coef, res_n);
     DWN_CHECK_LAUNCH();
     return 0;
 }
+// res / res_coef / res_n: optional residual term of the stored data gradient (dwn_gemm_nn_args.res; res_ld = res_n * Cin)
 int launch_pw_bwd_fused(const void* dh1, const void* a0, const void* bp, const float* r3, void* da0, float* tacc,
-                        long long M, int E, int Cin, int dtype, hipStream_t s) {
+                        long long M, int E, int Cin, int dtype, const void* res, const float* res_coef, int res_n, hipStream_t s) {
     if (!pw_bwd_fused_supported(dtype, M, E, Cin))
         return dwn_set_error(-3, "pw_bwd_fused: built for bf16, Cin = 64, E = 448 or 384, M % 128 == 0 only");
-    return E == 448 ? launch_pw_bwd_fused_t<7>(dh1, a0, bp, r3, da0, tacc, M, s) : launch_pw_bwd_fused_t<6>(dh1, a0, bp, r3, da0, tacc, M, s);
+    if (res && (!res_coef || res_n < 1 || res_n > 2)) return dwn_set_error(-3, "pw_bwd_fused: the residual term needs res_coef and res_n in {1, 2}");
+    return E == 448 ? launch_pw_bwd_fused_t<7>(dh1, a0, bp, r3, da0, tacc, M, res, res_coef, res_n, s)
+                    : launch_pw_bwd_fused_t<6>(dh1, a0, bp, r3, da0, tacc, M, res, res_coef, res_n, s);
 }

@@ -95,7 +95,7 @@ int k_assemble_targets(const dwn_clip_desc* descs, int B, int T, float* const* t
                        int n_mice, int max_neurons, float* mice_weights, hipStream_t s);
 int k_zero(void* p, size_t nbytes, hipStream_t s);
 int k_pw_bwd_prep(const float* w1, const float* abc, int E, int C, void* bp, float* gacc, float* r3, int dtype,
-                  hipStream_t s);
+                  const float* res_abc, int res_C, hipStream_t s);
 // conv_pw weight gradient from the raw products (see pw_bwd_fused_kernel): tacc [(E + C + 8)][C] fp32 = rows T1 = dh1^T a0,
 // Ga = a0^T a0, s = 1^T a0;  dw[e][c] = A1[e] T1[e][c] + A2[e] sum_c' W1[e][c'] Ga[c'][c] + A3[e] s[c]   (W1 as rounded to dtype)
 size_t pw_wgrad_tacc_floats(int E, int C);

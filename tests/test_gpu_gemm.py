@@ -361,6 +361,31 @@ def test_pw_backward_without_y1(L, M, E, Cin, dtype):
         dy = ab[0].double() * dh1.double() + ab[1].double() * y1 + ab[2].double()
         assert rel(dw, dy.t() @ a0.double()) < (2e-3 if dtype == torch.bfloat16 else 2e-5), sel
     a.abc = abc.data_ptr()
+    # ... and with a stride-1 shortcut branch folded in (res = the block's output gradient, 1x or 2x the input channels)
+    dy = abc[0].double() * dh1.double() + abc[1].double() * y1 + abc[2].double()
+    for mult in (1, 2):
+        rc = mult * Cin
+        if not fused:            # built into the one-pass kernel only
+            res = torch.zeros(M, rc, device=dev()).to(dtype)
+            rabc = torch.zeros(3, rc, device=dev())
+            a.res, a.res_abc, a.res_C = res.data_ptr(), rabc.data_ptr(), rc
+            assert L.lib.dwn_pw_backward(C.byref(a), _dt(L, dtype), 0, stream()) == -3
+            continue
+        res = torch.randn(M, rc, generator=g, device=dev()).to(dtype)
+        rabc = torch.randn(3, rc, generator=g, device=dev()).contiguous()
+        a.res, a.res_abc, a.res_C = res.data_ptr(), rabc.data_ptr(), rc
+        L.check(L.lib.dwn_pw_backward(C.byref(a), _dt(L, dtype), 0, stream()), "pw_backward")
+        torch.cuda.synchronize()
+        want = dy @ w1r
+        for j in range(mult):
+            sl = slice(j * Cin, (j + 1) * Cin)
+            want = want + rabc[0, sl].double() * res[:, sl].double() + rabc[1, sl].double() * a0.double() + rabc[2, sl].double()
+        assert rel(da0, want) < (8e-3 if dtype == torch.bfloat16 else 2e-5), mult
+        assert rel(dw, want_dw) < (2e-4 if dtype == torch.bfloat16 else 2e-5)       # the weight gradient does not see it
+    if fused:
+        a.res_C = 3 * Cin
+        assert L.lib.dwn_pw_backward(C.byref(a), _dt(L, dtype), 0, stream()) < 0
+    a.res, a.res_abc, a.res_C = None, None, 0
     a.ws_bytes = nws - 1
     assert L.lib.dwn_pw_backward(C.byref(a), _dt(L, dtype), 0, stream()) == -6
     a.ws_bytes, a.dw = nws, None
