@@ -416,6 +416,10 @@ typedef struct dwn_pw_bwd_args {
      * dwn_pw_bwd_fused_supported (the one-pass kernel's epilogue adds it; on the two-GEMM path it measured slower than the
      * separate pass it replaces: -3 there).  NULL = off. */
     const void* res; const float* res_abc; int res_C;
+    /* ... of a strided block: res_hinv [res_Hin] / res_winv [res_Win] = the inverse nearest maps (output row / column an input
+     * row / column is sampled into, or -1), M = frames * res_Hin * res_Win; only rows m = (f, hi, wi) with both >= 0 get the sum
+     * above, with res read at row (f * res_Hout + ho) * res_Wout + wo.  NULL = identity map (stride 1: res has M rows). */
+    const int* res_hinv; const int* res_winv; int res_Hin, res_Win, res_Hout, res_Wout;
 } dwn_pw_bwd_args;
 int dwn_pw_bwd_fused_supported(int dtype, long long M, int E, int Cin);
 size_t dwn_pw_backward_workspace_bytes(int E, int Cin, int dtype);

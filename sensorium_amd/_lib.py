@@ -157,7 +157,8 @@ class ClipDesc(C.Structure):
 class PwBwdArgs(C.Structure):
     _fields_ = [("dh1", c_p), ("a0", c_p), ("w_pw", c_p), ("abc", c_p), ("da0", c_p), ("dw", c_p),
                 ("M", c_ll), ("E", c_i), ("Cin", c_i), ("ws", c_p), ("ws_bytes", c_sz), ("res", c_p), ("res_abc", c_p),
-                ("res_C", c_i)]
+                ("res_C", c_i), ("res_hinv", c_p), ("res_winv", c_p), ("res_Hin", c_i), ("res_Win", c_i), ("res_Hout", c_i),
+                ("res_Wout", c_i)]
 
 
 class DwSpatialRcFwdArgs(C.Structure):

@@ -508,18 +508,23 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
 // in dwn_block_backward).  gacc (pw_fold_floats) and tacc (pw_wgrad_tacc_floats) must be zero on entry.
 // res / res_abc / res_C (optional, dwn.h dwn_pw_bwd_args): the stride-1 shortcut branch's gradient folded in — the A2 * a0 and A3
 // terms into G / r3, the A1 * dout term as the data-gradient GEMM's residual epilogue — so that da0 is the block's input gradient.
+// rg (optional, with res): the shortcut's nearest map when it is not the identity (stride-2 block) — hinv / winv and the two
+// plane sizes; the x terms then stay in the kernel's epilogue (only sampled rows have them).
 static int pw_backward(int dt, const void* dh1, const void* a0, const float* w_pw, const float* abc, int E, int Cin, i64 M,
                        void* bp, float* gacc, float* r3, float* tacc, void* da0, float* dw, const void* res,
-                       const float* res_abc, int res_C, hipStream_t s) {
+                       const float* res_abc, int res_C, const ResGeom* rg, hipStream_t s) {
     const int res_n = res ? res_C / Cin : 0;
+    const bool gathered = res && rg && rg->hinv;
     if (res && (!res_abc || res_C % Cin || res_n < 1 || res_n > 2))
         return dwn_set_error(-2, "pw_backward: the shortcut term needs res_abc and res_C in {Cin, 2 Cin}");
     if (res && !pw_bwd_fused_supported(dt, M, E, Cin))
         return dwn_set_error(-3, "pw_backward: the shortcut term is built into the one-pass kernel only (dwn_pw_bwd_fused_supported)");
-    TRY(k_pw_bwd_prep(w_pw, abc, E, Cin, bp, gacc, r3, dt, res ? res_abc : nullptr, res_C, s));
+    TRY(k_pw_bwd_prep(w_pw, abc, E, Cin, bp, gacc, r3, dt, (res && !gathered) ? res_abc : nullptr, res_C, s));
     if (pw_bwd_fused_supported(dt, M, E, Cin)) {
         // 64-channel blocks: both products from ONE pass over dh1
-        PROF(DWN_FAM_PW_DGRAD, launch_pw_bwd_fused(dh1, a0, bp, r3, da0, tacc, M, E, Cin, dt, res, res_abc, res_n, s));
+        PROF(DWN_FAM_PW_DGRAD, launch_pw_bwd_fused(dh1, a0, bp, r3, da0, tacc, M, E, Cin, dt, res, res_abc, res_n,
+                                                   gathered ? rg->hinv : nullptr, gathered ? rg->winv : nullptr, gathered ? rg->Hin : 0,
+                                                   gathered ? rg->Win : 0, gathered ? rg->Hout : 0, gathered ? rg->Wout : 0, s));
     } else {
         {
             GemmNN g = nn_base(ld_plain(dh1, E), LD_PLAIN, bp, (i64)E + Cin, da0, Cin, (int)M, Cin, E + Cin, 1);
@@ -647,11 +652,12 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     // On a stride-1 block (identity shortcut map, output channels = input channels tiled once or twice) the shortcut branch's
     // gradient is folded into this GEMM and its result IS dx: no pass over (da0, x, dout) -> dx.
     // (one-pass kernel only: as an epilogue of the two-GEMM path's data-gradient GEMM it cost 30-60 us where the pass it replaces
-    // takes 20-35)
-    const bool dx_folded = a.stride == 1 && a.Hin == a.Hout && a.Win == a.Wout && a.Cout % a.Cin == 0 && a.Cout / a.Cin <= 2 &&
-                           dwn_pw_bwd_fused_supported(dt, Min, a.Cmid, a.Cin);
+    // takes 20-35.)  On a strided block the epilogue gathers: only the rows the nearest map samples carry the shortcut's terms.
+    const bool identity_sc = a.stride == 1 && a.Hin == a.Hout && a.Win == a.Wout;
+    const bool dx_folded = a.Cout % a.Cin == 0 && a.Cout / a.Cin <= 2 && dwn_pw_bwd_fused_supported(dt, Min, a.Cmid, a.Cin) &&
+                           (identity_sc || (gm.hinv && gm.winv));
     TRY(pw_backward(dt, dh1, xin.p, a.w_pw, w.abc1, a.Cmid, a.Cin, Min, w.bp, w.gacc, w.r3, w.tacc, dx_folded ? a.dx : a.da0, a.dw_pw,
-                    dx_folded ? a.dout : nullptr, w.abcsc, a.Cout, s));
+                    dx_folded ? a.dout : nullptr, w.abcsc, a.Cout, (dx_folded && !identity_sc) ? &gm : nullptr, s));
     if (dx_folded) return 0;
     PROF(DWN_FAM_RESID_BWD, k_residual_bwd_dx(xin, a.da0, a.dout, w.abcsc, gm, a.dx, dt, s));
     return 0;
@@ -910,8 +916,10 @@ int dwn_pw_backward(const dwn_pw_bwd_args* a, int dtype, int device, void* strea
     float* r3 = gacc + (size_t)a->Cin * a->Cin;
     float* tacc = gacc + pw_fold_floats(a->Cin);
     TRY(k_zero(gacc, nz * sizeof(float), s));
+    ResGeom rg; memset(&rg, 0, sizeof(rg));
+    rg.hinv = a->res_hinv; rg.winv = a->res_winv; rg.Hin = a->res_Hin; rg.Win = a->res_Win; rg.Hout = a->res_Hout; rg.Wout = a->res_Wout;
     return pw_backward(dtype, a->dh1, a->a0, a->w_pw, a->abc, a->E, a->Cin, a->M, bp, gacc, r3, tacc, a->da0, a->dw, a->res,
-                       a->res_abc, a->res_C, s);
+                       a->res_abc, a->res_C, a->res_hinv ? &rg : nullptr, s);
 }
 
 int dwn_assemble_inputs(const dwn_clip_desc* descs, int B, int T, int H0, int W0, int H, int W, float pad_fill,

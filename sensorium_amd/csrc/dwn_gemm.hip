@@ -1216,14 +1216,22 @@ template <int NKC> struct Cfg {               // NKC = E / 64: 7 (expansion 7) o
     static constexpr int E = NKC * 64, KCAT = E + CIN;
     static constexpr int WRS = KCAT * 2 + 16;            // row stride of the resident Bp [64][E + 64]
     static constexpr int SW_BYTES = CIN * WRS, SD_BYTES = BM * RS, SX_BYTES = BM * RS;
-    static constexpr int LDS_BYTES = SW_BYTES + 2 * SD_BYTES + 2 * SX_BYTES + 3 * CIN * 4;     // + r3, residual coefficients
+    static constexpr int LDS_BYTES = SW_BYTES + 2 * SD_BYTES + 2 * SX_BYTES + 7 * CIN * 4;     // + r3 [64], residual coefficients [<= 3][128]
 };
 }  // namespace pwb
+// The shortcut branch's gradient in the kernel's epilogue (res != NULL), two forms:
+//   identity map (stride-1 block; gq.hinv == NULL): its x terms are already in G / r3 (k_pw_bwd_prep), the epilogue adds
+//     sum_j A1sc[n + 64 j] * res[m][n + 64 j];
+//   gathered rows (stride-2 block; gq.hinv / gq.winv = inverse nearest maps, -1 = row not sampled): a row m = (bt, hi, wi) that the
+//     shortcut samples adds sum_j (A1sc * res[rout][n + 64 j] + A2sc * a0[m][n] + A3sc) with rout = (bt * Hout + ho) * Wout + wo;
+//     the other rows add nothing (so nothing can be folded into G / r3).  res_coef = [3][res_n * 64] (A1sc, A2sc, A3sc).
+struct PwbGather { const int* hinv; const int* winv; int Hin, Win, Hout, Wout; };
 template <int NKC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pw_bwd_fused_kernel(const bf16_t* __restrict__ dh1, const bf16_t* __restrict__ a0,
                                                        const bf16_t* __restrict__ bp, const float* __restrict__ r3,
                                                        bf16_t* __restrict__ da0, float* __restrict__ tacc, int M,
-                                                       const bf16_t* __restrict__ res, const float* __restrict__ res_coef, int res_n) {
+                                                       const bf16_t* __restrict__ res, const float* __restrict__ res_coef, int res_n,
+                                                       const PwbGather gq) {
     using namespace pwb;
     constexpr int E = Cfg<NKC>::E, KCAT = Cfg<NKC>::KCAT, WRS = Cfg<NKC>::WRS;
     constexpr int SW_BYTES = Cfg<NKC>::SW_BYTES, SD_BYTES = Cfg<NKC>::SD_BYTES, SX_BYTES = Cfg<NKC>::SX_BYTES;
@@ -1237,7 +1245,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int lr = lane & 15, lg = lane >> 4;
     const int wm = wave & 3, wn = wave >> 2;
     if (tid < CIN) sR3[tid] = r3[tid];
-    if (res && tid < res_n * CIN) sR3[CIN + tid] = res_coef[tid];
+    const bool gather = res && gq.hinv;
+    if (res) for (int i = tid; i < (gather ? 3 : 1) * res_n * CIN; i += 512) sR3[CIN + i] = res_coef[i];
+    const RasterIdx ridx(gather ? gq.Hin : 1, gather ? gq.Win : 1);
     // resident Bp: [n][k], 16-byte chunks
     for (int c = tid; c < CIN * (KCAT / 8); c += 512) {
         const int n = c / (KCAT / 8), kc8 = c % (KCAT / 8);
@@ -1282,6 +1292,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         rx = fetch_a0(ntile);
         f32x4_t acc_da[2][2];
         uint2 rres[2][2][2];
+        bool rgat[2] = {true, true};            // gather form: is this lane's row i sampled by the shortcut?
 #pragma unroll
         for (int i = 0; i < 2; ++i) { acc_da[i][0] = f32x4_t{0, 0, 0, 0}; acc_da[i][1] = f32x4_t{0, 0, 0, 0}; }
 #pragma unroll
@@ -1293,13 +1304,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             rd[kc] = fetch_chunk(ntile, kc);                     // this chunk of the NEXT tile: a whole tile of loads in flight
             if (kc == NKC - 2 && res) {                          // the epilogue's residual values: in flight under the last two chunks
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) {
+                    size_t rrow = m0 + wm * 32 + i * 16 + lr;
+                    if (gather) {
+                        unsigned bt; int hi, wi;
+                        ridx.decode((unsigned)rrow, bt, hi, wi);
+                        const int ho = gq.hinv[hi], wo = gq.winv[wi];
+                        rgat[i] = ho >= 0 && wo >= 0;
+                        rrow = rgat[i] ? ((size_t)bt * gq.Hout + ho) * gq.Wout + wo : 0;
+                    }
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const bf16_t* rp_ = res + (m0 + wm * 32 + i * 16 + lr) * (size_t)(res_n * CIN) + wn * 32 + j * 16 + 4 * lg;
+                        const bf16_t* rp_ = res + rrow * (size_t)(res_n * CIN) + wn * 32 + j * 16 + 4 * lg;
                         rres[i][j][0] = *reinterpret_cast<const uint2*>(rp_);
                         rres[i][j][1] = *reinterpret_cast<const uint2*>(rp_ + (res_n > 1 ? CIN : 0));
                     }
+                }
             }
             // ---- data gradient: acc_da[m][n] += sum_k dh1[m][k] Bp[n][k]   (swapped roles: lanes own 4 consecutive n)
 #pragma unroll
@@ -1392,15 +1412,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const float4 b4 = *reinterpret_cast<const float4*>(sR3 + n);
                 float o[4] = {acc_da[i][j][0] + b4.x, acc_da[i][j][1] + b4.y, acc_da[i][j][2] + b4.z, acc_da[i][j][3] + b4.w};
                 if (res) {       // + the shortcut branch's gradient: sum_j coef[n + 64 j] * res[m][n + 64 j]   (dwn.h)
+                    const int rc = res_n * CIN;
+                    float x4[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (gather) {
+                        const uint2 xv = *reinterpret_cast<const uint2*>(sXt + (wm * 32 + i * 16 + lr) * RS + n * 2);
+                        x4[0] = __uint_as_float(xv.x << 16); x4[1] = __uint_as_float(xv.x & 0xffff0000u);
+                        x4[2] = __uint_as_float(xv.y << 16); x4[3] = __uint_as_float(xv.y & 0xffff0000u);
+                    }
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
-                        if (jj >= res_n) break;
+                        if (jj >= res_n || !rgat[i]) break;
                         const uint2 rv = rres[i][j][jj];
                         const float4 c4 = *reinterpret_cast<const float4*>(sR3 + CIN + jj * CIN + n);
-                        o[0] = fmaf(c4.x, __uint_as_float(rv.x << 16), o[0]);
-                        o[1] = fmaf(c4.y, __uint_as_float(rv.x & 0xffff0000u), o[1]);
-                        o[2] = fmaf(c4.z, __uint_as_float(rv.y << 16), o[2]);
-                        o[3] = fmaf(c4.w, __uint_as_float(rv.y & 0xffff0000u), o[3]);
+                        float t[4] = {c4.x * __uint_as_float(rv.x << 16), c4.y * __uint_as_float(rv.x & 0xffff0000u),
+                                      c4.z * __uint_as_float(rv.y << 16), c4.w * __uint_as_float(rv.y & 0xffff0000u)};
+                        if (gather) {
+                            const float4 a2 = *reinterpret_cast<const float4*>(sR3 + CIN + rc + jj * CIN + n);
+                            const float4 a3 = *reinterpret_cast<const float4*>(sR3 + CIN + 2 * rc + jj * CIN + n);
+                            t[0] += fmaf(a2.x, x4[0], a3.x); t[1] += fmaf(a2.y, x4[1], a3.y);
+                            t[2] += fmaf(a2.z, x4[2], a3.z); t[3] += fmaf(a2.w, x4[3], a3.w);
+                        }
+                        o[0] += t[0]; o[1] += t[1]; o[2] += t[2]; o[3] += t[3];
                     }
                 }
                 uint2 v = make_uint2(pwb_pack2(o[0], o[1]), pwb_pack2(o[2], o[3]));
@@ -1432,7 +1464,7 @@ bool pw_bwd_fused_supported(int dtype, long long M, int E, int Cin) {
 }
 template <int NKC>
 static int launch_pw_bwd_fused_t(const void* dh1, const void* a0, const void* bp, const float* r3, void* da0, float* tacc,
-                                 long long M, const void* res, const float* res_coef, int res_n, hipStream_t s) {
+                                 long long M, const void* res, const float* res_coef, int res_n, const PwbGather& gq, hipStream_t s) {
     auto kern = pw_bwd_fused_kernel<NKC>;
     {   // > 64 KB of dynamic LDS needs the opt-in; per device, so it is (cheaply) repeated on every call
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pwb::Cfg<NKC>::LDS_BYTES);
@@ -1441,16 +1473,21 @@ static int launch_pw_bwd_fused_t(const void* dh1, const void* a0, const void* bp
     int grid = 256;
     if (grid > (int)(M / pwb::BM)) grid = (int)(M / pwb::BM);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pwb::Cfg<NKC>::LDS_BYTES, s, (const bf16_t*)dh1, (const bf16_t*)a0,
-                       (const bf16_t*)bp, r3, (bf16_t*)da0, tacc, (int)M, (const bf16_t*)res, res_coef, res_n);
+                       (const bf16_t*)bp, r3, (bf16_t*)da0, tacc, (int)M, (const bf16_t*)res, res_coef, res_n, gq);
     DWN_CHECK_LAUNCH();
     return 0;
 }
-// res / res_coef / res_n: optional residual term of the stored data gradient (dwn_gemm_nn_args.res; res_ld = res_n * Cin)
+// res / res_coef / res_n (+ hinv, winv, Hin, Win, Hout, Wout for the gathered form): the shortcut branch's gradient in the epilogue
+// (see PwbGather above); res rows are res_n * Cin wide
 int launch_pw_bwd_fused(const void* dh1, const void* a0, const void* bp, const float* r3, void* da0, float* tacc,
-                        long long M, int E, int Cin, int dtype, const void* res, const float* res_coef, int res_n, hipStream_t s) {
+                        long long M, int E, int Cin, int dtype, const void* res, const float* res_coef, int res_n,
+                        const int* hinv, const int* winv, int Hin, int Win, int Hout, int Wout, hipStream_t s) {
+    PwbGather gq; gq.hinv = hinv; gq.winv = winv; gq.Hin = Hin; gq.Win = Win; gq.Hout = Hout; gq.Wout = Wout;
+    if (res && hinv && (!winv || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || M % ((long long)Hin * Win)))
+        return dwn_set_error(-2, "pw_bwd_fused: the gathered shortcut form needs both inverse maps and M = frames * Hin * Win");
     if (!pw_bwd_fused_supported(dtype, M, E, Cin))
         return dwn_set_error(-3, "pw_bwd_fused: built for bf16, Cin = 64, E = 448 or 384, M % 128 == 0 only");
     if (res && (!res_coef || res_n < 1 || res_n > 2)) return dwn_set_error(-3, "pw_bwd_fused: the residual term needs res_coef and res_n in {1, 2}");
-    return E == 448 ? launch_pw_bwd_fused_t<7>(dh1, a0, bp, r3, da0, tacc, M, res, res_coef, res_n, s)
-                    : launch_pw_bwd_fused_t<6>(dh1, a0, bp, r3, da0, tacc, M, res, res_coef, res_n, s);
+    return E == 448 ? launch_pw_bwd_fused_t<7>(dh1, a0, bp, r3, da0, tacc, M, res, res_coef, res_n, gq, s)
+                    : launch_pw_bwd_fused_t<6>(dh1, a0, bp, r3, da0, tacc, M, res, res_coef, res_n, gq, s);
 }

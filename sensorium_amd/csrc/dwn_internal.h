@@ -21,4 +21,5 @@ int launch_dw_temporal_fwd(const DwTemporalFwd& a, int dtype, hipStream_t s);
 int launch_dw_temporal_bwd(const DwTemporalBwd& a, int dtype, hipStream_t s);
 bool pw_bwd_fused_supported(int dtype, long long M, int E, int Cin);
 int launch_pw_bwd_fused(const void* dh1, const void* a0, const void* bp, const float* r3, void* da0, float* tacc,
-                        long long M, int E, int Cin, int dtype, const void* res, const float* res_coef, int res_n, hipStream_t s);
+                        long long M, int E, int Cin, int dtype, const void* res, const float* res_coef, int res_n,
+                        const int* hinv, const int* winv, int Hin, int Win, int Hout, int Wout, hipStream_t s);

@@ -390,3 +390,57 @@ def test_pw_backward_without_y1(L, M, E, Cin, dtype):
     assert L.lib.dwn_pw_backward(C.byref(a), _dt(L, dtype), 0, stream()) == -6
     a.ws_bytes, a.dw = nws, None
     assert L.lib.dwn_pw_backward(C.byref(a), _dt(L, dtype), 0, stream()) < 0
+
+
+@pytest.mark.parametrize("E,mult", [(448, 1), (448, 2), (384, 1)])
+def test_pw_backward_gathered_shortcut(L, E, mult):
+    """dwn_pw_backward with the shortcut branch of a STRIDED block in the one-pass kernel's epilogue: only the rows the nearest map
+    samples (here every second row and column) get  A1sc*dout[rout] + A2sc*a0 + A3sc  (include/dwn.h dwn_pw_bwd_args.res_hinv)."""
+    Cin, F, Hin, Win = 64, 5, 32, 32
+    Hout, Wout = 16, 16
+    M, rc = F * Hin * Win, mult * Cin
+    dtype = torch.bfloat16
+    assert L.lib.dwn_pw_bwd_fused_supported(L.DWN_BF16, M, E, Cin) == 1
+    g = torch.Generator(device="cuda").manual_seed(E + mult)
+    dh1 = torch.randn(M, E, generator=g, device=dev()).to(dtype)
+    a0 = (torch.randn(M, Cin, generator=g, device=dev()) + 0.3).to(dtype)
+    w1 = (torch.randn(E, Cin, generator=g, device=dev()) * 0.1).contiguous()
+    abc = torch.randn(3, E, generator=g, device=dev()).contiguous()
+    res = torch.randn(F * Hout * Wout, rc, generator=g, device=dev()).to(dtype)
+    rabc = torch.randn(3, rc, generator=g, device=dev()).contiguous()
+    hinv = torch.full((Hin,), -1, dtype=torch.int32); hinv[::2] = torch.arange(Hout, dtype=torch.int32)
+    winv = torch.full((Win,), -1, dtype=torch.int32); winv[::2] = torch.arange(Wout, dtype=torch.int32)
+    hinv_d, winv_d = hinv.to(dev()), winv.to(dev())
+    da0 = torch.full((M, Cin), float("nan"), device=dev()).to(dtype)
+    dw = torch.full((E, Cin), float("nan"), device=dev())
+    nws = L.lib.dwn_pw_backward_workspace_bytes(E, Cin, L.DWN_BF16)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev())
+    a = L.PwBwdArgs()
+    a.dh1, a.a0, a.w_pw, a.abc = dh1.data_ptr(), a0.data_ptr(), w1.data_ptr(), abc.data_ptr()
+    a.da0, a.dw, a.M, a.E, a.Cin, a.ws, a.ws_bytes = da0.data_ptr(), dw.data_ptr(), M, E, Cin, ws.data_ptr(), nws
+    a.res, a.res_abc, a.res_C = res.data_ptr(), rabc.data_ptr(), rc
+    a.res_hinv, a.res_winv = hinv_d.data_ptr(), winv_d.data_ptr()
+    a.res_Hin, a.res_Win, a.res_Hout, a.res_Wout = Hin, Win, Hout, Wout
+    L.check(L.lib.dwn_pw_backward(C.byref(a), L.DWN_BF16, 0, stream()), "pw_backward")
+    torch.cuda.synchronize()
+    w1r = w1.to(dtype).double()
+    y1 = a0.double() @ w1r.t()
+    dy = abc[0].double() * dh1.double() + abc[1].double() * y1 + abc[2].double()
+    want = (dy @ w1r).view(F, Hin, Win, Cin).clone()
+    a0v = a0.double().view(F, Hin, Win, Cin)
+    resv = res.double().view(F, Hout, Wout, rc)
+    for j in range(mult):
+        sl = slice(j * Cin, (j + 1) * Cin)
+        want[:, ::2, ::2] += rabc[0, sl].double() * resv[..., sl] + rabc[1, sl].double() * a0v[:, ::2, ::2] + rabc[2, sl].double()
+    assert torch.isfinite(da0.float()).all()
+    assert rel(da0, want.view(M, Cin)) < 8e-3
+    # the rows the map skips are exactly the plain data gradient
+    a.res = None
+    da1 = torch.empty_like(da0); a.da0 = da1.data_ptr()
+    L.check(L.lib.dwn_pw_backward(C.byref(a), L.DWN_BF16, 0, stream()), "pw_backward")
+    torch.cuda.synchronize()
+    skip = torch.ones(F, Hin, Win, dtype=torch.bool, device=dev()); skip[:, ::2, ::2] = False
+    # (not bit for bit: G is accumulated with fp32 atomics in arrival order and then rounded to bf16)
+    assert rel(da0.view(F, Hin, Win, Cin)[skip], da1.view(F, Hin, Win, Cin)[skip].double()) < 2e-3
+    assert rel(da0.view(F, Hin, Win, Cin)[~skip], da1.view(F, Hin, Win, Cin)[~skip].double()) > 5e-2     # the sampled rows did change
+    assert rel(dw, dy.t() @ a0.double()) < 2e-4
