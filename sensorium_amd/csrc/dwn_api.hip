@@ -655,7 +655,7 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     // takes 20-35.)  On a strided block the epilogue gathers: only the rows the nearest map samples carry the shortcut's terms.
     const bool identity_sc = a.stride == 1 && a.Hin == a.Hout && a.Win == a.Wout;
     const bool dx_folded = a.Cout % a.Cin == 0 && a.Cout / a.Cin <= 2 && dwn_pw_bwd_fused_supported(dt, Min, a.Cmid, a.Cin) &&
-                           (identity_sc || (gm.hinv && gm.winv));
+                           (identity_sc || (gm.hinv && gm.winv && a.Hin + a.Win <= 512));
     TRY(pw_backward(dt, dh1, xin.p, a.w_pw, w.abc1, a.Cmid, a.Cin, Min, w.bp, w.gacc, w.r3, w.tacc, dx_folded ? a.dx : a.da0, a.dw_pw,
                     dx_folded ? a.dout : nullptr, w.abcsc, a.Cout, (dx_folded && !identity_sc) ? &gm : nullptr, s));
     if (dx_folded) return 0;

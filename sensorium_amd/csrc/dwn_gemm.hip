@@ -1216,7 +1216,8 @@ template <int NKC> struct Cfg {               // NKC = E / 64: 7 (expansion 7) o
     static constexpr int E = NKC * 64, KCAT = E + CIN;
     static constexpr int WRS = KCAT * 2 + 16;            // row stride of the resident Bp [64][E + 64]
     static constexpr int SW_BYTES = CIN * WRS, SD_BYTES = BM * RS, SX_BYTES = BM * RS;
-    static constexpr int LDS_BYTES = SW_BYTES + 2 * SD_BYTES + 2 * SX_BYTES + 7 * CIN * 4;     // + r3 [64], residual coefficients [<= 3][128]
+    static constexpr int MAP_INTS = 512;      // staged inverse nearest maps of the gathered shortcut form: Hin + Win entries
+    static constexpr int LDS_BYTES = SW_BYTES + 2 * SD_BYTES + 2 * SX_BYTES + 7 * CIN * 4 + MAP_INTS * 4;   // + r3 [64], residual coefficients [<= 3][128], maps
 };
 }  // namespace pwb
 // The shortcut branch's gradient in the kernel's epilogue (res != NULL), two forms:
@@ -1247,6 +1248,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tid < CIN) sR3[tid] = r3[tid];
     const bool gather = res && gq.hinv;
     if (res) for (int i = tid; i < (gather ? 3 : 1) * res_n * CIN; i += 512) sR3[CIN + i] = res_coef[i];
+    // the inverse nearest maps, staged once (the epilogue's row decode must not wait for two dependent global loads per tile)
+    int* sMap = reinterpret_cast<int*>(sR3 + 7 * CIN);
+    if (gather) for (int i = tid; i < gq.Hin + gq.Win; i += 512) sMap[i] = i < gq.Hin ? gq.hinv[i] : gq.winv[i - gq.Hin];
     const RasterIdx ridx(gather ? gq.Hin : 1, gather ? gq.Win : 1);
     // resident Bp: [n][k], 16-byte chunks
     for (int c = tid; c < CIN * (KCAT / 8); c += 512) {
@@ -1302,14 +1306,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             *reinterpret_cast<uint4*>(sDk + (row_a + 64) * RS + ch * 16) = rd[kc].hi;
             nn_lds_barrier();      // LDS hand-off only: the next tile's loads stay in flight across it
             rd[kc] = fetch_chunk(ntile, kc);                     // this chunk of the NEXT tile: a whole tile of loads in flight
-            if (kc == NKC - 2 && res) {                          // the epilogue's residual values: in flight under the last two chunks
+            if (kc == NKC - 3 && res) {                          // the epilogue's residual values: in flight under the last three chunks
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     size_t rrow = m0 + wm * 32 + i * 16 + lr;
                     if (gather) {
                         unsigned bt; int hi, wi;
                         ridx.decode((unsigned)rrow, bt, hi, wi);
-                        const int ho = gq.hinv[hi], wo = gq.winv[wi];
+                        const int ho = sMap[hi], wo = sMap[gq.Hin + wi];
                         rgat[i] = ho >= 0 && wo >= 0;
                         rrow = rgat[i] ? ((size_t)bt * gq.Hout + ho) * gq.Wout + wo : 0;
                     }
@@ -1483,8 +1487,8 @@ int launch_pw_bwd_fused(const void* dh1, const void* a0, const void* bp, const f
                         long long M, int E, int Cin, int dtype, const void* res, const float* res_coef, int res_n,
                         const int* hinv, const int* winv, int Hin, int Win, int Hout, int Wout, hipStream_t s) {
     PwbGather gq; gq.hinv = hinv; gq.winv = winv; gq.Hin = Hin; gq.Win = Win; gq.Hout = Hout; gq.Wout = Wout;
-    if (res && hinv && (!winv || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || M % ((long long)Hin * Win)))
-        return dwn_set_error(-2, "pw_bwd_fused: the gathered shortcut form needs both inverse maps and M = frames * Hin * Win");
+    if (res && hinv && (!winv || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || M % ((long long)Hin * Win) || Hin + Win > 512))
+        return dwn_set_error(-2, "pw_bwd_fused: the gathered shortcut form needs both inverse maps, M = frames * Hin * Win and Hin + Win <= 512");
     if (!pw_bwd_fused_supported(dtype, M, E, Cin))
         return dwn_set_error(-3, "pw_bwd_fused: built for bf16, Cin = 64, E = 448 or 384, M % 128 == 0 only");
     if (res && (!res_coef || res_n < 1 || res_n > 2)) return dwn_set_error(-3, "pw_bwd_fused: the residual term needs res_coef and res_n in {1, 2}");
