@@ -47,12 +47,9 @@ struct XlArgs {
     bf16_t* C; i64 ldc;
     int M, N, K, groups;
     double* stats; int stat_nchan;
-    // DWN_EPI_STORE_CAT: columns k >= K1 of the A operand come from A2[m][k - K1] (K1 % 64 == 0: a k-step lies in one operand),
-    // bias[N] (fp32) is added before rounding.  A2 == NULL: plain store epilogue.
-    const bf16_t* A2; i64 lda2; int K1; const float* bias;
 };
 
-template <int BN, bool CAT = false>
+template <int BN>
 __global__ __launch_bounds__(512, 2) void gemm_nn_xl_kernel(const XlArgs g) {
     constexpr int BM = 256, BK = 64;
     constexpr int WN = BN / 64;                         // waves along N (4 or 2)
@@ -100,9 +97,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nn_xl_kernel(const XlArgs g) {
         const int klane = (cch ^ rin) << 3;                                  // source-side swizzle: LDS chunk cch holds k-chunk cch ^ (row & 7)
         const bool nfull = n0 + BN <= g.N;
         const bf16_t* b0 = Bg + (i64)(n0 + wave * 8 + rin < g.N ? n0 + wave * 8 + rin : g.N - 1) * g.ldb + klane;
-        const i64 bstride = 64 * g.ldb, astride = 64 * g.lda, astride2 = 64 * g.lda2;
+        const i64 bstride = 64 * g.ldb, astride = 64 * g.lda;
         const bf16_t* a0p = Ag;
-        const bf16_t* a1p = g.A2;                        // K-concatenated second operand: this lane's row of the tile
         int aptr_mt = -1;
         bool mfull = false;
         auto issue = [&](const int ks, const int mt, const int stage) {
@@ -112,24 +108,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nn_xl_kernel(const XlArgs g) {
                 aptr_mt = mt; mfull = mt * BM + BM <= g.M;
                 const int m = mt * BM + wave * 8 + rin < g.M ? mt * BM + wave * 8 + rin : g.M - 1;
                 a0p = Ag + (i64)m * g.lda + klane;
-                if constexpr (CAT) a1p = g.A2 + (i64)m * g.lda2 + klane;
             }
             const bool kfull = k0 + BK <= g.K;
-            const bool second = CAT && k0 >= g.K1;                // this k-step reads the concatenated operand
             if (mfull && kfull) {
-                const bf16_t* ab = second ? a1p + (k0 - g.K1) : a0p + k0;
-                const i64 as = second ? astride2 : astride;
 #pragma unroll
                 for (int r = 0; r < A_CH; ++r)
-                    xl_glds16(ab + r * as, (unsigned)__builtin_amdgcn_readfirstlane((int)(sa + (unsigned)r * 8192u)));
+                    xl_glds16(a0p + r * astride + k0, (unsigned)__builtin_amdgcn_readfirstlane((int)(sa + (unsigned)r * 8192u)));
             } else {
                 const bool kok = k0 + klane < g.K;
 #pragma unroll
                 for (int r = 0; r < A_CH; ++r) {
                     int m = mt * BM + (r * 8 + wave) * 8 + rin;
                     m = m < g.M ? m : g.M - 1;
-                    const bf16_t* src = second ? g.A2 + (i64)m * g.lda2 + klane + (k0 - g.K1) : Ag + (i64)m * g.lda + klane + k0;
-                    xl_glds16(kok ? (const void*)src : (const void*)xl_zero_src,
+                    xl_glds16(kok ? (const void*)(Ag + (i64)m * g.lda + klane + k0) : (const void*)xl_zero_src,
                               (unsigned)__builtin_amdgcn_readfirstlane((int)(sa + (unsigned)r * 8192u)));
                 }
             }
@@ -173,7 +164,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nn_xl_kernel(const XlArgs g) {
             // first MFMA (in-order issue) while the first-dispatched ones idled at the barrier (in-kernel stamps)
             bool fast = false;
             const bf16_t *pa = nullptr, *pb = nullptr;
-            i64 pastride = astride;
             unsigned sdst = 0;
             if (step + 1 < nsteps) {
                 const int k0 = ks1 * BK;
@@ -181,15 +171,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nn_xl_kernel(const XlArgs g) {
                     aptr_mt = mt1; mfull = mt1 * BM + BM <= g.M;
                     const int m = mt1 * BM + wave * 8 + rin < g.M ? mt1 * BM + wave * 8 + rin : g.M - 1;
                     a0p = Ag + (i64)m * g.lda + klane;
-                    if constexpr (CAT) a1p = g.A2 + (i64)m * g.lda2 + klane;
                 }
                 fast = mfull && nfull && k0 + BK <= g.K;
-                if (fast) {
-                    const bool second = CAT && k0 >= g.K1;
-                    pa = second ? a1p + (k0 - g.K1) : a0p + k0;
-                    pastride = second ? astride2 : astride;
-                    pb = b0 + k0; sdst = lds0 + (unsigned)((step + 1) & 1) * STG + (unsigned)wave * 1024u;
-                }
+                if (fast) { pa = a0p + k0; pb = b0 + k0; sdst = lds0 + (unsigned)((step + 1) & 1) * STG + (unsigned)wave * 1024u; }
                 else issue(ks1, mt1, (step + 1) & 1);                    // ragged tile / K tail: everything up front
             }
             const unsigned char* tA = xl_smem + (step & 1) * STG;
@@ -222,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nn_xl_kernel(const XlArgs g) {
                     if (slot % SP == 0 && slot / SP < NL) {
                         const int q = slot / SP;
                         if (fast) {
-                            if (q < A_CH) xl_glds16(pa + q * pastride, (unsigned)__builtin_amdgcn_readfirstlane((int)(sdst + (unsigned)q * 8192u)));
+                            if (q < A_CH) xl_glds16(pa + q * astride, (unsigned)__builtin_amdgcn_readfirstlane((int)(sdst + (unsigned)q * 8192u)));
                             else xl_glds16(pb + (q - A_CH) * bstride, (unsigned)__builtin_amdgcn_readfirstlane((int)(sdst + A_BYTES + (unsigned)(q - A_CH) * 8192u)));
                         }
                     }
@@ -245,11 +229,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nn_xl_kernel(const XlArgs g) {
                         const bool rok = mw + i * 16 + lr < g.M;
 #pragma unroll
                         for (int j = 0; j < RN; ++j) {
-                            if constexpr (CAT) {
-                                const int nb = n0 + n_base + j * 16 + 4 * lg;
-                                const float4 bv = *reinterpret_cast<const float4*>(g.bias + (nb + 3 < g.N ? nb : 0));
-                                acc[i][j][0] += bv.x; acc[i][j][1] += bv.y; acc[i][j][2] += bv.z; acc[i][j][3] += bv.w;
-                            }
                             const unsigned p0 = pk_bf16(acc[i][j][0], acc[i][j][1]), p1 = pk_bf16(acc[i][j][2], acc[i][j][3]);
                             *reinterpret_cast<uint2*>(slab + ii * 2048 + lr * 128 + (((j * 2 + (lg >> 1)) ^ (lr & 7)) << 4) + (lg & 1) * 8) = make_uint2(p0, p1);
                             if (g.stats && rok) {
@@ -303,27 +282,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nn_xl_kernel(const XlArgs g) {
 
 #undef XL_ADV
 
-// the K-concatenated data-gradient products through this kernel by default? (A/B switch of the build; see the launcher comment)
-#ifndef XL_CAT_AUTO
-#define XL_CAT_AUTO 1
-#endif
-
 // shapes this kernel takes over (dwn_gemm_nn_args.variant: DWN_NN_XL128 / DWN_NN_XL256 force it where the arguments allow it)
 bool gemm_nn_xl_eligible(const GemmNN& g, int dtype) {
 #ifdef DWN_DETERMINISTIC
     return false;                                         // the deterministic build keeps to the kernels with ordered reductions
 #endif
     if (g.variant == DWN_NN_TILE128) return false;
-    if (dtype != DWN_BF16 || g.a_kind != LD_PLAIN || g.b_sample_stride) return false;
-    const bool cat = g.epi == EPI_STORE_CAT;             // K-concatenated A operand + bias (the conv_pw data gradient, K = E + Cin)
-    if (g.epi != EPI_STORE && !cat) return false;
-    if (!cat && g.a2) return false;
-    if (cat && (!g.a2 || !g.bias || g.K1 % 64 || g.K1 <= 0 || g.K1 >= g.K || g.a2_ld % 8 || ((size_t)g.a2 & 15) || g.stats || g.groups != 1))
-        return false;
+    if (dtype != DWN_BF16 || g.a_kind != LD_PLAIN || g.epi != EPI_STORE || g.b_sample_stride || g.a2) return false;
     if (g.K % 8 || g.N % 8 || g.a.ld % 8 || g.ldb % 8 || g.ldc % 8 || g.M < 1) return false;
     if (((size_t)g.a.p | (size_t)g.b | (size_t)g.c) & 15) return false;
     if (g.variant == DWN_NN_XL128 || g.variant == DWN_NN_XL256) return true;
-    if (cat) return XL_CAT_AUTO && g.K >= 1024 && g.M >= 8192 && g.N >= 128;
     // measured (tools/xl_check.py): wins on the big-M, K = 256 expand convs of the 256-channel blocks (321 -> 222 us at
     // 147456 x 1792 x 256, 80 -> 66 us at 40960 rows); the M = 1024 cortex / readout-gradient shapes stay with the 128x128 kernel
     // (16-75 us there against 20-86 us here: too few tiles to amortise the 256-row pipeline's fill)
@@ -335,24 +303,23 @@ int launch_gemm_nn_xl(const GemmNN& g, hipStream_t s) {
     a.A = reinterpret_cast<const bf16_t*>(g.a.p); a.lda = g.a.ld; a.B = reinterpret_cast<const bf16_t*>(g.b); a.ldb = g.ldb;
     a.C = reinterpret_cast<bf16_t*>(g.c); a.ldc = g.ldc; a.M = g.M; a.N = g.N; a.K = g.K; a.groups = g.groups;
     a.stats = g.stats; a.stat_nchan = g.stat_nchan;
-    a.A2 = nullptr; a.lda2 = 0; a.K1 = 0; a.bias = nullptr;
-    if (g.epi == EPI_STORE_CAT) { a.A2 = reinterpret_cast<const bf16_t*>(g.a2); a.lda2 = g.a2_ld; a.K1 = g.K1; a.bias = g.bias; }
     const i64 ntm = (g.M + 255) / 256;
     const i64 tiles256 = ntm * ((g.N + 255) / 256) * g.groups;
-    // enough 256-column tiles to fill the chip — and columns to fill them
-    const bool wide = g.variant != DWN_NN_AUTO ? g.variant == DWN_NN_XL256 : (tiles256 >= 256 && g.N > 128);
+    const bool wide = g.variant != DWN_NN_AUTO ? g.variant == DWN_NN_XL256 : tiles256 >= 256;      // enough 256-column tiles to fill the chip
     const int grid = 256;                                                 // one workgroup per CU (LDS), a multiple of 8
-#define XL_LAUNCH(BN_, CAT_) do { \
-        constexpr size_t lds = 2 * (256 * 128 + BN_ * 128) + 2 * BN_ * sizeof(float); \
-        auto kern = gemm_nn_xl_kernel<BN_, CAT_>; \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-            (void)hipGetLastError(); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a); } while (0)
-    // (the K-concat variant is its own instantiation: its second base pointer and the bias vector cost the 256-column plain kernel,
-    // already at 248 VGPRs, 24 bytes of scratch)
-    if (a.A2) { if (wide) XL_LAUNCH(256, true); else XL_LAUNCH(128, true); }
-    else { if (wide) XL_LAUNCH(256, false); else XL_LAUNCH(128, false); }
-#undef XL_LAUNCH
+    if (wide) {
+        constexpr size_t lds = 2 * (256 * 128 + 256 * 128) + 2 * 256 * sizeof(float);
+        auto kern = gemm_nn_xl_kernel<256>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            (void)hipGetLastError();
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a);
+    } else {
+        constexpr size_t lds = 2 * (256 * 128 + 128 * 128) + 2 * 128 * sizeof(float);
+        auto kern = gemm_nn_xl_kernel<128>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            (void)hipGetLastError();
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a);
+    }
     DWN_CHECK_LAUNCH();
     return 0;
 }

@@ -79,33 +79,6 @@ def test_gemm_nn_xl_kernel(L, M, N, K, groups, bn):
     assert rel(s0, cf.sum(0)) < 1e-4 and rel(s1, (cf * cf).sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("variant", ["xl128", "xl256", "tile128", "auto"])
-@pytest.mark.parametrize("M,N,K1,K2", [(5000, 128, 896, 128), (3000, 256, 1792, 256), (777, 64, 448, 64), (8448, 128, 1024, 72)])
-def test_gemm_nn_kconcat_on_both_kernels(L, M, N, K1, K2, variant):
-    """DWN_EPI_STORE_CAT ([a | a2] . B^T + bias: the conv_pw data gradient) through the 256-row LDS-DMA kernel (both tile widths)
-    and through the 128-row kernel: the same product, ragged M, a second operand narrower than a k-tile."""
-    torch.manual_seed(M + N)
-    dtype = torch.bfloat16
-    K = K1 + K2
-    a = torch.randn(M, K1, device=dev()).to(dtype)
-    a2 = torch.randn(M, K2, device=dev()).to(dtype)
-    b = (torch.randn(N, K, device=dev()) / K ** 0.5).to(dtype)
-    bias = torch.randn(N, device=dev())
-    c = torch.full((M, N), float("nan"), dtype=dtype, device=dev())
-    g = L.GemmNNArgs()
-    g.a = load_desc(L, a, K1)
-    g.a_kind = L.LD_PLAIN
-    g.b = b.data_ptr(); g.ldb = K; g.c = c.data_ptr(); g.ldc = N
-    g.M, g.N, g.K, g.groups = M, N, K, 1
-    g.epi = L.EPI_STORE_CAT; g.a2 = a2.data_ptr(); g.a2_ld = K2; g.K1 = K1; g.bias = bias.data_ptr()
-    g.variant = {"xl128": L.NN_XL128, "xl256": L.NN_XL256, "tile128": L.NN_TILE128, "auto": L.NN_AUTO}[variant]
-    L.check(L.lib.dwn_gemm_nn(C.byref(g), _dt(L, dtype), 0, stream()), "gemm_nn")
-    torch.cuda.synchronize()
-    ref = torch.cat([a, a2], 1).double() @ b.double().t() + bias.double()
-    assert not torch.isnan(c.float()).any()
-    assert rel(c, ref) < 6e-3
-
-
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_nn_exact_small_integers(L, dtype):
     """A = I-like / asymmetric B with small integers: exact in both dtypes, catches any transposed tile map."""
