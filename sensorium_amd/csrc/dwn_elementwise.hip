@@ -2103,7 +2103,7 @@ int k_prep(const PrepArgs& pa, int dtype, hipStream_t s) {
 // gacc[C][C] / r3[C] with fp32 atomics (zeroed by the caller's prep launch); a second launch converts G into Bp.  Was five dependent tiny launches on the dws_bwd -> pw_dgrad critical path.
 template <typename T>
 __global__ __launch_bounds__(256) void pw_bwd_prep_kernel(const float* w1, const float* abc, int E, int C, T* bp, float* gacc,
-                                                          float* r3, int nscale, int gx, int gy) {
+                                                          float* r3, int nscale, int gx, int gy, int gr) {
     const i64 ld = (i64)E + C;
     int bid = blockIdx.x;
     __shared__ float sA[64][64 + 4], sB[64][64 + 4];
@@ -2127,14 +2127,15 @@ __global__ __launch_bounds__(256) void pw_bwd_prep_kernel(const float* w1, const
         return;
     }
     bid -= nscale;
+    const int GR = gr;                            // rows of E per Gram workgroup (<= 64)
     // Gram part: a 64 x 64 tile of G over a 64-row chunk of E, operands staged through LDS (the first version read both W1
     // columns straight from global memory: 0.9 GB of L1 traffic for 117 MFLOP at C = 256, 63 us)
     // sA[e][c'] = A2[e]*W1[e][c'], sB[e][c] = W1[e][c]
     const int bx = bid % gx, by = (bid / gx) % gy, bz = bid / (gx * gy);
-    const int e0 = bz * 64;
+    const int e0 = bz * GR;
     const float* A2 = abc + E;
     const float* A3 = abc + 2 * E;
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    for (int i = threadIdx.x; i < GR * 64; i += 256) {
         const int el = i >> 6, cl = i & 63;
         const int e = e0 + el;
         const int cpg = bx * 64 + cl, cg = by * 64 + cl;
@@ -2153,7 +2154,7 @@ __global__ __launch_bounds__(256) void pw_bwd_prep_kernel(const float* w1, const
     }
     const bool do_r3 = bx == 0 && ty == 0;
 #pragma unroll 8
-    for (int el = 0; el < 64; ++el) {             // ascending e with fmaf: the partial sums of the first version, bit for bit
+    for (int el = 0; el < GR; ++el) {             // ascending e with fmaf
         const float4 a4 = *reinterpret_cast<const float4*>(&sA[el][ty * 4]);
         const float4 b4 = *reinterpret_cast<const float4*>(&sB[el][tx * 4]);
         const float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
@@ -2210,11 +2211,14 @@ __global__ __launch_bounds__(256) void pw_bwd_gram_store_kernel(const float* gac
 int k_pw_bwd_prep(const float* w1, const float* abc, int E, int C, void* bp, float* gacc, float* r3, int dtype,
                   const float* res_abc, int res_C, hipStream_t s) {
     const int nscale = ((E + 63) / 64) * ((C + 63) / 64);
-    const int gx = (C + 63) / 64, gy = (C + 63) / 64, gz = (E + 63) / 64;
+    // rows of E per Gram workgroup: 32 with one 64 x 64 tile of G (C = 64: 14 -> 9 us, more workgroups on a latency chain), 64 with
+    // more (at C = 256 halving it doubles the atomic adders per element of G: 39 -> 62 us; four chunks per workgroup: 54 us)
+    const int gr = C <= 64 ? 32 : 64;
+    const int gx = (C + 63) / 64, gy = (C + 63) / 64, gz = (E + gr - 1) / gr;
     const int ngram = gx * gy * gz;
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL((pw_bwd_prep_kernel<bf16_t>), dim3(nscale + ngram), dim3(256), 0, s, w1, abc, E, C, (bf16_t*)bp, gacc, r3, nscale, gx, gy),
-        hipLaunchKernelGGL((pw_bwd_prep_kernel<float>), dim3(nscale + ngram), dim3(256), 0, s, w1, abc, E, C, (float*)bp, gacc, r3, nscale, gx, gy));
+        hipLaunchKernelGGL((pw_bwd_prep_kernel<bf16_t>), dim3(nscale + ngram), dim3(256), 0, s, w1, abc, E, C, (bf16_t*)bp, gacc, r3, nscale, gx, gy, gr),
+        hipLaunchKernelGGL((pw_bwd_prep_kernel<float>), dim3(nscale + ngram), dim3(256), 0, s, w1, abc, E, C, (float*)bp, gacc, r3, nscale, gx, gy, gr));
     DWN_CHECK_LAUNCH();
     dim3 g3((unsigned)(((i64)C * C + 255) / 256));
     DISPATCH_T(dtype,
