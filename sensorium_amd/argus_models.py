@@ -111,6 +111,8 @@ class MouseModel(Model):
         any time: an optimizer that already exists keeps its Adam moments and step counts and is re-bound to the new EMA
         copies (or detached when ``ema`` is None)."""
         self._model_ema = ema
+        if ema is not None and hasattr(ema.ema, "set_fp32_eval_products"):        # the copy follows the trained module's mode
+            ema.ema.set_fp32_eval_products(getattr(self.nn_module, "fp32_eval_products", "bf16x3"))
         if self.optimizer is not None:
             self._bind_ema_to_optimizer()
 
@@ -129,6 +131,13 @@ class MouseModel(Model):
         """train.py:53; the parameter EMA rides in the optimizer kernel (bound now if the optimizer exists, else when it
         is built)."""
         self.model_ema = ModelEma(self.nn_module, decay=decay)
+
+    def set_fp32_eval_products(self, mode: str = "bf16x3"):
+        """DwiseNeuro.set_fp32_eval_products on BOTH networks val_step / predict may evaluate: the trained module and the EMA
+        copy (a deepcopy taken when the EMA was set: a mode set on ``nn_module`` afterwards would not reach it)."""
+        self.nn_module.set_fp32_eval_products(mode)
+        if self._model_ema is not None:
+            self._model_ema.ema.set_fp32_eval_products(mode)
 
     def get_optimizer(self):
         self._ensure_optimizer()
@@ -192,6 +201,8 @@ class MouseModel(Model):
         host = weights if not weights.is_cuda else getattr(weights, "_dwn_host", None)
         if host is None or host.shape != weights.shape:
             return None
+        if weights.is_cuda and getattr(weights, "_dwn_host_version", weights._version) != weights._version:
+            return None        # the device weights were edited in place after the host copy was attached: dense backward
         key = (id(host), host._version, str(self.device))
         cached = getattr(self, "_active_cache", None)
         if cached is not None and cached[0] == key:
@@ -258,7 +269,11 @@ class MouseModel(Model):
         """Sharded optimizer: True while this rank's copy of the parameters / EMA network is incomplete, i.e. until EVERY
         rank has called ``sync_for_read()`` after the last training step."""
         b = self.buckets
-        return b is not None and b.shard and (b.ema_dirty or bool(b._param_handles))
+        if b is None or not b.shard:
+            return False
+        # the EMA slices only matter while an EMA network exists (gather_params marks them dirty after every step, and only
+        # gather_ema / adopt_ema clear the mark: without an EMA nothing ever would)
+        return bool(b._param_handles) or (self._model_ema is not None and b.ema_dirty)
 
     def _eval_module(self):
         self.sync_for_read()

@@ -155,6 +155,13 @@ class Checkpoint(Callback):
 
     def start(self, state: State):
         self.epochs_since_last_save = 0
+        # refused HERE, on every rank and before training: Model.save would raise on the writer rank only, from inside
+        # epoch_complete, and the other ranks would block in their next collective until the process group times out
+        b = getattr(state.model, "buckets", None)
+        shard = bool(getattr(state.model, "params", {}).get("ddp_shard_optimizer", False)) or (b is not None and b.shard)
+        if self.optimizer_state and shard:
+            raise RuntimeError("Checkpoint(optimizer_state=True) cannot be combined with the sharded optimizer: a rank holds only "
+                               "1/N of the readout moments")
 
     def epoch_complete(self, state: State):
         self.epochs_since_last_save += 1

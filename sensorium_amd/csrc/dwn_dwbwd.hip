@@ -163,6 +163,24 @@ __device__ __forceinline__ void wk_lds_barrier() {
 #endif
 }
 
+
+// workgroup -> (plane-group start, channel slice).  XCD-aware form: the slices of one plane group are consecutive workgroups of ONE
+// XCD (workgroups are dealt round-robin over the 8 XCDs), so what they all read (the block input a0, when y1 is rebuilt) is
+// fetched into that XCD's L2 once.  Needs gridDim.x % 8 == 0 (the launchers round it).
+struct WkBlk { int x, y; };
+__device__ __forceinline__ WkBlk wk_block() {
+#ifdef EXP_XCD_MAP
+    const int gx = (int)gridDim.x, ns = (int)gridDim.y;
+    const int b = (int)blockIdx.y * gx + (int)blockIdx.x;
+    const int xcd = b & 7, i = b >> 3;
+    WkBlk r; r.y = i % ns; r.x = (i / ns) * 8 + xcd;
+    return r;
+#else
+    WkBlk r; r.x = (int)blockIdx.x; r.y = (int)blockIdx.y;
+    return r;
+#endif
+}
+
 template <int LPW, int RB>
 __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1c_kernel(const DwSpatialBwd a) {
     typedef bf16_t T;
@@ -177,7 +195,8 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1c_kernel(const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cv = tid & 15, pl = tid >> 4;
     const int grp = pl / LPW, jj = pl % LPW;
-    const int c0 = blockIdx.y * CS;
+    const WkBlk blk = wk_block();
+    const int c0 = blk.y * CS;
     const int chan = c0 + cv * 4;
     const bool chan_ok = chan < a.C;
     const int chs = chan_ok ? chan : 0;
@@ -218,7 +237,11 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1c_kernel(const 
     const int dq = (dslot & 4) | ((dslot & 1) << 1) | ((dslot >> 1) & 1);     // pixel of the block that lives in slot dslot
     const int dp = wave * 8 + dq;                                              // pixel of the 32-pixel group row
     const int dgrp = dp / W, dx = dp % W;
+#ifdef EXP_SHARED_Y1
+    const int dce = c16 * 8;                                                   // experiment: every slice reads the same 64 channels
+#else
     const int dce = (c0 + c16 * 8 < a.C) ? c0 + c16 * 8 : c0;                   // channel tail: any valid address (never read back)
+#endif
     const unsigned lds_y1 = (unsigned)(size_t)wk_smem + RING_BYTES + (unsigned)wave * 1024u;
     // ... and where this thread finds its two pixels (2jj, 2jj+1) of a row in that block: slots s0 and s0 + 2
     const int jq = pl & 3;
@@ -229,7 +252,7 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1c_kernel(const 
     const unsigned lodelta = jj > 0 ? (unsigned)a.dy.ld : 0u;          // jj == 0: the low pixel is the halo (masked)
     const unsigned collast = (unsigned)(W - 1) * (unsigned)a.dy.ld;
 
-    for (int pg = blockIdx.x; pg < ngroups; pg += gridDim.x) {
+    for (int pg = blk.x; pg < ngroups; pg += gridDim.x) {
         const int plane = pg * NG + grp;
         const bool pvalid = plane < a.planes && chan_ok;
         const int psafe = plane < a.planes ? plane : 0;
@@ -437,7 +460,7 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1c_kernel(const 
         DET_ENTER();
         if (tid < 2 * CS) {
             const int which = tid / CS, c = c0 + tid % CS;
-            if (c < a.C) stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.C, which, c, lstat[tid]);
+            if (c < a.C) stat_add(a.stats, (int)(blk.x % DWN_NREP), a.C, which, c, lstat[tid]);
         }
     }
     DET_EXIT();
@@ -463,7 +486,8 @@ __global__ __launch_bounds__(256, WK_MINW2) void dw_spatial_bwd_s2_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63;
     const int cv = tid & 15, pl = tid >> 4;
     const int grp = pl / LPW, jj = pl % LPW;
-    const int c0 = blockIdx.y * CS;
+    const WkBlk blk = wk_block();
+    const int c0 = blk.y * CS;
     const int chan = c0 + cv * 4;
     const bool chan_ok = chan < a.C;
     const int chs = chan_ok ? chan : 0;
@@ -498,7 +522,7 @@ __global__ __launch_bounds__(256, WK_MINW2) void dw_spatial_bwd_s2_kernel(const 
     const unsigned* tcol = tile + (grp * rows_qmax * Wqp + jj) * CS + cv * 4;
     const unsigned y1row = (unsigned)Win * (unsigned)a.y1.ld, dhrow = (unsigned)Win * (unsigned)a.C;
 
-    for (int tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+    for (int tile_id = blk.x; tile_id < ntiles; tile_id += gridDim.x) {
         const int pg = tile_id / nbands, band = tile_id - pg * nbands;
         const int plane = pg * NG + grp;
         const bool pvalid = plane < a.planes && chan_ok;
@@ -511,7 +535,11 @@ __global__ __launch_bounds__(256, WK_MINW2) void dw_spatial_bwd_s2_kernel(const 
         __syncthreads();
         if (pvalid) {
             const i64 prow = (i64)plane * Hin * Win;
+#ifdef EXP_SHARED_Y1
+            const T* y10 = y1p + prow * a.y1.ld + cv * 4 + (unsigned)(hi0 * Win + 4 * jj) * (unsigned)a.y1.ld;
+#else
             const T* y10 = y1p + prow * a.y1.ld + chs + (unsigned)(hi0 * Win + 4 * jj) * (unsigned)a.y1.ld;
+#endif
             T* dh0 = dhp + prow * a.C + chan + (unsigned)(hi0 * Win + 4 * jj) * (unsigned)a.C;
             uint4 gA[2], gB[2];                          // gradient rows in use: pairs jj, jj+1
             gA[0] = *reinterpret_cast<const uint4*>(tcol); gA[1] = *reinterpret_cast<const uint4*>(tcol + CS);
@@ -654,7 +682,7 @@ __global__ __launch_bounds__(256, WK_MINW2) void dw_spatial_bwd_s2_kernel(const 
         DET_ENTER();
         if (tid < 2 * CS) {
             const int which = tid / CS, c = c0 + tid % CS;
-            if (c < a.C) stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.C, which, c, lstat[tid]);
+            if (c < a.C) stat_add(a.stats, (int)(blk.x % DWN_NREP), a.C, which, c, lstat[tid]);
         }
     }
     DET_EXIT();
@@ -712,6 +740,9 @@ static int launch_s2(const DwSpatialBwd& a, hipStream_t s) {
     i64 gx = (256 * bpc) / slices;
     if (gx < 1) gx = 1;
     if (gx > work) gx = work;
+#ifdef EXP_XCD_MAP
+    if (gx >= 8) gx &= ~(i64)7;
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, slices), dim3(256), lds, s, a, R, rows_qmax);
     DWN_CHECK_LAUNCH();
     return 0;
@@ -731,6 +762,9 @@ static int launch_s1c(const DwSpatialBwd& a, hipStream_t s) {
     i64 gx = (256 * bpc) / slices;
     if (gx < 1) gx = 1;
     if (gx > work) gx = work;
+#ifdef EXP_XCD_MAP
+    if (gx >= 8) gx &= ~(i64)7;
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, slices), dim3(256), lds, s, a);
     DWN_CHECK_LAUNCH();
     return 0;

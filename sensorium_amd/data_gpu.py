@@ -303,6 +303,7 @@ class BatchAssembler:
             host = torch.zeros(B, len(self.num_neurons), dtype=torch.float32)
             host[torch.arange(B), torch.tensor([p.mouse for p in picks])] = 1.0
             weights._dwn_host = host
+            weights._dwn_host_version = weights._version      # an in-place edit afterwards invalidates the host copy
             return x, (targets, weights)
         return x
 

@@ -32,5 +32,6 @@ def make_batch(batch: int, frames: int, height: int, width: int, readout_outputs
     if device is not None:
         host = wt
         xt, tt, wt = xt.to(device), [t.to(device) for t in tt], wt.to(device)
+        wt._dwn_host_version = wt._version   # (an in-place edit of wt afterwards invalidates the host copy)
         wt._dwn_host = host           # the host knows which mouse every sample belongs to: MouseModel.train_step uses it (no read-back)
     return xt, (tt, wt)

@@ -500,3 +500,49 @@ def test_checkpoint_with_sharded_optimizer_world2(tmp_path):
     for p in procs:
         assert p.exitcode == 0, "a rank failed or hung"
     assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+# ---- round-4 advisor findings: needs_sync() without an EMA; Checkpoint(optimizer_state=True) + sharded optimizer -----------
+def test_needs_sync_without_ema_clears_after_param_gather():
+    """Sharded optimizer and NO EMA network (the plain ``Checkpoint`` path of scripts/train.py:54-56): ``gather_params`` marks
+    the EMA slices dirty after every step and only an EMA gather clears the mark, so ``needs_sync`` must not look at it."""
+    from sensorium_amd.argus_models import MouseModel
+
+    class B:
+        shard = True
+        ema_dirty = True
+        _param_handles = []
+
+    m = object.__new__(MouseModel)
+    m.buckets, m._model_ema = B(), None
+    assert not MouseModel.needs_sync(m)                  # parameters gathered, no EMA: complete
+    m.buckets._param_handles = [object()]
+    assert MouseModel.needs_sync(m)                      # an all-gather of parameters is still in flight
+    m.buckets._param_handles = []
+    m._model_ema = object()
+    assert MouseModel.needs_sync(m)                      # with an EMA the dirty mark counts
+    m.buckets.ema_dirty = False
+    assert not MouseModel.needs_sync(m)
+    m.buckets = None
+    assert not MouseModel.needs_sync(m)
+
+
+def test_checkpoint_with_optimizer_state_is_refused_up_front_under_the_sharded_optimizer():
+    import pytest
+    from sensorium_amd.callbacks import Checkpoint
+    from sensorium_amd.engine import State
+
+    class Buckets:
+        shard = True
+
+    class M:
+        params = {}
+        buckets = Buckets()
+
+    st = State()
+    st.model = M()
+    with pytest.raises(RuntimeError, match="sharded optimizer"):
+        Checkpoint("/tmp/x", optimizer_state=True).start(st)
+    Checkpoint("/tmp/x", optimizer_state=False).start(st)        # fine
+    M.buckets = None
+    Checkpoint("/tmp/x", optimizer_state=True).start(st)         # not sharded: fine
