@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DWN_ABI_VERSION 5
+#define DWN_ABI_VERSION 6
 #define DWN_F32 0
 #define DWN_BF16 1
 /* How the dtype-f32 GEMMs of a block / cortex layer / readout multiply.  NATIVE: v_mfma_f32_16x16x4_f32.  SPLIT3: each operand
@@ -164,6 +164,11 @@ typedef struct dwn_dw_spatial_bwd_args {
     double* stats;
     int rows_band;
     int impl;           /* as in dwn_dw_spatial_fwd_args */
+    /* rebuilt-y1 mode (a0 != NULL; dwn_dw_spatial_bwd_rc_supported): y1.p is NOT read — the kernel rebuilds the y1 rows it needs as
+     * a0 . w1^T on the matrix cores, rounded to bf16 as conv_pw's stored output reads back (dwiseneuro.py:90-91), from the block
+     * input a0 [rows][a0_ld] (Cin channels, the positional encoding included) and w1 = conv_pw's weight [C][Cin] rounded to
+     * bf16, row-major.  y1.v1..v4 (BatchNorm-1 coefficients) as usual. */
+    const void* a0; long long a0_ld; const void* w1; int Cin;
 } dwn_dw_spatial_bwd_args;
 
 /* depth-wise (k,1,1) conv along T, pad k/2 — dwiseneuro.py:105-109 */
@@ -247,6 +252,11 @@ typedef struct dwn_block_args {
      * (the parity tests run both implementations against the oracle) */
     int pwl_bwd;
     int f32_products;                        /* DWN_F32_AUTO / _NATIVE / _SPLIT3: how dtype f32 multiplies (see below) */
+    /* training, bf16: 0 = the library leaves y1 (conv_pw's output, the widest tensor of the block) unmaterialised where both
+     * stencils can rebuild it from the block input on the matrix cores (BatchNorm-1 statistics from the Gram matrix of the
+     * input): y1 may then be NULL in forward and backward (dwn_block_forward_writes bit 0 clear); 1 = always materialise y1.
+     * Forward and backward of one block must be called with the same value. */
+    int y1_mode;
 } dwn_block_args;
 
 /* AdaptiveAvgPool3d((None,1,1)) — dwiseneuro.py:374,400 */
@@ -348,6 +358,8 @@ int dwn_gemm_nn(const dwn_gemm_nn_args* a, int dtype, int device, void* stream);
 int dwn_gemm_tn(const dwn_gemm_tn_args* a, int dtype, int device, void* stream);
 int dwn_dw_spatial_fwd(const dwn_dw_spatial_fwd_args* a, int dtype, int device, void* stream);
 int dwn_dw_spatial_bwd(const dwn_dw_spatial_bwd_args* a, int dtype, int device, void* stream);
+/* 1 when dwn_dw_spatial_bwd can run these arguments in rebuilt-y1 mode (bf16, Cin 64, C % 64 == 0, the row-walk plane widths) */
+int dwn_dw_spatial_bwd_rc_supported(const dwn_dw_spatial_bwd_args* a, int dtype);
 int dwn_dw_temporal_fwd(const dwn_dw_temporal_fwd_args* a, int dtype, int device, void* stream);
 int dwn_dw_temporal_bwd(const dwn_dw_temporal_bwd_args* a, int dtype, int device, void* stream);
 int dwn_bn_finalize(const double* stats, int stat_c, double count, const dwn_bn* bn, int C, int training,
@@ -356,6 +368,16 @@ int dwn_bn_bwd_finalize(const double* stats, double count, const dwn_bn* bn, flo
                         void* stream);
 int dwn_pack_weight(const float* src, void* dst, int groups, int R, int C, int transpose, int Rd, int Cd,
                     int dtype, int device, void* stream);
+/* BatchNorm-1 (conv_pw.1.bn, dwiseneuro.py:91-92) in training mode WITHOUT conv_pw's output: y1 = a0 . W1^T is linear in the block
+ * input a0 [M][a0_ld] (Cin channels), so its batch mean / variance follow from the Gram matrix a0^T a0 and the column sums 1^T a0
+ * (one Cin-wide pass): mean_e = w_e . mu, var_e = w_e^T (G / M - mu mu^T) w_e, with w_pw [E][Cin] rounded to `dtype` first (the
+ * weights the matrix cores multiply with).  Writes bn->coef [4][E] = scale, shift, mean, invstd and updates the running statistics
+ * and num_batches_tracked like nn.BatchNorm3d.  sc_stats (optional, double[DWN_NREP][2][Cin], zeroed by the caller): receives the
+ * shortcut BatchNorm's sums of an identity-map block (sum a0, sum a0^2 per channel) in replica 0.  ws: caller-owned scratch. */
+size_t dwn_conv_pw_bn_stats_workspace_bytes(int Cin);
+int dwn_conv_pw_bn_stats(const void* a0, long long a0_ld, long long M, const float* w_pw, int E, int Cin, const dwn_bn* bn,
+                         float momentum, float eps, double* sc_stats, void* ws, size_t ws_bytes, int dtype, int device,
+                         void* stream);
 
 /* composites (forward / backward of one reference module each) */
 size_t dwn_stem_workspace_bytes(const dwn_stem_args* a);

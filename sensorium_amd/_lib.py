@@ -74,7 +74,8 @@ class DwSpatialFwdArgs(C.Structure):
 class DwSpatialBwdArgs(C.Structure):
     _fields_ = [("dy", LoadDesc), ("y1", LoadDesc), ("w", c_p), ("dh1", c_p), ("dw", c_p), ("planes", c_i),
                 ("Hin", c_i), ("Win", c_i), ("Hout", c_i), ("Wout", c_i), ("C", c_i), ("stride", c_i),
-                ("ks", c_i), ("stats", c_p), ("rows_band", c_i), ("impl", c_i)]
+                ("ks", c_i), ("stats", c_p), ("rows_band", c_i), ("impl", c_i),
+                ("a0", c_p), ("a0_ld", c_ll), ("w1", c_p), ("Cin", c_i)]      # rebuilt-y1 mode (include/dwn.h)
 
 
 class DwTemporalFwdArgs(C.Structure):
@@ -117,7 +118,7 @@ class BlockArgs(C.Structure):
                 ("dout", c_p), ("dx", c_p), ("buf_a", c_p), ("buf_b", c_p), ("dy4", c_p), ("da0", c_p),
                 ("dw_pw", c_p), ("dw_dws", c_p), ("dw_dwt", c_p), ("dw_pwl", c_p), ("dse_wr", c_p),
                 ("dse_br", c_p), ("dse_we", c_p), ("dse_be", c_p),
-                ("ws", c_p), ("ws_bytes", c_sz), ("pwl_bwd", c_i), ("f32_products", c_i)]
+                ("ws", c_p), ("ws_bytes", c_sz), ("pwl_bwd", c_i), ("f32_products", c_i), ("y1_mode", c_i)]
 
 
 class PoolArgs(C.Structure):
@@ -193,6 +194,7 @@ SYMBOLS = {
     "dwn_gemm_tn": (c_i, [_P(GemmTNArgs), c_i, c_i, c_p]),
     "dwn_dw_spatial_fwd": (c_i, [_P(DwSpatialFwdArgs), c_i, c_i, c_p]),
     "dwn_dw_spatial_bwd": (c_i, [_P(DwSpatialBwdArgs), c_i, c_i, c_p]),
+    "dwn_dw_spatial_bwd_rc_supported": (c_i, [_P(DwSpatialBwdArgs), c_i]),
     "dwn_dw_temporal_fwd": (c_i, [_P(DwTemporalFwdArgs), c_i, c_i, c_p]),
     "dwn_dw_temporal_bwd": (c_i, [_P(DwTemporalBwdArgs), c_i, c_i, c_p]),
     "dwn_bn_finalize": (c_i, [c_p, c_i, c_d, _P(BN), c_i, c_i, c_f, c_f, c_i, c_p]),
@@ -219,6 +221,8 @@ SYMBOLS = {
     "dwn_f64_to_f32": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "dwn_adamw_ema_multi": (c_i, [c_p, c_i, c_i, c_d, c_d, c_d, c_d, c_d, c_ll, c_d, c_d, c_i, c_p]),
     "dwn_ema_lerp_multi": (c_i, [c_p, c_i, c_i, c_d, c_i, c_p]),
+    "dwn_conv_pw_bn_stats_workspace_bytes": (c_sz, [c_i]),
+    "dwn_conv_pw_bn_stats": (c_i, [c_p, c_ll, c_ll, c_p, c_i, c_i, _P(BN), c_f, c_f, c_p, c_p, c_sz, c_i, c_i, c_p]),
     "dwn_pw_bwd_fused_supported": (c_i, [c_i, c_ll, c_i, c_i]),
     "dwn_pw_backward_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "dwn_pw_backward": (c_i, [_P(PwBwdArgs), c_i, c_i, c_p]),
@@ -258,7 +262,7 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.dwn_abi_version() != 5:
+    if lib.dwn_abi_version() != 6:
         raise ImportError("libdwiseneuro_hip.so ABI version mismatch")
     built, have = lib.dwn_source_hash().decode(), source_hash()
     if built != have and not os.environ.get("DWN_LIB_PATH"):        # (an explicitly chosen other build is an A/B run)

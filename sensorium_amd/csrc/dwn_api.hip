@@ -15,6 +15,7 @@ extern "C" int dwn_dw_spatial_rc_supported(int dtype, int Cin, int E, int ks, in
 extern "C" int dwn_dw_spatial_rc_prep(const float* w_pw, const float* w_dws, const float* bn1_coef, int E, int Cin, void* blob,
                                       int device, void* stream);
 extern "C" int dwn_dw_spatial_fwd_rc(const dwn_dw_spatial_rc_fwd_args* a, int device, void* stream);
+bool dw_spatial_bwd_rc_supported(const DwSpatialBwd& a, int dtype);          // dwn_dwbwd.hip
 
 int dwn_set_error(int code, const char* msg) {
     snprintf(g_err, sizeof(g_err), "dwn error %d: %s", code, msg ? msg : "");
@@ -170,7 +171,8 @@ struct BlockWs {
     void* bp; float* r3; float* gacc;                      // conv_pw data-gradient folding (see dwn_elementwise.hip)
     float* tacc;                                           // conv_pw weight gradient: raw products T1 / Ga / s (k_pw_wgrad_fold)
     void* wgated;                                          // [B][Cout][Cmid] W2 . diag(gate_b) (forward only)
-    void* rcblob;                                          // eval forward: slice images of the y1-recomputing stencil
+    void* rcblob;                                          // forward: slice images of the y1-recomputing stencil
+    float* gram;                                           // y1-free training forward: [(Cin + 8)][Cin] raw products a0^T a0, 1^T a0
     float* pb;                                             // [B][Cout][Cmid] per-sample dy4^T z3 (backward, see pwl_bwd_per_sample)
     char* zero_beg; char* zero_end;
     size_t bytes;
@@ -195,9 +197,24 @@ static bool pwl_bwd_per_sample(const dwn_block_args& a) {
     const double pass = (double)a.B * a.T * a.Hout * a.Wout * a.Cmid * tsize(a.dtype);
     return pb <= pass;
 }
-// eval-mode forward without conv_pw as its own pass (DWN_RC_OFF=1 disables it)
+// Training WITHOUT a materialised y1 (round 5; dwn_block_args.y1_mode).  y1 = a0 . W1^T is the widest tensor of a block and a
+// Cin-deep product of one seven times narrower: the forward stencil rebuilds its tiles on the matrix cores (dwn_dwrc.hip) with
+// BatchNorm-1's batch statistics taken from the Gram matrix of a0 (k_bn1_gram_finalize), the backward stencil rebuilds the rows it
+// needs the same way (dwn_dwbwd.hip, CIN > 0), and conv_pw's backward has not read y1 since round 4 — so y1 is neither written nor
+// read: three E-wide passes over M_in rows less per block.  Both directions decide with this one predicate.
+static bool block_y1_free(const dwn_block_args& a) {
+    if (!a.training || a.dtype != DWN_BF16 || a.y1_mode == 1) return false;
+    if (!dwn_dw_spatial_rc_supported(a.dtype, a.Cin, a.Cmid, a.ks, a.stride, a.Hin, a.Win)) return false;
+    DwSpatialBwd d; memset(&d, 0, sizeof(d));
+    d.planes = a.B * a.T; d.Hin = a.Hin; d.Win = a.Win; d.Hout = a.Hout; d.Wout = a.Wout; d.C = a.Cmid; d.stride = a.stride; d.ks = a.ks;
+    d.dy.ld = a.Cmid; d.y1.ld = a.Cmid; d.a0_ld = a.Cin; d.Cin = a.Cin;
+    if (!dw_spatial_bwd_rc_supported(d, a.dtype)) return false;
+    return true;
+}
+// forward without conv_pw as its own pass: eval mode (BatchNorm-1 is known), or y1-free training
 static bool block_fwd_rc(const dwn_block_args& a) {
-    return !a.training && dwn_dw_spatial_rc_supported(a.dtype, a.Cin, a.Cmid, a.ks, a.stride, a.Hin, a.Win) != 0;
+    if (a.training) return block_y1_free(a);
+    return dwn_dw_spatial_rc_supported(a.dtype, a.Cin, a.Cmid, a.ks, a.stride, a.Hin, a.Win) != 0;
 }
 // floats of the conv_pw data-gradient folding scratch: G accumulator [Cin][Cin] and r3 [Cin]
 static size_t pw_fold_floats(int Cin) { return (size_t)Cin * Cin + Cin; }
@@ -219,6 +236,7 @@ BlockWs carve_block(const dwn_block_args& a, int backward, void* base, size_t ca
     w.st4 = c.take<double>(nstat(a.Cout));
     w.stsc = c.take<double>(nstat(backward ? a.Cout : a.Cin));
     w.pooled = c.take<long long>((size_t)a.B * a.Cmid);
+    if (!backward && block_y1_free(a)) w.gram = c.take<float>((size_t)(a.Cin + 8) * a.Cin);
     size_t z1 = c.off;
     if (backward) {
         w.abc1 = c.take<float>(3 * (size_t)a.Cmid);
@@ -323,6 +341,7 @@ int dwn_dw_spatial_bwd(const dwn_dw_spatial_bwd_args* a, int dtype, int device, 
     ENTER(device);
     return launch_dw_spatial_bwd(*a, dtype, (hipStream_t)stream);
 }
+int dwn_dw_spatial_bwd_rc_supported(const dwn_dw_spatial_bwd_args* a, int dtype) { return dw_spatial_bwd_rc_supported(*a, dtype) ? 1 : 0; }
 int dwn_dw_temporal_fwd(const dwn_dw_temporal_fwd_args* a, int dtype, int device, void* stream) {
     ENTER(device);
     return launch_dw_temporal_fwd(*a, dtype, (hipStream_t)stream);
@@ -340,6 +359,24 @@ int dwn_bn_bwd_finalize(const double* stats, double count, const dwn_bn* bn, flo
                         void* stream) {
     ENTER(device);
     return k_bn_bwd_finalize(stats, count, bn->coef, bn->dgamma, bn->dbeta, abc, C, (hipStream_t)stream);
+}
+// BatchNorm-1 of conv_pw WITHOUT conv_pw's output (dwn.h): raw products [a0 | 1]^T a0 by one gemm_tn pass, then k_bn1_gram_finalize
+size_t dwn_conv_pw_bn_stats_workspace_bytes(int Cin) { return (size_t)(Cin + 8) * Cin * sizeof(float) + 256; }
+int dwn_conv_pw_bn_stats(const void* a0, long long a0_ld, long long M, const float* w_pw, int E, int Cin, const dwn_bn* bn,
+                         float momentum, float eps, double* sc_stats, void* ws, size_t ws_bytes, int dtype, int device, void* stream) {
+    ENTER(device);
+    hipStream_t s = (hipStream_t)stream;
+    if (!a0 || !w_pw || !bn || !bn->coef || !ws) return dwn_set_error(-1, "conv_pw_bn_stats: null pointer");
+    if (Cin % 8 || E <= 0 || M <= 0 || M >= (1ll << 31)) return dwn_set_error(-2, "conv_pw_bn_stats: Cin % 8 == 0, 0 < M < 2^31");
+    if (ws_bytes < dwn_conv_pw_bn_stats_workspace_bytes(Cin)) return dwn_set_error(-6, "conv_pw_bn_stats: workspace too small");
+    float* gram = reinterpret_cast<float*>(((size_t)ws + 255) & ~(size_t)255);
+    TRY(k_zero(gram, (size_t)(Cin + 8) * Cin * sizeof(float), s));
+    LoadDesc cat = ld_plain(a0, a0_ld);
+    cat.cat_c1 = Cin; cat.cat_c2 = 0;
+    GemmTN g = tn_base(cat, LD_CAT1, ld_plain(a0, a0_ld), LD_PLAIN, (int)M, Cin + 8, Cin, gram, Cin, 1);
+    TRY(launch_gemm_tn(g, dtype, s));
+    return k_bn1_gram_finalize(gram, w_pw, E, Cin, (double)M, bn->gamma, bn->beta, bn->running_mean, bn->running_var,
+                               bn->num_batches_tracked, momentum, eps, bn->coef, sc_stats, dtype, s);
 }
 int dwn_pack_weight(const float* src, void* dst, int groups, int R, int C, int transpose, int Rd, int Cd, int dtype,
                     int device, void* stream) {
@@ -430,13 +467,25 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     }
     // conv_pw (dwiseneuro.py:90-93): y1 = a0 @ W1^T, Σ/Σ² for bn1
     LoadDesc xin = ld_plain(a0, a.Cin);
+    const bool identity_sc = a.stride == 1 && a.Hin == a.Hout && a.Win == a.Wout;
+    const bool y1_free = tr && block_y1_free(a);
     if (block_fwd_rc(a)) {
         // eval: BatchNorm-1 needs no batch statistics and nobody reads y1 again, so the stencil kernel rebuilds its y1
         // tiles from a0 (MFMA) and conv_pw disappears as a pass (a.y1 is not written)
+        // y1-free training: the same, with BatchNorm-1's batch statistics from the Gram matrix of a0 (one C-wide pass)
+        if (y1_free) {
+            LoadDesc cat = ld_plain(a0, a.Cin);
+            cat.cat_c1 = a.Cin; cat.cat_c2 = 0;
+            GemmTN g = tn_base(cat, LD_CAT1, ld_plain(a0, a.Cin), LD_PLAIN, (int)Min, a.Cin + 8, a.Cin, w.gram, a.Cin, 1);
+            PROF(DWN_FAM_PW_FWD, launch_gemm_tn(g, dt, s));
+            PROF(DWN_FAM_PW_FWD, k_bn1_gram_finalize(w.gram, a.w_pw, a.Cmid, a.Cin, (double)Min, a.bn1.gamma, a.bn1.beta, a.bn1.running_mean,
+                                                     a.bn1.running_var, a.bn1.num_batches_tracked, a.momentum, a.eps, a.bn1.coef,
+                                                     identity_sc ? w.stsc : nullptr, dt, s));
+        }
         TRY(dwn_dw_spatial_rc_prep(a.w_pw, w.wdws, a.bn1.coef, a.Cmid, a.Cin, w.rcblob, device, stream));
         dwn_dw_spatial_rc_fwd_args r; memset(&r, 0, sizeof(r));
         r.a0 = a0; r.a0_ld = a.Cin; r.blob = w.rcblob; r.out = a.y2; r.planes = a.B * a.T; r.Hin = a.Hin; r.Win = a.Win;
-        r.Hout = a.Hout; r.Wout = a.Wout; r.Cin = a.Cin; r.E = a.Cmid; r.stride = a.stride; r.stats = nullptr;
+        r.Hout = a.Hout; r.Wout = a.Wout; r.Cin = a.Cin; r.E = a.Cmid; r.stride = a.stride; r.stats = tr ? w.st2 : nullptr;
         r.rows_band = 0; r.round_y1 = 1;
         PROF(DWN_FAM_DWS_FWD, dwn_dw_spatial_fwd_rc(&r, device, stream));
     } else {
@@ -495,7 +544,8 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     // shortcut (:125-134) + residual (:143); the two linear BatchNorms (conv_pwl.1.bn, bn_sc.bn) finalise in one launch
     ResGeom gm = geom_of(a);
     if (tr) {
-        PROF(DWN_FAM_RESID_FWD, k_shortcut_stats(xin, gm, w.stsc, dt, s));
+        // (y1-free on an identity-map block: the shortcut's sums came out of the Gram pass, k_bn1_gram_finalize)
+        if (!(y1_free && identity_sc)) PROF(DWN_FAM_RESID_FWD, k_shortcut_stats(xin, gm, w.stsc, dt, s));
         TRY(k_bn_finalize_train2(fin_job(w.st4, a.Cout, (double)Mout, a.bn4, a.Cout),
                                  fin_job(w.stsc, a.Cin, (double)Mout, a.bnsc, a.Cout), a.momentum, a.eps, s));
     }
@@ -553,10 +603,12 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     const i64 Min = (i64)a.B * a.T * a.Hin * a.Win, Mout = (i64)a.B * a.T * a.Hout * a.Wout;
     const int S_out = a.T * a.Hout * a.Wout;
     float* dg = reinterpret_cast<float*>(w.pooled);
+    const bool y1_free = block_y1_free(a);           // the forward of these arguments wrote no y1 (dwn_block_forward_writes)
     {   // one launch: zero the statistics arena, W2^T [Cmid][Cout], tap-major depth-wise weights, identity affine
         PrepArgs pa;
         bool ok = pa.zero(w.zero_beg, ((size_t)(w.zero_end - w.zero_beg) + 15) & ~(size_t)15);
         ok = ok && pa.packw(a.w_pwl, w.wpwl, 1, a.Cout, a.Cmid, 1, a.Cmid, a.Cout);
+        if (y1_free) ok = ok && pa.packw(a.w_pw, w.wpw, 1, a.Cmid, a.Cin, 0, a.Cmid, a.Cin);      // W1 as rounded: the stencil rebuilds y1 with it
         ok = ok && pa.packdw(a.w_dws, w.wdws, a.Cmid, a.ks * a.ks);
         ok = ok && pa.packdw(a.w_dwt, w.wdwt, a.Cmid, a.kt);
         ok = ok && pa.fill(w.ident3, 1.0f, a.Cmid);
@@ -640,7 +692,8 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
     {
         DwSpatialBwd d; memset(&d, 0, sizeof(d));
         d.dy = ld_affine2(a.buf_b, a.y2, a.Cmid, w.abc2, a.Cmid);
-        d.y1 = ld_ycoef(a.y1, a.Cmid, a.bn1.coef, a.Cmid);
+        d.y1 = ld_ycoef(y1_free ? nullptr : a.y1, a.Cmid, a.bn1.coef, a.Cmid);
+        if (y1_free) { d.a0 = xin.p; d.a0_ld = a.Cin; d.w1 = w.wpw; d.Cin = a.Cin; }      // y1 rebuilt from the block input
         d.w = w.wdws; d.dh1 = dh1; d.dw = a.dw_dws; d.planes = a.B * a.T; d.Hin = a.Hin; d.Win = a.Win;
         d.Hout = a.Hout; d.Wout = a.Wout; d.C = a.Cmid; d.stride = a.stride; d.ks = a.ks; d.stats = w.st1;
         PROF(DWN_FAM_DWS_BWD, launch_dw_spatial_bwd(d, dt, s));
@@ -668,7 +721,7 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
 // directly — the caller need not allocate what is not written (and may pass NULL for it).
 int dwn_block_forward_writes(const dwn_block_args* ap) {
     const dwn_block_args& a = *ap;
-    if (a.training) return 3;
+    if (a.training) return block_y1_free(a) ? 2 : 3;
     return block_fwd_rc(a) ? 0 : 1;
 }
 

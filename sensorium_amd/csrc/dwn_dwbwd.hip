@@ -25,10 +25,21 @@
 #ifndef WK_MINW2
 #define WK_MINW2 3         // ... the stride-2 kernel (a thread owns four pixels: more registers)
 #endif
+#ifndef WK_MINW_RC
+#define WK_MINW_RC 2       // the y1-rebuilding forms keep 32 registers of W1 fragments: two workgroups per CU
+#endif
+#ifndef WK_MINW2_RC
+#define WK_MINW2_RC 2      // ... its y1-rebuilding form (W1 fragments + accumulators on top)
+#endif
 
 extern __shared__ __attribute__((aligned(16))) unsigned char wk_smem[];
 
 typedef float wk_f2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(8))) short wk_bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float wk_f32x4_t;
+__device__ __forceinline__ wk_f32x4_t wk_mfma(const uint4& a, const uint4& b, const wk_f32x4_t& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wk_bf16x8_t, a), __builtin_bit_cast(wk_bf16x8_t, b), c, 0, 0, 0);
+}
 typedef __attribute__((ext_vector_type(2))) __bf16 wk_bf16x2_t;
 typedef unsigned wk_u32x2_t __attribute__((ext_vector_type(2)));
 
@@ -166,25 +177,33 @@ __device__ __forceinline__ void wk_lds_barrier() {
 
 // workgroup -> (plane-group start, channel slice).  XCD-aware form: the slices of one plane group are consecutive workgroups of ONE
 // XCD (workgroups are dealt round-robin over the 8 XCDs), so what they all read (the block input a0, when y1 is rebuilt) is
-// fetched into that XCD's L2 once.  Needs gridDim.x % 8 == 0 (the launchers round it).
+// fetched into that XCD's L2 once (measured, profiles/r5_l2share_pmc.json: fabric reads halve).  Needs gridDim.x % 8 == 0.
 struct WkBlk { int x, y; };
+template <bool XCD>
 __device__ __forceinline__ WkBlk wk_block() {
-#ifdef EXP_XCD_MAP
-    const int gx = (int)gridDim.x, ns = (int)gridDim.y;
-    const int b = (int)blockIdx.y * gx + (int)blockIdx.x;
-    const int xcd = b & 7, i = b >> 3;
-    WkBlk r; r.y = i % ns; r.x = (i / ns) * 8 + xcd;
+    WkBlk r;
+    if constexpr (XCD) {
+        const int gx = (int)gridDim.x, ns = (int)gridDim.y;
+        const int b = (int)blockIdx.y * gx + (int)blockIdx.x;
+        const int xcd = b & 7, i = b >> 3;
+        r.y = i % ns; r.x = (i / ns) * 8 + xcd;
+    } else {
+        r.x = (int)blockIdx.x; r.y = (int)blockIdx.y;
+    }
     return r;
-#else
-    WkBlk r; r.x = (int)blockIdx.x; r.y = (int)blockIdx.y;
-    return r;
-#endif
 }
 
-template <int LPW, int RB>
-__global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1c_kernel(const DwSpatialBwd a) {
+// CIN > 0: y1 is NOT read — the chunk's rows of this 64-channel slice are REBUILT from the block input a0 (a.a0, Cin = CIN
+// channels, seven times narrower) with v_mfma_f32_16x16x32_bf16 and W1 (a.w1, as rounded to bf16): a wave fetches the a0 rows of
+// its own 8 pixels straight into B-operand fragments (16 pixels = two rows x 8 pixels per MFMA tile), keeps its W1 fragments
+// in registers for the whole launch, rounds the accumulators to bf16 as the stored tensor would read back (bit-identical to
+// conv_pw's output: same operand roles, same k order) and writes them where the LDS-DMA would have put y1.  The slices of a
+// plane group run on one XCD (wk_block), so a0 crosses the fabric once and the other slices find it in that L2.
+template <int LPW, int RB, int CIN>
+__global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatial_bwd_s1c_kernel(const DwSpatialBwd a) {
     typedef bf16_t T;
     constexpr int NT = 256, CS = 64, NG = 16 / LPW, Wqp = LPW + 1, RQ = RB + 2, W = 2 * LPW;
+    constexpr int KB = CIN > 0 ? CIN / 32 : 1;
     constexpr int rowdw = Wqp * CS;                                         // dwords between ring rows of one plane
     constexpr unsigned RING_BYTES = (unsigned)NG * RQ * Wqp * CS * 4u;
     constexpr int NEX = (RB + LPW - 1) / LPW;                              // halo-column rows a thread stages per chunk
@@ -195,7 +214,7 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1c_kernel(const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cv = tid & 15, pl = tid >> 4;
     const int grp = pl / LPW, jj = pl % LPW;
-    const WkBlk blk = wk_block();
+    const WkBlk blk = wk_block<(CIN > 0)>();
     const int c0 = blk.y * CS;
     const int chan = c0 + cv * 4;
     const bool chan_ok = chan < a.C;
@@ -237,15 +256,32 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1c_kernel(const 
     const int dq = (dslot & 4) | ((dslot & 1) << 1) | ((dslot >> 1) & 1);     // pixel of the block that lives in slot dslot
     const int dp = wave * 8 + dq;                                              // pixel of the 32-pixel group row
     const int dgrp = dp / W, dx = dp % W;
-#ifdef EXP_SHARED_Y1
-    const int dce = c16 * 8;                                                   // experiment: every slice reads the same 64 channels
-#else
     const int dce = (c0 + c16 * 8 < a.C) ? c0 + c16 * 8 : c0;                   // channel tail: any valid address (never read back)
-#endif
     const unsigned lds_y1 = (unsigned)(size_t)wk_smem + RING_BYTES + (unsigned)wave * 1024u;
     // ... and where this thread finds its two pixels (2jj, 2jj+1) of a row in that block: slots s0 and s0 + 2
     const int jq = pl & 3;
     const unsigned char* yld = wk_smem + RING_BYTES + wave * 1024 + (((jq & 1) + ((jq >> 1) << 2)) * 128) + cv * 8;
+    // ---- rebuilt y1 (CIN > 0): MFMA tile = this wave's 8 pixels of two consecutive rows; lane (lr, lg): tile pixel lr = (row
+    // parity lr >> 3, slot lr & 7), k group lg.  The 8-byte channel chunk c8 of tile pixel lr is stored at chunk c8 ^ lr of its
+    // 128-byte slot (conflict-free ds_write_b64; the walk reads its chunk cv at cv ^ key with key = 8 * row parity + slot).
+    const int lr = lane & 15, lg = lane >> 4;
+    uint4 wfr[4][KB];
+    const T* a0src0 = nullptr;
+    if constexpr (CIN > 0) {
+        const T* w1 = reinterpret_cast<const T*>(a.w1);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int ch = c0 + 16 * n + lr;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                wfr[n][kb] = *reinterpret_cast<const uint4*>(w1 + (i64)(ch < a.C ? ch : c0) * CIN + 8 * lg + 32 * kb);
+        }
+    }
+    // the walk's chunk offsets inside a slot: [row parity][h]
+    const int s0w = (jq & 1) + ((jq >> 1) << 2);
+    const int ykey[2][2] = {{(cv ^ s0w) * 8, (cv ^ (s0w + 2)) * 8}, {(cv ^ (8 + s0w)) * 8, (cv ^ (8 + s0w + 2)) * 8}};
+    const unsigned char* yslot = wk_smem + RING_BYTES + wave * 1024 + s0w * 128;
+    (void)ykey; (void)yslot; (void)lr; (void)lg;
     // staging constants
     const unsigned cmask = (jj > 0 ? 0x0000ffffu : 0u) | 0xffff0000u;          // pair jj = (wo = 2jj-1, wo = 2jj)
     const unsigned colhi = (unsigned)(2 * jj) * (unsigned)a.dy.ld;
@@ -261,6 +297,12 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1c_kernel(const 
         const T* dq0 = reinterpret_cast<const T*>(a.dy.q) + pbase;
         const int dplane = pg * NG + dgrp < a.planes ? pg * NG + dgrp : 0;
         const T* ysrc0 = y1p + ((i64)dplane * Hin * W + dx) * a.y1.ld + dce;
+        if constexpr (CIN > 0) {
+            const int tq = lr & 7;                                                  // slot of this lane's tile pixel
+            const int tpx = wave * 8 + ((tq & 4) | ((tq & 1) << 1) | ((tq >> 1) & 1));   // its pixel of the 32-pixel group row
+            const int tplane = pg * NG + tpx / W < a.planes ? pg * NG + tpx / W : 0;
+            a0src0 = reinterpret_cast<const T*>(a.a0) + ((i64)tplane * Hin * W + tpx % W) * a.a0_ld + 8 * lg;
+        }
         const i64 prow = (i64)psafe * Hin * W;
         const T* y10 = y1p + prow * a.y1.ld;      // (unused for loads: y1 comes from LDS)
         (void)y10;
@@ -271,12 +313,25 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1c_kernel(const 
         int slot_s = 1;                            // ring slot of gradient row s = chunk * RB   (slot(r) = (r + 1) mod RQ)
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             const int s = chunk * RB;
-            // ---------------- y1 rows s-1 .. s+RB-2 -> LDS (DMA, this wave's pixels only)
+            // ---------------- y1 rows s-1 .. s+RB-2 -> LDS (DMA, this wave's pixels only) — or the a0 rows they are rebuilt from
+            uint4 afr[RB / 2][KB];
+            if constexpr (CIN > 0) {
+                const unsigned a0row = (unsigned)W * (unsigned)a.a0_ld;
 #pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                const int row = s - 1 + i;
-                if ((unsigned)row < (unsigned)Hin)
-                    wk_glds16(ysrc0 + (unsigned)row * y1row, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_y1 + (unsigned)i * 4096u)));
+                for (int t = 0; t < RB / 2; ++t) {
+                    int row = s - 1 + 2 * t + (lr >> 3);                     // rows outside the plane: any valid address (never read back)
+                    row = row < 0 ? 0 : (row >= Hin ? Hin - 1 : row);
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb)
+                        afr[t][kb] = *reinterpret_cast<const uint4*>(a0src0 + (unsigned)row * a0row + 32 * kb);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int row = s - 1 + i;
+                    if ((unsigned)row < (unsigned)Hin)
+                        wk_glds16(ysrc0 + (unsigned)row * y1row, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_y1 + (unsigned)i * 4096u)));
+                }
             }
             // ---------------- stage dL/dy2 rows s .. s+RB-1 (BatchNorm-backward affine), x-pair-packed, into their ring slots
             {
@@ -331,7 +386,22 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1c_kernel(const 
                     }
                 }
             }
-            wk_wait_vm0();                          // this wave's y1 blocks have landed (it is their only reader)
+            if constexpr (CIN > 0) {
+                // rebuild this wave's y1 blocks: 4 channel tiles x KB k-steps per pixel tile, rounded as stored
+#pragma unroll
+                for (int t = 0; t < RB / 2; ++t) {
+                    unsigned char* dst = wk_smem + RING_BYTES + (2 * t + (lr >> 3)) * 4096 + wave * 1024 + (lr & 7) * 128;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        wk_f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kb = 0; kb < KB; ++kb) acc = wk_mfma(wfr[n][kb], afr[t][kb], acc);
+                        *reinterpret_cast<uint2*>(dst + (((4 * n + lg) ^ lr) << 3)) = make_uint2(pk_bf16(acc[0], acc[1]), pk_bf16(acc[2], acc[3]));
+                    }
+                }
+            } else {
+                wk_wait_vm0();                      // this wave's y1 blocks have landed (it is their only reader)
+            }
             wk_lds_barrier();
             // ---------------- walk rows s-1 .. s+RB-2 of this thread's pixel-pair column
             const int r_lo = s > 0 ? s - 1 : 0;
@@ -350,8 +420,17 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1c_kernel(const 
                     g2[0] = *reinterpret_cast<const uint4*>(tcol + sl2 * rowdw);
                     g2[1] = *reinterpret_cast<const uint4*>(tcol + sl2 * rowdw + CS);
                     sl2 = sl2 + 1 == RQ ? 0 : sl2 + 1;
-                    const unsigned char* yr = yld + (r - (s - 1)) * 4096;
-                    const uint2 ry[2] = {*reinterpret_cast<const uint2*>(yr), *reinterpret_cast<const uint2*>(yr + 256)};
+                    uint2 ry[2];
+                    if constexpr (CIN > 0) {
+                        const int ri = r - (s - 1);
+                        const unsigned char* yr = yslot + ri * 4096;
+                        const int par = ri & 1;
+                        ry[0] = *reinterpret_cast<const uint2*>(yr + (par ? ykey[1][0] : ykey[0][0]));
+                        ry[1] = *reinterpret_cast<const uint2*>(yr + 256 + (par ? ykey[1][1] : ykey[0][1]));
+                    } else {
+                        const unsigned char* yr = yld + (r - (s - 1)) * 4096;
+                        ry[0] = *reinterpret_cast<const uint2*>(yr); ry[1] = *reinterpret_cast<const uint2*>(yr + 256);
+                    }
                     wk_f2_t y[2][2], z1[2][2], dsl[2][2];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -476,17 +555,21 @@ __global__ __launch_bounds__(256, WK_MINW) void dw_spatial_bwd_s1c_kernel(const 
 // the two gradient rows in use slide down in registers (one tile row read per two input rows).
 // LPW = quads per input row = output pairs per row (Win == 4*LPW in {64, 32, 16}); NG = 16/LPW planes per tile.
 // ------------------------------------------------------------------------------------------------
-template <int LPW>
-__global__ __launch_bounds__(256, WK_MINW2) void dw_spatial_bwd_s2_kernel(const DwSpatialBwd a, const int R, const int rows_qmax) {
+// CIN > 0: y1 is rebuilt from a0 (see the stride-1 kernel).  Here the MFMA runs with the PIXELS as its A operand (the wave's 16
+// pixels of the input row: four quads) and W1 rows as B in the order 4 cv + n, so that accumulator register j of channel tile n
+// in lane (cv, quad) IS y1[pixel j of the thread's quad][channel 4 cv + n]: the thread's own 4 x 4 values, no LDS round trip.
+template <int LPW, int CIN>
+__global__ __launch_bounds__(256, CIN > 0 ? WK_MINW2_RC : WK_MINW2) void dw_spatial_bwd_s2_kernel(const DwSpatialBwd a, const int R, const int rows_qmax) {
     typedef bf16_t T;
     constexpr int NT = 256, CS = 64, NG = 16 / LPW, Wqp = LPW + 1;
+    constexpr int KB = CIN > 0 ? CIN / 32 : 1;
     __shared__ float lstat[2 * CS];
     __shared__ __attribute__((aligned(16))) unsigned lwp[3 * 3 * CS];        // packed weights [dy][combo][channel]
     __shared__ __attribute__((aligned(16))) float lcoef[2 * CS];             // BatchNorm-1 scale, shift (re-read per row: registers)
     const int tid = threadIdx.x, lane = tid & 63;
     const int cv = tid & 15, pl = tid >> 4;
     const int grp = pl / LPW, jj = pl % LPW;
-    const WkBlk blk = wk_block();
+    const WkBlk blk = wk_block<(CIN > 0)>();
     const int c0 = blk.y * CS;
     const int chan = c0 + cv * 4;
     const bool chan_ok = chan < a.C;
@@ -506,6 +589,22 @@ __global__ __launch_bounds__(256, WK_MINW2) void dw_spatial_bwd_s2_kernel(const 
     }
     __syncthreads();
 
+        uint4 wfr[4][KB];
+    if constexpr (CIN > 0) {
+        // B operand: column cv of channel tile n = W1 row c0 + 4 cv + n, k group lane >> 4
+        const T* w1 = reinterpret_cast<const T*>(a.w1);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int ch = chs + n;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                wfr[n][kb] = *reinterpret_cast<const uint4*>(w1 + (i64)(ch < a.C ? ch : chs) * CIN + 8 * (lane >> 4) + 32 * kb);
+        }
+    }
+    // A operand: tile pixel lane & 15 = (quad (lane & 15) >> 2 of this wave, pixel (lane & 15) & 3)
+    const int apl = (tid >> 6) * 4 + ((lane & 15) >> 2);
+    const int agrp = apl / LPW, ajj = apl % LPW;
+    (void)agrp; (void)ajj;
     float dwp[9][4];
 #pragma unroll
     for (int k = 0; k < 9; ++k) { dwp[k][0] = dwp[k][1] = dwp[k][2] = dwp[k][3] = 0.f; }
@@ -535,19 +634,25 @@ __global__ __launch_bounds__(256, WK_MINW2) void dw_spatial_bwd_s2_kernel(const 
         __syncthreads();
         if (pvalid) {
             const i64 prow = (i64)plane * Hin * Win;
-#ifdef EXP_SHARED_Y1
-            const T* y10 = y1p + prow * a.y1.ld + cv * 4 + (unsigned)(hi0 * Win + 4 * jj) * (unsigned)a.y1.ld;
-#else
             const T* y10 = y1p + prow * a.y1.ld + chs + (unsigned)(hi0 * Win + 4 * jj) * (unsigned)a.y1.ld;
-#endif
             T* dh0 = dhp + prow * a.C + chan + (unsigned)(hi0 * Win + 4 * jj) * (unsigned)a.C;
+            const T* a0t = nullptr;
+            if constexpr (CIN > 0) {
+                const int aplane = pg * NG + agrp < a.planes ? pg * NG + agrp : 0;
+                a0t = reinterpret_cast<const T*>(a.a0) + ((i64)aplane * Hin * Win + (unsigned)(hi0 * Win + 4 * ajj + (lane & 3))) * a.a0_ld + 8 * (lane >> 4);
+            }
+            const unsigned a0row = (unsigned)Win * (unsigned)(CIN > 0 ? a.a0_ld : 0);
             uint4 gA[2], gB[2];                          // gradient rows in use: pairs jj, jj+1
             gA[0] = *reinterpret_cast<const uint4*>(tcol); gA[1] = *reinterpret_cast<const uint4*>(tcol + CS);
             // one input row: NTAP tap rows (dy, gradient row) — even rows (dy 1, gcur), odd rows (dy 0, gnext) and (dy 2, gcur)
             auto row_step = [&](const int iy, auto odd_c, const uint4 (&gcur)[2], const uint4 (&gnext)[2]) {
                 constexpr bool ODD = decltype(odd_c)::value;
                 uint2 ry[4];
-                {
+                uint4 afr[KB];
+                if constexpr (CIN > 0) {
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) afr[kb] = *reinterpret_cast<const uint4*>(a0t + (unsigned)iy * a0row + 32 * kb);
+                } else {
                     const T* yn = y10 + (unsigned)iy * y1row;
 #pragma unroll
                     for (int p = 0; p < 4; ++p) ry[p] = wk_ld8(yn + p * a.y1.ld);       // in flight under the data-gradient taps
@@ -573,6 +678,18 @@ __global__ __launch_bounds__(256, WK_MINW2) void dw_spatial_bwd_s2_kernel(const 
                 };
                 if constexpr (ODD) { tap_dz(0, gnext); __builtin_amdgcn_sched_barrier(0); tap_dz(2, gcur); } else { tap_dz(1, gcur); }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (CIN > 0) {
+                    // y1 of the thread's quad: acc[n][p] = y1[pixel p][channel 4 cv + n], rounded as the stored tensor reads back
+                    wk_f32x4_t acc[4];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        acc[n] = wk_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kb = 0; kb < KB; ++kb) acc[n] = wk_mfma(afr[kb], wfr[n][kb], acc[n]);
+                    }
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) ry[p] = make_uint2(pk_bf16(acc[0][p], acc[1][p]), pk_bf16(acc[2][p], acc[3][p]));
+                }
                 // 2) activation, pixel by pixel (order 0, 2, 1, 3 so that (z0, z2) and (z1, z3) pack as soon as possible);
                 //    each pixel is finished at once: dh1 = dz * SiLU', store, BatchNorm-backward sums
                 T* dst = dh0 + (unsigned)iy * dhrow;
@@ -712,14 +829,26 @@ bool dw_spatial_bwd_walk_supported(const DwSpatialBwd& a, int dtype) {
     return false;
 }
 
-template <int LPW>
+// rebuilt-y1 mode (a.a0 != NULL): bf16, Cin = 64 (one or two... k-steps of 32 per MFMA tile; W1 fragments live in registers),
+// whole 64-channel slices (an MFMA needs every lane of the wave: no channel tail)
+bool dw_spatial_bwd_rc_supported(const DwSpatialBwd& a, int dtype) {
+    if (!dw_spatial_bwd_walk_supported(a, dtype)) return false;
+    if (a.Cin != 64 || a.C % 64) return false;
+    if (a.a0_ld % 8 || a.a0_ld < a.Cin) return false;
+    if ((i64)a.Hin * a.Win * a.a0_ld >= (1ll << 31)) return false;
+    return true;
+}
+
+template <int LPW, int CIN>
 static int launch_s2(const DwSpatialBwd& a, hipStream_t s) {
     constexpr int NG = 16 / LPW, Wqp = LPW + 1;
     const size_t rowb = (size_t)NG * Wqp * 256;
+    // rebuilt-y1 form: two workgroups per CU (registers), so the tile may be larger
+    const size_t budget = CIN > 0 ? (size_t)(WK_LDS_BUDGET * 3 / 2) : (size_t)WK_LDS_BUDGET;
     int R = a.rows_band;                              // input rows per band, even
     if (R <= 0) {
         R = 2;
-        while (R < a.Hin && (size_t)((R + 2) / 2 + 1) * rowb <= (size_t)WK_LDS_BUDGET) R += 2;
+        while (R < a.Hin && (size_t)((R + 2) / 2 + 1) * rowb <= budget) R += 2;
         const int nb = (a.Hin + R - 1) / R;
         R = (a.Hin + nb - 1) / nb;                    // even split
     }
@@ -729,7 +858,7 @@ static int launch_s2(const DwSpatialBwd& a, hipStream_t s) {
     size_t lds = (size_t)rows_qmax * rowb;
     if (lds < 9 * 64 * sizeof(float)) lds = 9 * 64 * sizeof(float);
     if (lds > 150 * 1024) return dwn_set_error(-5, "dw_spatial_bwd: rows_band too large for the LDS tile");
-    auto kern = dw_spatial_bwd_s2_kernel<LPW>;
+    auto kern = dw_spatial_bwd_s2_kernel<LPW, CIN>;
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         (void)hipGetLastError();
     int bpc = 0;
@@ -740,19 +869,17 @@ static int launch_s2(const DwSpatialBwd& a, hipStream_t s) {
     i64 gx = (256 * bpc) / slices;
     if (gx < 1) gx = 1;
     if (gx > work) gx = work;
-#ifdef EXP_XCD_MAP
-    if (gx >= 8) gx &= ~(i64)7;
-#endif
+    if (CIN > 0) gx = gx >= 8 ? (gx & ~(i64)7) : 8;   // wk_block<true>: the slices of a tile share an XCD (a workgroup past the work just exits)
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, slices), dim3(256), lds, s, a, R, rows_qmax);
     DWN_CHECK_LAUNCH();
     return 0;
 }
 
-template <int LPW, int RB>
+template <int LPW, int RB, int CIN>
 static int launch_s1c(const DwSpatialBwd& a, hipStream_t s) {
     constexpr int NG = 16 / LPW, Wqp = LPW + 1;
     const size_t lds = (size_t)NG * (RB + 2) * Wqp * 256 + (size_t)RB * 4096;
-    auto kern = dw_spatial_bwd_s1c_kernel<LPW, RB>;
+    auto kern = dw_spatial_bwd_s1c_kernel<LPW, RB, CIN>;
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         (void)hipGetLastError();
     int bpc = 0;
@@ -762,34 +889,43 @@ static int launch_s1c(const DwSpatialBwd& a, hipStream_t s) {
     i64 gx = (256 * bpc) / slices;
     if (gx < 1) gx = 1;
     if (gx > work) gx = work;
-#ifdef EXP_XCD_MAP
-    if (gx >= 8) gx &= ~(i64)7;
-#endif
+    if (CIN > 0) gx = gx >= 8 ? (gx & ~(i64)7) : 8;
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, slices), dim3(256), lds, s, a);
     DWN_CHECK_LAUNCH();
     return 0;
 }
 // chained stride-1 kernel: rows per chunk = a.rows_band, or the measured best at the metric shapes (tools/bwd_chain_check.py):
 // 4 rows per chunk at 18x32 planes (three workgroups per CU), 2 at 9x16 and 5x8
-template <int LPW>
+template <int LPW, int CIN>
 static int launch_s1c_rb(const DwSpatialBwd& a, hipStream_t s) {
     const int rb = a.rows_band > 0 ? a.rows_band : (LPW == 16 ? 4 : 2);
-    if (rb <= 2) return launch_s1c<LPW, 2>(a, s);
-    if (rb <= 4) return launch_s1c<LPW, 4>(a, s);
-    if (rb <= 6) return launch_s1c<LPW, 6>(a, s);
-    return launch_s1c<LPW, 8>(a, s);
+    if (rb <= 2) return launch_s1c<LPW, 2, CIN>(a, s);
+    if (rb <= 4) return launch_s1c<LPW, 4, CIN>(a, s);
+    if constexpr (CIN > 0) return launch_s1c<LPW, 4, CIN>(a, s);     // (the rebuilt-y1 form is built for 2 / 4 rows per chunk)
+    if (rb <= 6) return launch_s1c<LPW, 6, CIN>(a, s);
+    return launch_s1c<LPW, 8, CIN>(a, s);
+}
+
+template <int CIN>
+static int launch_walk_c(const DwSpatialBwd& a, hipStream_t s) {
+    if (a.stride == 1) {
+        if (a.Win == 32) return launch_s1c_rb<16, CIN>(a, s);
+        if (a.Win == 16) return launch_s1c_rb<8, CIN>(a, s);
+        return launch_s1c_rb<4, CIN>(a, s);
+    }
+    if (a.stride == 2) {
+        if (a.Win == 64) return launch_s2<16, CIN>(a, s);
+        if (a.Win == 32) return launch_s2<8, CIN>(a, s);
+        return launch_s2<4, CIN>(a, s);
+    }
+    return dwn_set_error(-3, "dw_spatial_bwd_walk: unsupported configuration");
 }
 
 int launch_dw_spatial_bwd_walk(const DwSpatialBwd& a, hipStream_t s) {
-    if (a.stride == 1) {
-        if (a.Win == 32) return launch_s1c_rb<16>(a, s);
-        if (a.Win == 16) return launch_s1c_rb<8>(a, s);
-        return launch_s1c_rb<4>(a, s);
+    if (a.a0) {
+        if (!dw_spatial_bwd_rc_supported(a, DWN_BF16) || !a.w1)
+            return dwn_set_error(-3, "dw_spatial_bwd: rebuilt-y1 mode needs bf16, Cin = 64, C % 64 == 0, w1 and a row-walk plane width");
+        return launch_walk_c<64>(a, s);
     }
-    if (a.stride == 2) {
-        if (a.Win == 64) return launch_s2<16>(a, s);
-        if (a.Win == 32) return launch_s2<8>(a, s);
-        return launch_s2<4>(a, s);
-    }
-    return dwn_set_error(-3, "dw_spatial_bwd_walk: unsupported configuration");
+    return launch_walk_c<0>(a, s);
 }

@@ -1348,6 +1348,8 @@ static int spatial_bwd_t(DwSpatialBwd a, hipStream_t s) {
 bool dw_spatial_bwd_walk_supported(const DwSpatialBwd& a, int dtype);
 int launch_dw_spatial_bwd_walk(const DwSpatialBwd& a, hipStream_t s);
 int launch_dw_spatial_bwd(const DwSpatialBwd& a, int dtype, hipStream_t s) {
+    if (a.a0 && !dw_spatial_bwd_walk_supported(a, dtype))
+        return dwn_set_error(-3, "dw_spatial_bwd: rebuilt-y1 mode (a0 != NULL) is built into the row-walk kernels only (dwn_dw_spatial_bwd_rc_supported)");
     if (dw_spatial_bwd_walk_supported(a, dtype)) return launch_dw_spatial_bwd_walk(a, s);     // row-walk kernels (dwn_dwbwd.hip)
     return dtype == DWN_BF16 ? spatial_bwd_t<bf16_t>(a, s) : spatial_bwd_t<float>(a, s);
 }

@@ -348,10 +348,12 @@ __global__ __launch_bounds__(NT, NT / 256) void dw_spatial_fwd_rc_kernel(const R
 #endif
     if (a.stats) {
         __syncthreads();
+        DET_ENTER();
         for (int i = tid; i < 2 * a.E; i += NT) {
             const int which = i >= a.E ? 1 : 0;
             stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.E, which, i - which * a.E, lstat[i]);
         }
+        DET_EXIT();
     }
 }
 

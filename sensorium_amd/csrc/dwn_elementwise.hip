@@ -212,6 +212,79 @@ int k_bn_bwd_finalize(const double* stats, double count, const float* coef, floa
 }
 
 // ------------------------------------------------------------------------------------------------
+// BatchNorm-1 batch statistics WITHOUT y1 (round 5).  y1 = a0 . W1^T is linear in the block input, so over the n rows
+//   mean_e = w_e . mu,   var_e = w_e^T (G / n - mu mu^T) w_e     with G = a0^T a0, mu = (1^T a0) / n
+// (gram = [(Cin + 8)][Cin] fp32: rows 0 .. Cin-1 = G, row Cin = 1^T a0 — the raw products a gemm_tn pass over a0 with the
+// [a0 | 1] loader accumulates; W1 as rounded to the compute type, i.e. the weights the MFMAs that rebuild y1 multiply with).
+// These are the statistics of the UNROUNDED product; a stored bf16 y1 carries 2^-9 of unbiased rounding noise per element on
+// top, which moves the mean by nothing and the variance by 3e-6 of itself.  One wave per channel, fp64 from the products on.
+// sc_stats != NULL: the same raw products also are the shortcut BatchNorm's sums on an identity-map block (its input is a0):
+// block 0 writes sum x = 1^T a0 and sum x^2 = diag(G) into replica 0 of that statistics buffer (zeroed by the caller).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn1_gram_finalize_kernel(const float* __restrict__ gram, const float* __restrict__ w1,
+                                                                int E, int Cin, double count, const float* gamma, const float* beta,
+                                                                float* running_mean, float* running_var, long long* nbt,
+                                                                float momentum, float eps, float* coef, double* sc_stats) {
+    __shared__ float lw[4][512];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int e = blockIdx.x * 4 + wv;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+    if (sc_stats && blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < Cin; c += 256) {
+            sc_stats[c] = (double)gram[(i64)Cin * Cin + c];
+            sc_stats[Cin + c] = (double)gram[(i64)c * Cin + c];
+        }
+    }
+    if (e >= E) return;
+    for (int j = lane; j < Cin; j += 64) lw[wv][j] = round_t<T>(w1[(i64)e * Cin + j]);
+    __builtin_amdgcn_wave_barrier();
+    const double inv_n = 1.0 / count;
+    double quad = 0.0, lin = 0.0;
+    for (int i = lane; i < Cin; i += 64) {
+        const float* grow = gram + (i64)i * Cin;
+        double r = 0.0;
+        for (int j = 0; j < Cin; j += 4) {
+            const float4 g4 = *reinterpret_cast<const float4*>(grow + j);
+            r += (double)g4.x * (double)lw[wv][j] + (double)g4.y * (double)lw[wv][j + 1] + (double)g4.z * (double)lw[wv][j + 2] +
+                 (double)g4.w * (double)lw[wv][j + 3];
+        }
+        quad += (double)lw[wv][i] * r;
+        lin += (double)lw[wv][i] * (double)gram[(i64)Cin * Cin + i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { quad += __shfl_xor(quad, o); lin += __shfl_xor(lin, o); }
+    if (lane != 0) return;
+    const double mean = lin * inv_n;
+    double var = quad * inv_n - mean * mean;
+    if (var < 0) var = 0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float scale = gamma[e] * invstd;
+    coef[e] = scale;
+    coef[E + e] = beta[e] - (float)mean * scale;
+    coef[2 * E + e] = (float)mean;
+    coef[3 * E + e] = invstd;
+    if (running_mean) {
+        const double unbiased = count > 1 ? var * count / (count - 1) : var;
+        running_mean[e] = (1.f - momentum) * running_mean[e] + momentum * (float)mean;
+        running_var[e] = (1.f - momentum) * running_var[e] + momentum * (float)unbiased;
+    }
+}
+int k_bn1_gram_finalize(const float* gram, const float* w1, int E, int Cin, double count, const float* gamma, const float* beta,
+                        float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef, double* sc_stats, int dtype,
+                        hipStream_t s) {
+    if (Cin > 512 || Cin % 4) return dwn_set_error(-2, "bn1_gram_finalize: Cin must be a multiple of 4, at most 512");
+    if (dtype == DWN_BF16)
+        hipLaunchKernelGGL(bn1_gram_finalize_kernel<bf16_t>, dim3((E + 3) / 4), dim3(256), 0, s, gram, w1, E, Cin, count, gamma, beta,
+                           rm, rv, nbt, momentum, eps, coef, sc_stats);
+    else
+        hipLaunchKernelGGL(bn1_gram_finalize_kernel<float>, dim3((E + 3) / 4), dim3(256), 0, s, gram, w1, E, Cin, count, gamma, beta,
+                           rm, rv, nbt, momentum, eps, coef, sc_stats);
+    DWN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // generic "materialise a loader" and per-channel statistics of a loader
 // ------------------------------------------------------------------------------------------------
 template <typename T, int KIND>

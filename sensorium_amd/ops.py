@@ -76,6 +76,9 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 # conv_pwl backward implementation forced for a process (the block / model parity tests are re-run under both): "new" =
 # per-sample products + recompute epilogue, "old" = materialised du; unset = the library chooses by shape
 _PWL_BWD = {"": 0, "new": 1, "old": 2}[os.environ.get("DWN_PWL_BWD", "")]
+# dwn_block_args.y1_mode: "" = the library leaves y1 (conv_pw's output) unmaterialised in bf16 training where both stencils rebuild it
+# from the block input; DWN_Y1=materialise forces the stored-y1 path (the parity tests run both; same-box A/B runs)
+_Y1_MODE = {"": 0, "free": 0, "materialise": 1}[os.environ.get("DWN_Y1", "")]
 
 
 def grad_out(param: torch.Tensor, zero: bool = False) -> torch.Tensor:
@@ -231,6 +234,7 @@ def _block_args(blk, geom, x, dtype, training, coefs, saved, drop_scale, x_has_p
     a.se_pmean = saved["pmean"].data_ptr(); a.se_hidpre = saved["hidpre"].data_ptr()
     a.se_gate = saved["gate"].data_ptr()
     a.f32_products = _f32_products(blk)
+    a.y1_mode = getattr(blk, "_dwn_y1_mode", _Y1_MODE)
     return a
 
 
@@ -262,8 +266,9 @@ class BlockFn(torch.autograd.Function):
                      gate=torch.empty(B, Cmid, **f32))
         a = _block_args(blk, geom, x, dtype, training, coefs, saved, drop_scale, x_has_pe, a0)
         a.out = out.data_ptr()
-        # eval: y1 is not written where the stencil rebuilds it, y3 not where the temporal pass emits z3 directly
-        writes = 3 if training else L.lib.dwn_block_forward_writes(C.byref(a))
+        # y1 is not written where the stencils rebuild it (eval; bf16 training where both directions are built: the backward then
+        # gets no y1 either), y3 not where the eval-mode temporal pass emits z3 directly
+        writes = L.lib.dwn_block_forward_writes(C.byref(a))
         y1 = torch.empty(B, T, Hin, Win, Cmid, dtype=dtype, device=dev) if writes & 1 else None
         y3 = torch.empty_like(y2) if writes & 2 else None
         a.y1 = _ptr(y1); a.y2 = y2.data_ptr(); a.y3 = _ptr(y3); a.y4 = y4.data_ptr()
@@ -305,7 +310,7 @@ class BlockFn(torch.autograd.Function):
         Cmid, Cout = blk.mid_features, blk.out_features
         f32 = dict(dtype=torch.float32, device=dev)
         a = _block_args(blk, ctx.geom, x, dtype, True, coefs, saved, drop_scale, True, None)
-        a.y1 = y1.data_ptr(); a.y2 = y2.data_ptr(); a.y3 = y3.data_ptr(); a.y4 = y4.data_ptr()
+        a.y1 = _ptr(y1); a.y2 = y2.data_ptr(); a.y3 = y3.data_ptr(); a.y4 = y4.data_ptr()      # (y1 is None on a y1-free block)
         a.z3 = z3.data_ptr()
         bns = blk.bn_modules()
         dg = [grad_out(bn.weight) for bn in bns]

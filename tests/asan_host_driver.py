@@ -11,7 +11,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import sensorium_amd._lib as L
 
 lib = L.lib
-assert lib.dwn_abi_version() == 5
+assert lib.dwn_abi_version() == 6
 for cname, struct in L._STRUCTS.items():
     assert lib.dwn_sizeof(cname.encode()) == C.sizeof(struct), cname
 
@@ -39,6 +39,11 @@ for dtype in (L.DWN_F32, L.DWN_BF16):
                     for mode in (0, 1, 2):       # conv_pwl backward path: by shape / per-sample products / materialised du
                         a.pwl_bwd = mode
                         assert lib.dwn_block_workspace_bytes(C.byref(a), 1) > 0
+                    for y1m in (0, 1):           # y1 left unmaterialised where both stencils rebuild it / always stored
+                        a.y1_mode = y1m
+                        wr = lib.dwn_block_forward_writes(C.byref(a))
+                        assert wr in (0, 1, 2, 3) and (wr & 1 or y1m == 0 or not training)
+                        assert lib.dwn_block_workspace_bytes(C.byref(a), 0) > 0 and lib.dwn_block_workspace_bytes(C.byref(a), 1) > 0
                     lib.dwn_pw_bwd_fused_supported(dtype, B * T * h * w, a.Cmid, a.Cin)
                     calls += 8
             h, w = (h - 1) // st + 1, (w - 1) // st + 1
@@ -61,6 +66,19 @@ for cin in (64, 128, 256, 72):
                 for dtype in (L.DWN_F32, L.DWN_BF16):
                     assert lib.dwn_dw_spatial_rc_supported(dtype, cin, cin * 7, 3, st, hin, win) in (0, 1)
                     calls += 1
+# the rebuilt-y1 backward stencils: support predicate over plane sizes / channel counts
+for cin in (64, 128, 72):
+    for cmid in (64, 448, 72, 896):
+        for st in (1, 2):
+            for hin in (1, 9, 18, 36):
+                for win in (8, 16, 32, 64, 30, 130):
+                    for dtype in (L.DWN_F32, L.DWN_BF16):
+                        d = L.DwSpatialBwdArgs()
+                        d.planes = 3; d.Hin = hin; d.Win = win; d.Hout = (hin - 1) // st + 1; d.Wout = (win - 1) // st + 1
+                        d.C = cmid; d.stride = st; d.ks = 3; d.dy.ld = cmid; d.y1.ld = cmid; d.a0_ld = cin; d.Cin = cin
+                        assert lib.dwn_dw_spatial_bwd_rc_supported(C.byref(d), dtype) in (0, 1)
+                        calls += 1
+assert lib.dwn_conv_pw_bn_stats_workspace_bytes(64) > 0
 # every entry point's error path: no device, null / zero arguments — an error code and a message, never a crash
 def expect_error(rc):
     assert rc != 0

@@ -88,3 +88,93 @@ def test_walk_kernels_band_heights(stride, rows_band):
     assert float((d0.float() != d1.float()).float().mean()) < (1e-3 if stride == 2 else 1e-30)
     assert float((w0 - w1).norm() / w0.norm()) < 2e-3
     assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-4
+
+
+# ---- rebuilt-y1 mode (round 5): the kernels rebuild the y1 rows they need from the block input a0 on the matrix cores -----------
+def _conv_pw(a0, w1):
+    """y1 = a0 . W1^T as the product path stores it: the real conv_pw GEMM through dwn_gemm_nn (bf16 output)."""
+    M, K = a0.shape
+    N = w1.shape[0]
+    c = torch.empty(M, N, dtype=BF, device=a0.device)
+    g = L.GemmNNArgs()
+    g.a = _desc(a0, K)
+    g.a_kind = L.LD_PLAIN
+    g.b = w1.data_ptr(); g.ldb = K; g.c = c.data_ptr(); g.ldc = N
+    g.M, g.N, g.K, g.groups = M, N, K, 1
+    g.epi = L.EPI_STORE
+    L.check(L.lib.dwn_gemm_nn(C.byref(g), L.DWN_BF16, a0.device.index, torch.cuda.current_stream().cuda_stream), "gemm_nn")
+    return c
+
+
+def _stored_vs_rebuilt(planes, Hin, Win, Cc, stride, rows_band=0, seed=0, cin=64):
+    d = dev()
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=d); g.manual_seed(seed)
+    Hout, Wout = (Hin - 1) // stride + 1, (Win - 1) // stride + 1
+    a0 = torch.randn(planes * Hin * Win, cin, device=d, generator=g).to(BF)
+    w1 = (torch.randn(Cc, cin, device=d, generator=g) / cin ** 0.5).to(BF)
+    y1 = _conv_pw(a0, w1)
+    dh2 = torch.randn(planes * Hout * Wout, Cc, device=d, generator=g).to(BF)
+    y2 = torch.randn(planes * Hout * Wout, Cc, device=d, generator=g).to(BF)
+    coef = torch.cat([torch.rand(Cc, device=d, generator=g) + 0.5, torch.randn(Cc, device=d, generator=g) * 0.3,
+                      torch.randn(Cc, device=d, generator=g) * 0.2, torch.rand(Cc, device=d, generator=g) + 0.5])
+    abc = torch.randn(3 * Cc, device=d, generator=g) * 0.5
+    w = (torch.randn(9, Cc, device=d, generator=g) / 3.0).to(BF).float()
+    out = {}
+    for mode in ("stored", "rebuilt"):
+        dh1 = torch.full((planes * Hin * Win, Cc), float("nan"), dtype=BF, device=d)
+        dw = torch.zeros(Cc, 9, device=d)
+        st = torch.zeros(32 * 2 * Cc, dtype=torch.float64, device=d)
+        a = L.DwSpatialBwdArgs()
+        a.dy = _desc(dh2, Cc, q=y2, v1=abc, v2=abc[Cc:], v3=abc[2 * Cc:])
+        a.y1 = _desc(y1, Cc, v1=coef, v2=coef[Cc:], v3=coef[2 * Cc:], v4=coef[3 * Cc:])
+        a.w = w.data_ptr(); a.dh1 = dh1.data_ptr(); a.dw = dw.data_ptr(); a.planes = planes; a.Hin = Hin; a.Win = Win
+        a.Hout = Hout; a.Wout = Wout; a.C = Cc; a.stride = stride; a.ks = 3; a.stats = st.data_ptr()
+        a.rows_band = rows_band
+        if mode == "rebuilt":
+            a.y1.p = None
+            a.a0 = a0.data_ptr(); a.a0_ld = cin; a.w1 = w1.data_ptr(); a.Cin = cin
+            assert L.lib.dwn_dw_spatial_bwd_rc_supported(C.byref(a), L.DWN_BF16) == 1
+        L.check(L.lib.dwn_dw_spatial_bwd(C.byref(a), L.DWN_BF16, d.index, s), "dwn_dw_spatial_bwd")
+        torch.cuda.synchronize()
+        out[mode] = (dh1, dw, st.view(32, 2, Cc).sum(0))
+    return out["stored"], out["rebuilt"]
+
+
+RC_CASES = [
+    # planes, Hin, Win, C (whole 64-channel slices), stride
+    (3, 18, 32, 64, 1), (5, 9, 16, 128, 1), (7, 5, 8, 64, 1), (9, 1, 8, 64, 1), (1, 20, 16, 64, 1), (2, 3, 32, 192, 1),
+    (3, 36, 64, 64, 2), (5, 18, 32, 128, 2), (7, 9, 16, 64, 2), (2, 4, 64, 128, 2), (9, 1, 16, 64, 2), (3, 7, 32, 64, 2),
+    (130, 9, 16, 448, 1), (130, 9, 16, 448, 2), (131, 5, 8, 448, 1), (129, 18, 32, 448, 2), (33, 18, 32, 448, 1), (40, 36, 64, 448, 2),
+]
+
+
+@pytest.mark.parametrize("case", RC_CASES)
+def test_rebuilt_y1_matches_stored_y1(case):
+    """Same kernels, y1 read from HBM vs rebuilt as a0 . W1^T by MFMA (rounded as the stored bf16 tensor): the rebuilt rows equal
+    conv_pw's output bit for bit, so dh1 is BIT-identical and the sums differ by summation order only."""
+    (d0, w0, s0), (d1, w1, s1) = _stored_vs_rebuilt(*case)
+    assert not torch.isnan(d1.float()).any()
+    assert torch.equal(d0.view(torch.int16), d1.view(torch.int16)), "dh1 differs"
+    assert float((w0 - w1).norm() / w0.norm()) < 1e-5
+    assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-5
+
+
+@pytest.mark.parametrize("stride,rows_band", [(1, 2), (1, 4), (2, 2), (2, 4), (2, 6), (2, 12)])
+def test_rebuilt_y1_band_heights(stride, rows_band):
+    H, W = (18, 32) if stride == 1 else (36, 64)
+    (d0, w0, s0), (d1, w1, s1) = _stored_vs_rebuilt(5, H, W, 128, stride, rows_band=rows_band, seed=3)
+    assert torch.equal(d0.view(torch.int16), d1.view(torch.int16))
+    assert float((w0 - w1).norm() / w0.norm()) < 1e-5
+
+
+def test_rebuilt_y1_is_refused_where_it_is_not_built():
+    a = L.DwSpatialBwdArgs()
+    a.planes, a.Hin, a.Win, a.Hout, a.Wout, a.C, a.stride, a.ks = 2, 18, 32, 18, 32, 72, 1, 3          # a channel tail
+    a.dy.ld = 72; a.y1.ld = 72; a.a0_ld = 64; a.Cin = 64
+    assert L.lib.dwn_dw_spatial_bwd_rc_supported(C.byref(a), L.DWN_BF16) == 0
+    a.C = 128; a.dy.ld = 128; a.y1.ld = 128; a.Cin = 128; a.a0_ld = 128                                   # Cin 128: not built
+    assert L.lib.dwn_dw_spatial_bwd_rc_supported(C.byref(a), L.DWN_BF16) == 0
+    a.Cin = 64; a.a0_ld = 64
+    assert L.lib.dwn_dw_spatial_bwd_rc_supported(C.byref(a), L.DWN_BF16) == 1
+    assert L.lib.dwn_dw_spatial_bwd_rc_supported(C.byref(a), L.DWN_F32) == 0

@@ -444,3 +444,42 @@ def test_pw_backward_gathered_shortcut(L, E, mult):
     assert rel(da0.view(F, Hin, Win, Cin)[skip], da1.view(F, Hin, Win, Cin)[skip].double()) < 2e-3
     assert rel(da0.view(F, Hin, Win, Cin)[~skip], da1.view(F, Hin, Win, Cin)[~skip].double()) > 5e-2     # the sampled rows did change
     assert rel(dw, dy.t() @ a0.double()) < 2e-4
+
+
+def test_conv_pw_batchnorm_statistics_from_the_gram_matrix(L):
+    """dwn_conv_pw_bn_stats: BatchNorm-1's batch statistics of y1 = a0 . W1^T from a0^T a0 and 1^T a0 (y1 never computed), against
+    float64 statistics of the product of the same rounded operands: mean / variance to 1e-6 (of the standard deviation / of the
+    variance), running statistics like nn.BatchNorm3d, and the shortcut BatchNorm's raw sums of a0."""
+    import ctypes as C
+    torch.manual_seed(5)
+    for dtype, M, E, Cin in ((torch.bfloat16, 40000, 448, 64), (torch.bfloat16, 9001, 896, 128), (torch.float32, 5000, 192, 64)):
+        # inputs with per-channel offsets (the positional encoding adds constants of order one) and unequal scales
+        a0 = (torch.randn(M, Cin, device=dev()) * (0.5 + torch.rand(Cin, device=dev())) + torch.randn(Cin, device=dev())).to(dtype)
+        w = torch.randn(E, Cin, device=dev()) / Cin ** 0.5
+        gamma = torch.rand(E, device=dev()) + 0.5
+        beta = torch.randn(E, device=dev()) * 0.2
+        rm = torch.randn(E, device=dev()) * 0.1
+        rv = torch.rand(E, device=dev()) + 0.5
+        rm0, rv0 = rm.clone(), rv.clone()
+        nbt = torch.zeros(1, dtype=torch.int64, device=dev())
+        coef = torch.empty(4 * E, device=dev())
+        sc = torch.zeros(32 * 2 * Cin, dtype=torch.float64, device=dev())
+        ws = torch.empty(L.lib.dwn_conv_pw_bn_stats_workspace_bytes(Cin), dtype=torch.uint8, device=dev())
+        bn = L.BN()
+        bn.gamma = gamma.data_ptr(); bn.beta = beta.data_ptr(); bn.running_mean = rm.data_ptr(); bn.running_var = rv.data_ptr()
+        bn.num_batches_tracked = nbt.data_ptr(); bn.coef = coef.data_ptr()
+        L.check(L.lib.dwn_conv_pw_bn_stats(a0.data_ptr(), Cin, M, w.data_ptr(), E, Cin, C.byref(bn), 0.1, 1e-5, sc.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), _dt(L, dtype), 0, stream()), "conv_pw_bn_stats")
+        torch.cuda.synchronize()
+        y = a0.double() @ w.to(dtype).double().t()
+        mean, var = y.mean(0), y.var(0, unbiased=False)
+        c = coef.view(4, E).double()
+        assert float(((c[2] - mean).abs() / var.sqrt()).max()) < 1e-6
+        invstd = 1.0 / (var + 1e-5).sqrt()
+        assert float(((c[3] - invstd).abs() / invstd).max()) < (1e-6 if dtype == torch.float32 else 3e-6)
+        assert rel(c[0], gamma.double() * invstd) < 1e-6 and rel(c[1], beta.double() - mean * gamma.double() * invstd) < 1e-5
+        assert rel(rm, 0.9 * rm0.double() + 0.1 * mean) < 1e-6
+        assert rel(rv, 0.9 * rv0.double() + 0.1 * var * M / (M - 1)) < 1e-6
+        assert int(nbt) == 1
+        s0, s1 = read_stats(sc, Cin)
+        assert rel(s0, a0.double().sum(0)) < 1e-6 and rel(s1, (a0.double() ** 2).sum(0)) < 1e-6
