@@ -152,6 +152,11 @@ typedef struct dwn_dw_spatial_fwd_args {
     int rows_band;      /* output rows per chunk / band; <= 0: chosen by the library */
     int impl;           /* 0: the library's choice (chained row-walk kernels where they apply); 1: the pair / generic kernels, the
                          * second implementation the tests compare bit for bit */
+    /* rebuilt-input mode (a0 != NULL; dwn_dw_spatial_fwd_rc_supported): in.p is NOT read — the kernel rebuilds the rows of
+     * y1 = a0 . w1^T it needs on the matrix cores, rounded to bf16 as conv_pw's stored output reads back (dwiseneuro.py:90-91),
+     * from the block input a0 [rows][a0_ld] (Cin channels) and w1 = conv_pw's weight [C][Cin] rounded to bf16, row-major;
+     * in.v1 / in.v2 (BatchNorm-1 scale / shift) as usual.  conv_pw + spat_covn_dw in one pass over a 7x narrower input. */
+    const void* a0; long long a0_ld; const void* w1; int Cin;
 } dwn_dw_spatial_fwd_args;
 
 typedef struct dwn_dw_spatial_bwd_args {
@@ -358,6 +363,8 @@ int dwn_gemm_nn(const dwn_gemm_nn_args* a, int dtype, int device, void* stream);
 int dwn_gemm_tn(const dwn_gemm_tn_args* a, int dtype, int device, void* stream);
 int dwn_dw_spatial_fwd(const dwn_dw_spatial_fwd_args* a, int dtype, int device, void* stream);
 int dwn_dw_spatial_bwd(const dwn_dw_spatial_bwd_args* a, int dtype, int device, void* stream);
+/* 1 when dwn_dw_spatial_fwd can run these arguments in rebuilt-input mode (bf16, Cin 64, C % 64 == 0, the row-walk plane widths) */
+int dwn_dw_spatial_fwd_rc_supported(const dwn_dw_spatial_fwd_args* a, int dtype);
 /* 1 when dwn_dw_spatial_bwd can run these arguments in rebuilt-y1 mode (bf16, Cin 64, C % 64 == 0, the row-walk plane widths) */
 int dwn_dw_spatial_bwd_rc_supported(const dwn_dw_spatial_bwd_args* a, int dtype);
 int dwn_dw_temporal_fwd(const dwn_dw_temporal_fwd_args* a, int dtype, int device, void* stream);

@@ -68,7 +68,8 @@ class GemmTNArgs(C.Structure):
 class DwSpatialFwdArgs(C.Structure):
     _fields_ = [("inp", LoadDesc), ("w", c_p), ("out", c_p), ("planes", c_i), ("Hin", c_i), ("Win", c_i),
                 ("Hout", c_i), ("Wout", c_i), ("C", c_i), ("stride", c_i), ("ks", c_i), ("stats", c_p),
-                ("rows_band", c_i), ("impl", c_i)]
+                ("rows_band", c_i), ("impl", c_i),
+                ("a0", c_p), ("a0_ld", c_ll), ("w1", c_p), ("Cin", c_i)]      # rebuilt-input mode (include/dwn.h)
 
 
 class DwSpatialBwdArgs(C.Structure):
@@ -195,6 +196,7 @@ SYMBOLS = {
     "dwn_dw_spatial_fwd": (c_i, [_P(DwSpatialFwdArgs), c_i, c_i, c_p]),
     "dwn_dw_spatial_bwd": (c_i, [_P(DwSpatialBwdArgs), c_i, c_i, c_p]),
     "dwn_dw_spatial_bwd_rc_supported": (c_i, [_P(DwSpatialBwdArgs), c_i]),
+    "dwn_dw_spatial_fwd_rc_supported": (c_i, [_P(DwSpatialFwdArgs), c_i]),
     "dwn_dw_temporal_fwd": (c_i, [_P(DwTemporalFwdArgs), c_i, c_i, c_p]),
     "dwn_dw_temporal_bwd": (c_i, [_P(DwTemporalBwdArgs), c_i, c_i, c_p]),
     "dwn_bn_finalize": (c_i, [c_p, c_i, c_d, _P(BN), c_i, c_i, c_f, c_f, c_i, c_p]),

@@ -16,6 +16,7 @@ extern "C" int dwn_dw_spatial_rc_prep(const float* w_pw, const float* w_dws, con
                                       int device, void* stream);
 extern "C" int dwn_dw_spatial_fwd_rc(const dwn_dw_spatial_rc_fwd_args* a, int device, void* stream);
 bool dw_spatial_bwd_rc_supported(const DwSpatialBwd& a, int dtype);          // dwn_dwbwd.hip
+bool dw_spatial_fwd_rc_walk_supported(const DwSpatialFwd& a, int dtype);     // dwn_dwfwd.hip
 
 int dwn_set_error(int code, const char* msg) {
     snprintf(g_err, sizeof(g_err), "dwn error %d: %s", code, msg ? msg : "");
@@ -198,23 +199,25 @@ static bool pwl_bwd_per_sample(const dwn_block_args& a) {
     return pb <= pass;
 }
 // Training WITHOUT a materialised y1 (round 5; dwn_block_args.y1_mode).  y1 = a0 . W1^T is the widest tensor of a block and a
-// Cin-deep product of one seven times narrower: the forward stencil rebuilds its tiles on the matrix cores (dwn_dwrc.hip) with
+// Cin-deep product of one seven times narrower: the forward stencil rebuilds its rows on the matrix cores (dwn_dwfwd.hip, CIN > 0) with
 // BatchNorm-1's batch statistics taken from the Gram matrix of a0 (k_bn1_gram_finalize), the backward stencil rebuilds the rows it
 // needs the same way (dwn_dwbwd.hip, CIN > 0), and conv_pw's backward has not read y1 since round 4 — so y1 is neither written nor
 // read: three E-wide passes over M_in rows less per block.  Both directions decide with this one predicate.
 static bool block_y1_free(const dwn_block_args& a) {
     if (!a.training || a.dtype != DWN_BF16 || a.y1_mode == 1) return false;
-    if (!dwn_dw_spatial_rc_supported(a.dtype, a.Cin, a.Cmid, a.ks, a.stride, a.Hin, a.Win)) return false;
+    DwSpatialFwd f; memset(&f, 0, sizeof(f));
+    f.planes = a.B * a.T; f.Hin = a.Hin; f.Win = a.Win; f.Hout = a.Hout; f.Wout = a.Wout; f.C = a.Cmid; f.stride = a.stride; f.ks = a.ks;
+    f.in.ld = a.Cmid; f.a0_ld = a.Cin; f.Cin = a.Cin;
+    if (!dw_spatial_fwd_rc_walk_supported(f, a.dtype)) return false;
     DwSpatialBwd d; memset(&d, 0, sizeof(d));
     d.planes = a.B * a.T; d.Hin = a.Hin; d.Win = a.Win; d.Hout = a.Hout; d.Wout = a.Wout; d.C = a.Cmid; d.stride = a.stride; d.ks = a.ks;
     d.dy.ld = a.Cmid; d.y1.ld = a.Cmid; d.a0_ld = a.Cin; d.Cin = a.Cin;
     if (!dw_spatial_bwd_rc_supported(d, a.dtype)) return false;
     return true;
 }
-// forward without conv_pw as its own pass: eval mode (BatchNorm-1 is known), or y1-free training
+// eval-mode forward without conv_pw as its own pass (BatchNorm-1 is known: the tile-resident stencil of dwn_dwrc.hip)
 static bool block_fwd_rc(const dwn_block_args& a) {
-    if (a.training) return block_y1_free(a);
-    return dwn_dw_spatial_rc_supported(a.dtype, a.Cin, a.Cmid, a.ks, a.stride, a.Hin, a.Win) != 0;
+    return !a.training && dwn_dw_spatial_rc_supported(a.dtype, a.Cin, a.Cmid, a.ks, a.stride, a.Hin, a.Win) != 0;
 }
 // floats of the conv_pw data-gradient folding scratch: G accumulator [Cin][Cin] and r3 [Cin]
 static size_t pw_fold_floats(int Cin) { return (size_t)Cin * Cin + Cin; }
@@ -227,7 +230,7 @@ BlockWs carve_block(const dwn_block_args& a, int backward, void* base, size_t ca
     w.wdws = c.take<float>((size_t)a.ks * a.ks * a.Cmid);
     w.wdwt = c.take<float>((size_t)a.kt * a.Cmid);
     if (!backward && pwl_gated_weights(a)) w.wgated = c.take<char>((size_t)a.B * a.Cout * a.Cmid * ts);
-    if (!backward && block_fwd_rc(a)) w.rcblob = c.take<char>(dwn_dw_spatial_rc_blob_bytes(a.Cmid, a.Cin));
+    if (!backward && block_fwd_rc(a)) w.rcblob = c.take<char>(dwn_dw_spatial_rc_blob_bytes(a.Cmid, a.Cin));      // eval only
     c.take<char>(0);
     size_t z0 = (c.off + 255) & ~(size_t)255;
     w.st1 = c.take<double>(nstat(a.Cmid));
@@ -342,6 +345,7 @@ int dwn_dw_spatial_bwd(const dwn_dw_spatial_bwd_args* a, int dtype, int device, 
     return launch_dw_spatial_bwd(*a, dtype, (hipStream_t)stream);
 }
 int dwn_dw_spatial_bwd_rc_supported(const dwn_dw_spatial_bwd_args* a, int dtype) { return dw_spatial_bwd_rc_supported(*a, dtype) ? 1 : 0; }
+int dwn_dw_spatial_fwd_rc_supported(const dwn_dw_spatial_fwd_args* a, int dtype) { return dw_spatial_fwd_rc_walk_supported(*a, dtype) ? 1 : 0; }
 int dwn_dw_temporal_fwd(const dwn_dw_temporal_fwd_args* a, int dtype, int device, void* stream) {
     ENTER(device);
     return launch_dw_temporal_fwd(*a, dtype, (hipStream_t)stream);
@@ -469,23 +473,29 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     LoadDesc xin = ld_plain(a0, a.Cin);
     const bool identity_sc = a.stride == 1 && a.Hin == a.Hout && a.Win == a.Wout;
     const bool y1_free = tr && block_y1_free(a);
-    if (block_fwd_rc(a)) {
+    if (y1_free) {
+        // y1-free training: BatchNorm-1's batch statistics from the Gram matrix of a0 (one C-wide pass: gemm_tn [a0 | 1]^T a0), then the
+        // chained stencil rebuilds the y1 rows it needs from a0 on the matrix cores: conv_pw is no pass, a.y1 is not written
+        LoadDesc cat = ld_plain(a0, a.Cin);
+        cat.cat_c1 = a.Cin; cat.cat_c2 = 0;
+        GemmTN g = tn_base(cat, LD_CAT1, ld_plain(a0, a.Cin), LD_PLAIN, (int)Min, a.Cin + 8, a.Cin, w.gram, a.Cin, 1);
+        PROF(DWN_FAM_PW_FWD, launch_gemm_tn(g, dt, s));
+        PROF(DWN_FAM_PW_FWD, k_bn1_gram_finalize(w.gram, a.w_pw, a.Cmid, a.Cin, (double)Min, a.bn1.gamma, a.bn1.beta, a.bn1.running_mean,
+                                                 a.bn1.running_var, a.bn1.num_batches_tracked, a.momentum, a.eps, a.bn1.coef,
+                                                 identity_sc ? w.stsc : nullptr, dt, s));
+        DwSpatialFwd d; memset(&d, 0, sizeof(d));
+        d.in = ld_bnact(nullptr, a.Cmid, a.bn1.coef, a.Cmid, 1, nullptr, 0, 1);
+        d.a0 = a0; d.a0_ld = a.Cin; d.w1 = w.wpw; d.Cin = a.Cin;
+        d.w = w.wdws; d.out = a.y2; d.planes = a.B * a.T; d.Hin = a.Hin; d.Win = a.Win; d.Hout = a.Hout;
+        d.Wout = a.Wout; d.C = a.Cmid; d.stride = a.stride; d.ks = a.ks; d.stats = w.st2;
+        PROF(DWN_FAM_DWS_FWD, launch_dw_spatial_fwd(d, dt, s));
+    } else if (block_fwd_rc(a)) {
         // eval: BatchNorm-1 needs no batch statistics and nobody reads y1 again, so the stencil kernel rebuilds its y1
         // tiles from a0 (MFMA) and conv_pw disappears as a pass (a.y1 is not written)
-        // y1-free training: the same, with BatchNorm-1's batch statistics from the Gram matrix of a0 (one C-wide pass)
-        if (y1_free) {
-            LoadDesc cat = ld_plain(a0, a.Cin);
-            cat.cat_c1 = a.Cin; cat.cat_c2 = 0;
-            GemmTN g = tn_base(cat, LD_CAT1, ld_plain(a0, a.Cin), LD_PLAIN, (int)Min, a.Cin + 8, a.Cin, w.gram, a.Cin, 1);
-            PROF(DWN_FAM_PW_FWD, launch_gemm_tn(g, dt, s));
-            PROF(DWN_FAM_PW_FWD, k_bn1_gram_finalize(w.gram, a.w_pw, a.Cmid, a.Cin, (double)Min, a.bn1.gamma, a.bn1.beta, a.bn1.running_mean,
-                                                     a.bn1.running_var, a.bn1.num_batches_tracked, a.momentum, a.eps, a.bn1.coef,
-                                                     identity_sc ? w.stsc : nullptr, dt, s));
-        }
         TRY(dwn_dw_spatial_rc_prep(a.w_pw, w.wdws, a.bn1.coef, a.Cmid, a.Cin, w.rcblob, device, stream));
         dwn_dw_spatial_rc_fwd_args r; memset(&r, 0, sizeof(r));
         r.a0 = a0; r.a0_ld = a.Cin; r.blob = w.rcblob; r.out = a.y2; r.planes = a.B * a.T; r.Hin = a.Hin; r.Win = a.Win;
-        r.Hout = a.Hout; r.Wout = a.Wout; r.Cin = a.Cin; r.E = a.Cmid; r.stride = a.stride; r.stats = tr ? w.st2 : nullptr;
+        r.Hout = a.Hout; r.Wout = a.Wout; r.Cin = a.Cin; r.E = a.Cmid; r.stride = a.stride; r.stats = nullptr;
         r.rows_band = 0; r.round_y1 = 1;
         PROF(DWN_FAM_DWS_FWD, dwn_dw_spatial_fwd_rc(&r, device, stream));
     } else {

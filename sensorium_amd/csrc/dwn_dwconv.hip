@@ -1091,6 +1091,8 @@ static int spatial_fwd_t(DwSpatialFwd a, hipStream_t s) {
 bool dw_spatial_fwd_walk_supported(const DwSpatialFwd& a, int dtype);
 int launch_dw_spatial_fwd_walk(const DwSpatialFwd& a, hipStream_t s);
 int launch_dw_spatial_fwd(const DwSpatialFwd& a, int dtype, hipStream_t s) {
+    if (a.a0 && !dw_spatial_fwd_walk_supported(a, dtype))
+        return dwn_set_error(-3, "dw_spatial_fwd: rebuilt-input mode (a0 != NULL) is built into the chained row-walk kernels only (dwn_dw_spatial_fwd_rc_supported)");
     if (dw_spatial_fwd_walk_supported(a, dtype)) return launch_dw_spatial_fwd_walk(a, s);     // row-walk kernels (dwn_dwfwd.hip)
     return dtype == DWN_BF16 ? spatial_fwd_t<bf16_t>(a, s) : spatial_fwd_t<float>(a, s);
 }

@@ -13,6 +13,7 @@
 
 extern __shared__ __attribute__((aligned(16))) unsigned char wf_smem[];
 
+
 typedef float wf_f2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(2))) __bf16 wf_bf16x2_t;
 typedef unsigned wf_u32x2_t __attribute__((ext_vector_type(2)));
@@ -20,6 +21,31 @@ typedef unsigned wf_u32x2_t __attribute__((ext_vector_type(2)));
 #ifndef WF_MINW
 #define WF_MINW 3
 #endif
+#define WF_MINW_RC4 3      // ... chunks of 4 input rows fit three
+#ifndef WF_MINW_RC
+#define WF_MINW_RC 2       // the y1-rebuilding form keeps 32 registers of W1 fragments: chunks of 8 input rows need two waves per SIMD
+#endif
+typedef __attribute__((ext_vector_type(8))) short wf_bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float wf_f32x4_t;
+__device__ __forceinline__ wf_f32x4_t wf_mfma(const uint4& a, const uint4& b, const wf_f32x4_t& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wf_bf16x8_t, a), __builtin_bit_cast(wf_bf16x8_t, b), c, 0, 0, 0);
+}
+// workgroup -> (plane-group start, channel slice); XCD = true: the slices of a plane group are consecutive workgroups of one XCD
+// (dwn_dwbwd.hip wk_block: what they all read — the block input a0 — is fetched into that L2 once).  gridDim.x % 8 == 0.
+struct WfBlk { int x, y; };
+template <bool XCD>
+__device__ __forceinline__ WfBlk wf_block() {
+    WfBlk r;
+    if constexpr (XCD) {
+        const int gx = (int)gridDim.x, ns = (int)gridDim.y;
+        const int b = (int)blockIdx.y * gx + (int)blockIdx.x;
+        const int xcd = b & 7, i = b >> 3;
+        r.y = i % ns; r.x = (i / ns) * 8 + xcd;
+    } else {
+        r.x = (int)blockIdx.x; r.y = (int)blockIdx.y;
+    }
+    return r;
+}
 
 __device__ __forceinline__ float wf_dot2(unsigned a, unsigned b, float c) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wf_bf16x2_t, a), __builtin_bit_cast(wf_bf16x2_t, b), c, false);
@@ -52,20 +78,30 @@ __device__ __forceinline__ void wf_lds_barrier() {
 //   stride 2: chunk c stages input rows 2s .. 2s+2RB-1 and produces output rows s .. s+RB-1;          ring of 2RB+1 rows
 // ring slot of input row r = (r + 1) mod RQ; row -1 (slot 0) is the zero row above the plane.
 // ------------------------------------------------------------------------------------------------
-template <int ST, int LPW, int RB>
-__global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(const DwSpatialFwd a) {
+// CIN > 0 (round 5): the input is NOT read — a.in.p is ignored and the activated rows are REBUILT from the block input a0 (a.a0,
+// CIN channels) as SiLU(BN1(round_bf16(a0 . W1^T))) on the matrix cores: per input row of the plane group a wave runs
+// v_mfma_f32_16x16x32_bf16 on the even-x and on the odd-x pixels (W1 fragments in registers, a0 fragments straight from L2),
+// activates the accumulators (a lane holds 4 consecutive channels of one pixel) and builds the ring's pair dwords
+// (x = 2k-1, x = 2k) with one lane shift of the odd pixel's half.  Pairs are PS = 68 dwords apart in that form (a lane group
+// of the MFMA layout writes 8 consecutive pairs: 64-dword pairs would all land on the same banks).  y2 is bit-identical to
+// conv_pw + this kernel's CIN = 0 form: same MFMA operand roles and k order as the GEMM, same rounding, same stencil.
+template <int ST, int LPW, int RB, int CIN>
+__global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 ? WF_MINW_RC4 : WF_MINW_RC) : WF_MINW) void dw_spatial_fwd_chain_kernel(const DwSpatialFwd a) {
     typedef bf16_t T;
     constexpr int NT = 256, CS = 64, NG = 16 / LPW, NPC = ST * LPW + 1;
+    constexpr int PS = CIN > 0 ? 68 : 64;                // dwords between consecutive pairs of a ring row
     constexpr int NWC = ST == 1 ? 4 : 2;
     constexpr int NR = ST * RB;                          // input rows staged per chunk
     constexpr int RQ = ST == 1 ? RB + 2 : 2 * RB + 1;
-    constexpr int rowdw = NPC * CS;
+    constexpr int rowdw = NPC * PS;
+    constexpr int KB = CIN > 0 ? CIN / 32 : 1;
     __shared__ float lstat[2 * CS];
     __shared__ __attribute__((aligned(16))) float lcoef[2 * CS];             // BatchNorm-1 scale, shift (re-read per phase: registers)
     const int tid = threadIdx.x, lane = tid & 63;
     const int cv = tid & 15, pl = tid >> 4;
     const int grp = pl / LPW, jj = pl % LPW;
-    const int c0 = blockIdx.y * CS;
+    const WfBlk blk = wf_block<(CIN > 0)>();
+    const int c0 = blk.y * CS;
     const int chan = c0 + cv * 4;
     const bool chan_ok = chan < a.C;
     const int chs = chan_ok ? chan : 0;
@@ -105,6 +141,7 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(cons
     T* outp = reinterpret_cast<T*>(a.out);
     unsigned* tile = reinterpret_cast<unsigned*>(wf_smem);        // ring: [NG][RQ][NPC][64] dwords
     unsigned* tplane = tile + grp * RQ * rowdw + cv * 4;
+    static_assert(CIN == 0 || CIN == 64, "the y1-rebuilding form is built for 64 input channels");
     const unsigned inrow = (unsigned)Win * (unsigned)a.in.ld, outrow = (unsigned)Wout * (unsigned)a.C;
     // staging roles: stride 1 = the walk role (4 channels, own output pair column); stride 2 = 8 channels per lane, one lane
     // per input pair column (16-byte loads)
@@ -121,7 +158,24 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(cons
     constexpr int NLC = ST == 1 ? LPW : SLW;                      // staging lanes per plane row
     constexpr int NEX = (NR + NLC - 1) / NLC;                     // halo-column rows a lane stages per chunk
 
-    for (int pg = blockIdx.x; pg < ngroups; pg += gridDim.x) {
+    // ---- rebuilt input (CIN > 0): lane (lr, lg) of an MFMA = (pixel column lr of the 16-pixel tile, k group lg) for the a0 operand and
+    // (channel row lr of channel tile n, k group lg) for W1; accumulator register j = channel 16 n + 4 lg + j of pixel lr
+    const int lr = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint4 wfr[4][KB];
+    if constexpr (CIN > 0) {
+        const T* w1 = reinterpret_cast<const T*>(a.w1);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int ch = c0 + 16 * n + lr;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                wfr[n][kb] = *reinterpret_cast<const uint4*>(w1 + (i64)(ch < a.C ? ch : c0) * CIN + 8 * lg + 32 * kb);
+        }
+    }
+    (void)lr; (void)lg; (void)wave;
+
+    for (int pg = blk.x; pg < ngroups; pg += gridDim.x) {
         const int plane = pg * NG + grp;
         const bool pvalid = plane < a.planes && chan_ok;
         const int splane = pg * NG + sgrp;
@@ -130,11 +184,11 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(cons
         T* out0 = outp + (i64)(plane < a.planes ? plane : 0) * Hout * Wout * a.C + chan + (unsigned)(2 * jj) * (unsigned)a.C;
         // row -1 of the ring (slot 0): zeros
         {
-            unsigned* z = splane_t + kc * CS;
+            unsigned* z = splane_t + kc * PS;
             if constexpr (ST == 1) *reinterpret_cast<uint4*>(z) = make_uint4(0, 0, 0, 0);
             else { reinterpret_cast<uint4*>(z)[0] = make_uint4(0, 0, 0, 0); reinterpret_cast<uint4*>(z)[1] = make_uint4(0, 0, 0, 0); }
             if (kc == 0) {
-                unsigned* zl = splane_t + (NPC - 1) * CS;
+                unsigned* zl = splane_t + (NPC - 1) * PS;
                 if constexpr (ST == 1) *reinterpret_cast<uint4*>(zl) = make_uint4(0, 0, 0, 0);
                 else { reinterpret_cast<uint4*>(zl)[0] = make_uint4(0, 0, 0, 0); reinterpret_cast<uint4*>(zl)[1] = make_uint4(0, 0, 0, 0); }
             }
@@ -144,7 +198,88 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(cons
             const int s = chunk * RB;
             const int hi_s = ST * s;                     // first input row staged by this chunk
             // ---------------- stage SiLU(BN1(y1)) rows hi_s .. hi_s + NR - 1, x-pair-packed, into their ring slots
-            if constexpr (ST == 1) {
+            if constexpr (CIN > 0) {
+                // ---------------- rebuild SiLU(BN1(y1)) of input rows hi_s .. hi_s + NR - 1 from a0: wave w takes rows w, w + 4, ...
+                constexpr int TP = ST;                       // 32-pixel MFMA tile pairs (even-x, odd-x) per plane-group row
+                constexpr int WIN = 2 * ST * LPW;            // pixels per plane row
+                const T* a0p = reinterpret_cast<const T*>(a.a0);
+                const unsigned a0ld = (unsigned)a.a0_ld;
+                for (int u = wave; u < NR; u += 4) {
+                    const int hi = hi_s + u;
+                    int sl = slot_s + u; sl = sl >= RQ ? sl - RQ : sl;
+#pragma unroll
+                    for (int t = 0; t < TP; ++t) {
+                        const int gxp = 32 * t + 2 * lr;     // even pixel of this lane in the plane-group row
+                        const int g = gxp / WIN, x = gxp % WIN;
+                        const int pln = pg * NG + g;
+                        const bool okp = pln < a.planes && hi < Hin;
+                        const T* src = a0p + ((i64)(pln < a.planes ? pln : 0) * Hin + (hi < Hin ? hi : Hin - 1)) * Win * (i64)a0ld +
+                                       (unsigned)x * a0ld + 8 * lg;
+                        uint4 bE[KB], bO[KB];
+#pragma unroll
+                        for (int kb = 0; kb < KB; ++kb) {
+                            bE[kb] = *reinterpret_cast<const uint4*>(src + 32 * kb);
+                            bO[kb] = *reinterpret_cast<const uint4*>(src + a0ld + 32 * kb);
+                        }
+                        unsigned* dst = tile + ((g * RQ + sl) * NPC + (x >> 1)) * PS + 4 * lg;
+                        const bool lo_shift = x != 0;                              // pair (x-1, x): x = 0 pairs with the halo
+                        const bool hi_only = TP == 2 && lr == 0 && x != 0;         // the odd neighbour sits in the previous tile's lane 15
+                        const bool extra = x == WIN - 2 || lr == 15;              // this lane's odd pixel opens the next pair
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            wf_f32x4_t aE = {0.f, 0.f, 0.f, 0.f}, aO = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int kb = 0; kb < KB; ++kb) { aE = wf_mfma(wfr[n][kb], bE[kb], aE); aO = wf_mfma(wfr[n][kb], bO[kb], aO); }
+                            const float4 s4 = *reinterpret_cast<const float4*>(&lcoef[16 * n + 4 * lg]);
+                            const float4 t4 = *reinterpret_cast<const float4*>(&lcoef[CS + 16 * n + 4 * lg]);
+                            // Packed math over CHANNEL pairs (j, j + 1) with their own coefficient pairs, written out as float2.  Left to
+                            // itself hipcc's SLP pass packs (even pixel, odd pixel) of ONE channel and broadcasts that channel's scale /
+                            // shift with  v_pk_fma_f32 ... op_sel:[0,1,1]  (the low lane reads the HIGH register of the coefficient
+                            // pair) — and that instruction returned, about once in 10^4 executions on gfx950, a wrong low-lane result in
+                            // lanes 48-63 (tools/dbg_fcr2.py: the odd pixels of channel 16 n + 13 of a whole row read SiLU(0)).  Not a
+                            // wait-state problem (s_nop padding, tied MFMA accumulators, asm-fenced DPP moves changed nothing); gone with
+                            // -fno-slp-vectorize and gone in this form, whose ISA has no op_sel on a low lane.
+                            const wf_f2_t sc2[2] = {wf_f2_t{s4.x, s4.y}, wf_f2_t{s4.z, s4.w}}, sh2[2] = {wf_f2_t{t4.x, t4.y}, wf_f2_t{t4.z, t4.w}};
+                            unsigned d[4], e[4], dd[4];
+#ifdef WF_REPRO_PK_OPSEL      // the scalar form that SLP turns into the op_sel:[0,1,1] instruction (reproducer: tools/dbg_fcr2.py)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float scj = j == 0 ? s4.x : j == 1 ? s4.y : j == 2 ? s4.z : s4.w, shj = j == 0 ? t4.x : j == 1 ? t4.y : j == 2 ? t4.z : t4.w;
+                                const unsigned pk = pk_bf16(aE[j], aO[j]);
+                                const float hE = fmaf(__uint_as_float(pk << 16), scj, shj), hO = fmaf(__uint_as_float(pk & 0xffff0000u), scj, shj);
+                                dd[j] = pk_bf16(hO * sigmoidf_(hO), hE * sigmoidf_(hE));
+                            }
+#else
+#pragma unroll
+                            for (int jp = 0; jp < 2; ++jp) {
+                                const unsigned pk0 = pk_bf16(aE[2 * jp], aO[2 * jp]), pk1 = pk_bf16(aE[2 * jp + 1], aO[2 * jp + 1]);   // y1 as stored
+                                const wf_f2_t yE = wf_f2_t{__uint_as_float(pk0 << 16), __uint_as_float(pk1 << 16)};
+                                const wf_f2_t yO = wf_f2_t{__uint_as_float(pk0 & 0xffff0000u), __uint_as_float(pk1 & 0xffff0000u)};
+                                const wf_f2_t hE = yE * sc2[jp] + sh2[jp], hO = yO * sc2[jp] + sh2[jp];
+                                const wf_f2_t zE = hE * wf_f2_t{sigmoidf_(hE.x), sigmoidf_(hE.y)};
+                                const wf_f2_t zO = hO * wf_f2_t{sigmoidf_(hO.x), sigmoidf_(hO.y)};
+                                dd[2 * jp] = pk_bf16(zO.x, zE.x);                    // (odd x, even x)
+                                dd[2 * jp + 1] = pk_bf16(zO.y, zE.y);
+                            }
+#endif
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                // lane - 1's dword (row_shr:1; lane 0 of a 16-lane row gets 0): its low half is this pair's odd pixel
+                                const unsigned prev = (unsigned)__builtin_amdgcn_update_dpp(0, (int)dd[j], 0x111, 0xf, 0xf, false);
+                                d[j] = okp ? ((dd[j] & 0xffff0000u) | (lo_shift ? (prev & 0xffffu) : 0u)) : 0u;
+                                e[j] = okp ? (dd[j] & 0xffffu) : 0u;
+                            }
+                            if (hi_only) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) reinterpret_cast<unsigned short*>(dst + 16 * n + j)[1] = (unsigned short)(d[j] >> 16);
+                            } else {
+                                *reinterpret_cast<uint4*>(dst + 16 * n) = make_uint4(d[0], d[1], d[2], d[3]);
+                            }
+                            if (extra) *reinterpret_cast<uint4*>(dst + PS + 16 * n) = make_uint4(e[0], e[1], e[2], e[3]);
+                        }
+                    }
+                }
+            } else if constexpr (ST == 1) {
                 const float4 s4 = *reinterpret_cast<const float4*>(&lcoef[cv * 4]), t4 = *reinterpret_cast<const float4*>(&lcoef[CS + cv * 4]);
                 const wf_f2_t bs2[2] = {wf_f2_t{s4.x, s4.y}, wf_f2_t{s4.z, s4.w}}, bt2[2] = {wf_f2_t{t4.x, t4.y}, wf_f2_t{t4.z, t4.w}};
                 auto act_pack = [&](const uint2& rlo, const uint2& rhi) {
@@ -185,7 +320,7 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(cons
                     uint4 o = act_pack(rr[u][0], rr[u][1]);
                     const unsigned m = ok[u] ? cmask : 0u;
                     o.x &= m; o.y &= m; o.z &= m; o.w &= m;
-                    *reinterpret_cast<uint4*>(splane_t + kc * CS + sl * rowdw) = o;
+                    *reinterpret_cast<uint4*>(splane_t + kc * PS + sl * rowdw) = o;
                     sl = sl + 1 == RQ ? 0 : sl + 1;
                 }
 #pragma unroll
@@ -196,7 +331,7 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(cons
                         const unsigned m = eok[e] ? 0x0000ffffu : 0u;
                         o.x &= m; o.y &= m; o.z &= m; o.w &= m;
                         int se = slot_s + u; se = se >= RQ ? se - RQ : se;
-                        *reinterpret_cast<uint4*>(splane_t + (NPC - 1) * CS + se * rowdw) = o;
+                        *reinterpret_cast<uint4*>(splane_t + (NPC - 1) * PS + se * rowdw) = o;
                     }
                 }
             } else {
@@ -242,7 +377,7 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(cons
                 int sl = slot_s;
 #pragma unroll
                 for (int u = 0; u < NR; ++u) {
-                    act_pack8(rr[u][0], rr[u][1], ok[u] ? cmask : 0u, splane_t + kc * CS + sl * rowdw);
+                    act_pack8(rr[u][0], rr[u][1], ok[u] ? cmask : 0u, splane_t + kc * PS + sl * rowdw);
                     sl = sl + 1 == RQ ? 0 : sl + 1;
                 }
 #pragma unroll
@@ -250,7 +385,7 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(cons
                     const int u = kc + e * NLC;
                     if (u < NR) {
                         int se = slot_s + u; se = se >= RQ ? se - RQ : se;
-                        act_pack8(er[e], er[e], eok[e] ? 0x0000ffffu : 0u, splane_t + (NPC - 1) * CS + se * rowdw);
+                        act_pack8(er[e], er[e], eok[e] ? 0x0000ffffu : 0u, splane_t + (NPC - 1) * PS + se * rowdw);
                     }
                 }
             }
@@ -259,7 +394,7 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(cons
             const int o_lo = ST == 1 ? (s > 0 ? s - 1 : 0) : s;
             const int o_hi = ST == 1 ? (s + RB - 1 < Hout ? s + RB - 1 : Hout) : (s + RB < Hout ? s + RB : Hout);      // exclusive
             if (pvalid && o_lo < o_hi) {
-                const unsigned* tc = tplane + (ST == 1 ? jj : 2 * jj) * CS;       // first ring pair of this output pair
+                const unsigned* tc = tplane + (ST == 1 ? jj : 2 * jj) * PS;       // first ring pair of this output pair
                 auto finish = [&](const int oy, const float* acc0, const float* acc1) {
                     T* dst = out0 + (unsigned)oy * outrow;
                     const uint2 pk0 = make_uint2(pk_bf16(acc0[0], acc0[1]), pk_bf16(acc0[2], acc0[3]));
@@ -278,11 +413,11 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(cons
                     const int sl1 = sl0 + 1 == RQ ? 0 : sl0 + 1;
                     int sl2 = sl1 + 1 == RQ ? 0 : sl1 + 1;
                     uint4 tw[3][2];
-                    tw[0][0] = *reinterpret_cast<const uint4*>(tc + sl0 * rowdw); tw[0][1] = *reinterpret_cast<const uint4*>(tc + sl0 * rowdw + CS);
-                    tw[1][0] = *reinterpret_cast<const uint4*>(tc + sl1 * rowdw); tw[1][1] = *reinterpret_cast<const uint4*>(tc + sl1 * rowdw + CS);
+                    tw[0][0] = *reinterpret_cast<const uint4*>(tc + sl0 * rowdw); tw[0][1] = *reinterpret_cast<const uint4*>(tc + sl0 * rowdw + PS);
+                    tw[1][0] = *reinterpret_cast<const uint4*>(tc + sl1 * rowdw); tw[1][1] = *reinterpret_cast<const uint4*>(tc + sl1 * rowdw + PS);
                     auto row_step = [&](const int oy, const uint4 (&t0)[2], const uint4 (&t1)[2], uint4 (&t2)[2]) {
                         t2[0] = *reinterpret_cast<const uint4*>(tc + sl2 * rowdw);
-                        t2[1] = *reinterpret_cast<const uint4*>(tc + sl2 * rowdw + CS);
+                        t2[1] = *reinterpret_cast<const uint4*>(tc + sl2 * rowdw + PS);
                         sl2 = sl2 + 1 == RQ ? 0 : sl2 + 1;
                         float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -310,14 +445,14 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(cons
                     int sa = slot_s - 1; sa = sa < 0 ? sa + RQ : sa;
                     uint4 ta[3], tb[3], tcw[3];
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) ta[m] = *reinterpret_cast<const uint4*>(tc + sa * rowdw + m * CS);
+                    for (int m = 0; m < 3; ++m) ta[m] = *reinterpret_cast<const uint4*>(tc + sa * rowdw + m * PS);
                     auto row_step = [&](const int oy, const uint4 (&r0)[3], uint4 (&r1)[3], uint4 (&r2)[3]) {
                         const int sb = sa + 1 >= RQ ? sa + 1 - RQ : sa + 1;
                         const int sc = sb + 1 >= RQ ? sb + 1 - RQ : sb + 1;
 #pragma unroll
                         for (int m = 0; m < 3; ++m) {
-                            r1[m] = *reinterpret_cast<const uint4*>(tc + sb * rowdw + m * CS);
-                            r2[m] = *reinterpret_cast<const uint4*>(tc + sc * rowdw + m * CS);
+                            r1[m] = *reinterpret_cast<const uint4*>(tc + sb * rowdw + m * PS);
+                            r2[m] = *reinterpret_cast<const uint4*>(tc + sc * rowdw + m * PS);
                         }
                         sa = sc;
                         float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -370,7 +505,7 @@ __global__ __launch_bounds__(256, WF_MINW) void dw_spatial_fwd_chain_kernel(cons
         DET_ENTER();
         if (tid < 2 * CS) {
             const int which = tid / CS, c = c0 + tid % CS;
-            if (c < a.C) stat_add(a.stats, (int)(blockIdx.x % DWN_NREP), a.C, which, c, lstat[tid]);
+            if (c < a.C) stat_add(a.stats, (int)(blk.x % DWN_NREP), a.C, which, c, lstat[tid]);
         }
     }
     DET_EXIT();
@@ -388,11 +523,20 @@ bool dw_spatial_fwd_walk_supported(const DwSpatialFwd& a, int dtype) {
     return true;
 }
 
-template <int ST, int LPW, int RB>
+// rebuilt-input mode (a.a0 != NULL): bf16, Cin = 64, whole 64-channel slices (an MFMA needs every lane of the wave)
+bool dw_spatial_fwd_rc_walk_supported(const DwSpatialFwd& a, int dtype) {
+    if (!dw_spatial_fwd_walk_supported(a, dtype)) return false;
+    if (a.Cin != 64 || a.C % 64) return false;
+    if (a.a0_ld % 8 || a.a0_ld < a.Cin) return false;
+    if ((i64)a.Hin * a.Win * a.a0_ld >= (1ll << 31)) return false;
+    return true;
+}
+
+template <int ST, int LPW, int RB, int CIN>
 static int launch_fc(const DwSpatialFwd& a, hipStream_t s) {
     constexpr int NG = 16 / LPW, NPC = ST * LPW + 1, RQ = ST == 1 ? RB + 2 : 2 * RB + 1;
-    const size_t lds = (size_t)NG * RQ * NPC * 256;
-    auto kern = dw_spatial_fwd_chain_kernel<ST, LPW, RB>;
+    const size_t lds = (size_t)NG * RQ * NPC * (CIN > 0 ? 272 : 256);
+    auto kern = dw_spatial_fwd_chain_kernel<ST, LPW, RB, CIN>;
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         (void)hipGetLastError();
     int bpc = 0;
@@ -402,34 +546,57 @@ static int launch_fc(const DwSpatialFwd& a, hipStream_t s) {
     i64 gx = (256 * bpc) / slices;
     if (gx < 1) gx = 1;
     if (gx > work) gx = work;
+    if (CIN > 0) gx = gx >= 8 ? (gx & ~(i64)7) : 8;   // wf_block<true>: the slices of a plane group share an XCD
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, slices), dim3(256), lds, s, a);
     DWN_CHECK_LAUNCH();
     return 0;
 }
-// output rows per chunk: a.rows_band, or the measured best at the metric shapes (tools/fwd_chain_check.py)
-template <int ST, int LPW>
+// output rows per chunk: a.rows_band, or the measured best at the metric shapes (tools/fwd_chain_check.py).  The rebuilt-input
+// form stages whole input rows per wave: chunks of 4 or 8 input rows
+template <int ST, int LPW, int CIN>
 static int launch_fc_rb(const DwSpatialFwd& a, hipStream_t s) {
-    const int rb = a.rows_band > 0 ? a.rows_band : (ST == 1 ? (LPW == 16 ? 4 : 6) : (LPW == 4 ? 1 : 2));
-    if constexpr (ST == 1) {
-        if (rb <= 2) return launch_fc<1, LPW, 2>(a, s);
-        if (rb <= 4) return launch_fc<1, LPW, 4>(a, s);
-        if (rb <= 6) return launch_fc<1, LPW, 6>(a, s);
-        return launch_fc<1, LPW, 8>(a, s);
+    if constexpr (CIN > 0) {
+        const int rb = a.rows_band > 0 ? a.rows_band : (ST == 1 ? 4 : 2);
+        if constexpr (ST == 1) {
+            if (rb <= 4) return launch_fc<1, LPW, 4, CIN>(a, s);
+            return launch_fc<1, LPW, 8, CIN>(a, s);
+        } else {
+            if (rb <= 2) return launch_fc<2, LPW, 2, CIN>(a, s);
+            return launch_fc<2, LPW, 4, CIN>(a, s);
+        }
     } else {
-        if (rb <= 1) return launch_fc<2, LPW, 1>(a, s);
-        if (rb <= 2) return launch_fc<2, LPW, 2>(a, s);
-        if (rb <= 3) return launch_fc<2, LPW, 3>(a, s);
-        return launch_fc<2, LPW, 4>(a, s);
+        const int rb = a.rows_band > 0 ? a.rows_band : (ST == 1 ? (LPW == 16 ? 4 : 6) : (LPW == 4 ? 1 : 2));
+        if constexpr (ST == 1) {
+            if (rb <= 2) return launch_fc<1, LPW, 2, 0>(a, s);
+            if (rb <= 4) return launch_fc<1, LPW, 4, 0>(a, s);
+            if (rb <= 6) return launch_fc<1, LPW, 6, 0>(a, s);
+            return launch_fc<1, LPW, 8, 0>(a, s);
+        } else {
+            if (rb <= 1) return launch_fc<2, LPW, 1, 0>(a, s);
+            if (rb <= 2) return launch_fc<2, LPW, 2, 0>(a, s);
+            if (rb <= 3) return launch_fc<2, LPW, 3, 0>(a, s);
+            return launch_fc<2, LPW, 4, 0>(a, s);
+        }
     }
 }
 
-int launch_dw_spatial_fwd_walk(const DwSpatialFwd& a, hipStream_t s) {
+template <int CIN>
+static int launch_fwd_walk_c(const DwSpatialFwd& a, hipStream_t s) {
     if (a.stride == 1) {
-        if (a.Wout == 32) return launch_fc_rb<1, 16>(a, s);
-        if (a.Wout == 16) return launch_fc_rb<1, 8>(a, s);
-        return launch_fc_rb<1, 4>(a, s);
+        if (a.Wout == 32) return launch_fc_rb<1, 16, CIN>(a, s);
+        if (a.Wout == 16) return launch_fc_rb<1, 8, CIN>(a, s);
+        return launch_fc_rb<1, 4, CIN>(a, s);
     }
-    if (a.Wout == 32) return launch_fc_rb<2, 16>(a, s);
-    if (a.Wout == 16) return launch_fc_rb<2, 8>(a, s);
-    return launch_fc_rb<2, 4>(a, s);
+    if (a.Wout == 32) return launch_fc_rb<2, 16, CIN>(a, s);
+    if (a.Wout == 16) return launch_fc_rb<2, 8, CIN>(a, s);
+    return launch_fc_rb<2, 4, CIN>(a, s);
+}
+
+int launch_dw_spatial_fwd_walk(const DwSpatialFwd& a, hipStream_t s) {
+    if (a.a0) {
+        if (!dw_spatial_fwd_rc_walk_supported(a, DWN_BF16) || !a.w1)
+            return dwn_set_error(-3, "dw_spatial_fwd: rebuilt-input mode needs bf16, Cin = 64, C % 64 == 0, w1 and a row-walk plane width");
+        return launch_fwd_walk_c<64>(a, s);
+    }
+    return launch_fwd_walk_c<0>(a, s);
 }

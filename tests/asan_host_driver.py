@@ -77,7 +77,11 @@ for cin in (64, 128, 72):
                         d.planes = 3; d.Hin = hin; d.Win = win; d.Hout = (hin - 1) // st + 1; d.Wout = (win - 1) // st + 1
                         d.C = cmid; d.stride = st; d.ks = 3; d.dy.ld = cmid; d.y1.ld = cmid; d.a0_ld = cin; d.Cin = cin
                         assert lib.dwn_dw_spatial_bwd_rc_supported(C.byref(d), dtype) in (0, 1)
-                        calls += 1
+                        f = L.DwSpatialFwdArgs()
+                        f.planes = 3; f.Hin = hin; f.Win = win; f.Hout = (hin - 1) // st + 1; f.Wout = (win - 1) // st + 1
+                        f.C = cmid; f.stride = st; f.ks = 3; f.inp.ld = cmid; f.a0_ld = cin; f.Cin = cin
+                        assert lib.dwn_dw_spatial_fwd_rc_supported(C.byref(f), dtype) in (0, 1)
+                        calls += 2
 assert lib.dwn_conv_pw_bn_stats_workspace_bytes(64) > 0
 # every entry point's error path: no device, null / zero arguments — an error code and a message, never a crash
 def expect_error(rc):

@@ -59,7 +59,17 @@ def test_bf16_full_width_digest_and_gradient_directions(golden_dir):
     dot = sum(float((g16[k] * g32[k]).sum()) for k in g32)
     gain = dot / tot32 ** 2
     rho = math.sqrt(max(tot16 ** 2 / tot32 ** 2 - gain ** 2, 0.0))
-    assert abs(gain - 1.0) <= 8e-3, gain
+    # Round 5 (tools/gain_probe.py, twelve passes on one box, both y1 modes): a single pass's gain scatters 1.0024 ... 1.0080 from
+    # run to run (the product build re-draws the bf16 rounding noise with its summation order), so ONE draw against 8e-3 failed
+    # every ~15th run; the bound stays where it was, on the MEAN of four draws (scatter / 2), which is what a systematic gain
+    # error would move.
+    gains = [gain]
+    for _ in range(3):
+        _, _, gx = _fwd_bwd(model, x, t, w, True)
+        gains.append(sum(float((gx[k] * g32[k]).sum()) for k in g32) / tot32 ** 2)
+    gain_mean = sum(gains) / len(gains)
+    assert abs(gain_mean - 1.0) <= 8e-3, gains
+    assert all(abs(gv - 1.0) <= 1.4e-2 for gv in gains), gains
     assert rho <= 0.15, rho
     assert abs(tot16 - float(z["grad_total_norm"])) <= 2e-2 * float(z["grad_total_norm"])
     # bf16 against fp32 HIP, element-wise
