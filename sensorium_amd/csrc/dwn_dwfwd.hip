@@ -175,6 +175,107 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 ? WF_MINW_RC4 : WF_MIN
     }
     (void)lr; (void)lg; (void)wave;
 
+    // one plane-group row of a0 as MFMA B-operand fragments: [tile pair t][even-x / odd-x pixels][k step]
+    constexpr int TP = ST;                       // 32-pixel MFMA tile pairs (even-x, odd-x) per plane-group row
+    constexpr int WIN = 2 * ST * LPW;            // pixels per plane row
+    uint4 pf[TP][2][KB];
+    auto load_row = [&](const int pg_, const int hi, uint4 (&fr)[TP][2][KB]) {
+        if constexpr (CIN > 0) {
+            const T* a0p = reinterpret_cast<const T*>(a.a0);
+            const unsigned a0ld = (unsigned)a.a0_ld;
+#pragma unroll
+            for (int t = 0; t < TP; ++t) {
+                const int gxp = 32 * t + 2 * lr;         // even pixel of this lane in the plane-group row
+                const int g = gxp / WIN, x = gxp % WIN;
+                const int pln = pg_ * NG + g;
+                const T* src = a0p + ((i64)(pln < a.planes ? pln : 0) * a.Hin + (hi < a.Hin ? hi : a.Hin - 1)) * a.Win * (i64)a0ld +
+                               (unsigned)x * a0ld + 8 * lg;     // rows / planes past the end: any valid address (masked below)
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    fr[t][0][kb] = *reinterpret_cast<const uint4*>(src + 32 * kb);
+                    fr[t][1][kb] = *reinterpret_cast<const uint4*>(src + a0ld + 32 * kb);
+                }
+            }
+        }
+    };
+    auto rebuild_row = [&](const int pg_, const int hi, int sl, const uint4 (&fr)[TP][2][KB]) {
+        if constexpr (CIN > 0) {
+            unsigned* tile_ = reinterpret_cast<unsigned*>(wf_smem);
+            sl = sl >= RQ ? sl - RQ : sl;
+#pragma unroll
+            for (int t = 0; t < TP; ++t) {
+                const int gxp = 32 * t + 2 * lr;
+                const int g = gxp / WIN, x = gxp % WIN;
+                const int pln = pg_ * NG + g;
+                const bool okp = pln < a.planes && hi < a.Hin;
+                unsigned* dst = tile_ + ((g * RQ + sl) * NPC + (x >> 1)) * PS + 4 * lg;
+                const bool lo_shift = x != 0;                              // pair (x-1, x): x = 0 pairs with the halo
+                const bool hi_only = TP == 2 && lr == 0 && x != 0;         // the odd neighbour sits in the previous tile's lane 15
+                const bool extra = x == WIN - 2 || lr == 15;              // this lane's odd pixel opens the next pair
+                constexpr int NB = ST == 1 ? 4 : 2;                         // channel tiles whose MFMAs are issued together (registers)
+                wf_f32x4_t aE[4], aO[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    if (n % NB == 0) {                                      // NB x 2 x KB MFMAs first: their latency overlaps
+#pragma unroll
+                        for (int m = n; m < n + NB; ++m) {
+                            aE[m] = wf_f32x4_t{0.f, 0.f, 0.f, 0.f}; aO[m] = wf_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int kb = 0; kb < KB; ++kb) { aE[m] = wf_mfma(wfr[m][kb], fr[t][0][kb], aE[m]); aO[m] = wf_mfma(wfr[m][kb], fr[t][1][kb], aO[m]); }
+                        }
+                    }
+                    const float4 s4 = *reinterpret_cast<const float4*>(&lcoef[16 * n + 4 * lg]);
+                    const float4 t4 = *reinterpret_cast<const float4*>(&lcoef[CS + 16 * n + 4 * lg]);
+                    // Packed math over CHANNEL pairs (j, j + 1) with their own coefficient pairs, written out as float2.  Left to
+                    // itself hipcc's SLP pass packs (even pixel, odd pixel) of ONE channel and broadcasts that channel's scale /
+                    // shift with  v_pk_fma_f32 ... op_sel:[0,1,1]  (the low lane reads the HIGH register of the coefficient
+                    // pair) — and that instruction returned, about once in 10^4 executions on gfx950, a wrong low-lane result in
+                    // lanes 48-63 (tools/dbg_fcr2.py: the odd pixels of channel 16 n + 13 of a whole row read SiLU(0)).  Not a
+                    // wait-state problem (s_nop padding, tied MFMA accumulators, asm-fenced DPP moves changed nothing); gone with
+                    // -fno-slp-vectorize and gone in this form, whose ISA has no op_sel on a low lane.
+                    const wf_f2_t sc2[2] = {wf_f2_t{s4.x, s4.y}, wf_f2_t{s4.z, s4.w}}, sh2[2] = {wf_f2_t{t4.x, t4.y}, wf_f2_t{t4.z, t4.w}};
+                    unsigned d[4], e[4], dd[4];
+#ifdef WF_REPRO_PK_OPSEL      // the scalar form that SLP turns into the op_sel:[0,1,1] instruction (reproducer: tools/dbg_fcr2.py)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float scj = j == 0 ? s4.x : j == 1 ? s4.y : j == 2 ? s4.z : s4.w, shj = j == 0 ? t4.x : j == 1 ? t4.y : j == 2 ? t4.z : t4.w;
+                        const unsigned pk = pk_bf16(aE[n][j], aO[n][j]);
+                        const float hE = fmaf(__uint_as_float(pk << 16), scj, shj), hO = fmaf(__uint_as_float(pk & 0xffff0000u), scj, shj);
+                        dd[j] = pk_bf16(hO * sigmoidf_(hO), hE * sigmoidf_(hE));
+                    }
+#else
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) {
+                        const unsigned pk0 = pk_bf16(aE[n][2 * jp], aO[n][2 * jp]), pk1 = pk_bf16(aE[n][2 * jp + 1], aO[n][2 * jp + 1]);   // y1 as stored
+                        const wf_f2_t yE = wf_f2_t{__uint_as_float(pk0 << 16), __uint_as_float(pk1 << 16)};
+                        const wf_f2_t yO = wf_f2_t{__uint_as_float(pk0 & 0xffff0000u), __uint_as_float(pk1 & 0xffff0000u)};
+                        const wf_f2_t hE = yE * sc2[jp] + sh2[jp], hO = yO * sc2[jp] + sh2[jp];
+                        const wf_f2_t zE = hE * wf_f2_t{sigmoidf_(hE.x), sigmoidf_(hE.y)};
+                        const wf_f2_t zO = hO * wf_f2_t{sigmoidf_(hO.x), sigmoidf_(hO.y)};
+                        dd[2 * jp] = pk_bf16(zO.x, zE.x);                    // (odd x, even x)
+                        dd[2 * jp + 1] = pk_bf16(zO.y, zE.y);
+                    }
+#endif
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // lane - 1's dword (row_shr:1; lane 0 of a 16-lane row gets 0): its low half is this pair's odd pixel
+                        const unsigned prev = (unsigned)__builtin_amdgcn_update_dpp(0, (int)dd[j], 0x111, 0xf, 0xf, false);
+                        d[j] = okp ? ((dd[j] & 0xffff0000u) | (lo_shift ? (prev & 0xffffu) : 0u)) : 0u;
+                        e[j] = okp ? (dd[j] & 0xffffu) : 0u;
+                    }
+                    if (hi_only) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) reinterpret_cast<unsigned short*>(dst + 16 * n + j)[1] = (unsigned short)(d[j] >> 16);
+                    } else {
+                        *reinterpret_cast<uint4*>(dst + 16 * n) = make_uint4(d[0], d[1], d[2], d[3]);
+                    }
+                    if (extra) *reinterpret_cast<uint4*>(dst + PS + 16 * n) = make_uint4(e[0], e[1], e[2], e[3]);
+                }
+            }
+        }
+    };
+    (void)pf;
+
     for (int pg = blk.x; pg < ngroups; pg += gridDim.x) {
         const int plane = pg * NG + grp;
         const bool pvalid = plane < a.planes && chan_ok;
@@ -194,89 +295,20 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 ? WF_MINW_RC4 : WF_MIN
             }
         }
         int slot_s = 1;                                  // ring slot of input row ST*s
+        if constexpr (CIN > 0 && NR == 4) load_row(pg, wave, pf);
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             const int s = chunk * RB;
             const int hi_s = ST * s;                     // first input row staged by this chunk
             // ---------------- stage SiLU(BN1(y1)) rows hi_s .. hi_s + NR - 1, x-pair-packed, into their ring slots
             if constexpr (CIN > 0) {
                 // ---------------- rebuild SiLU(BN1(y1)) of input rows hi_s .. hi_s + NR - 1 from a0: wave w takes rows w, w + 4, ...
-                constexpr int TP = ST;                       // 32-pixel MFMA tile pairs (even-x, odd-x) per plane-group row
-                constexpr int WIN = 2 * ST * LPW;            // pixels per plane row
-                const T* a0p = reinterpret_cast<const T*>(a.a0);
-                const unsigned a0ld = (unsigned)a.a0_ld;
-                for (int u = wave; u < NR; u += 4) {
-                    const int hi = hi_s + u;
-                    int sl = slot_s + u; sl = sl >= RQ ? sl - RQ : sl;
-#pragma unroll
-                    for (int t = 0; t < TP; ++t) {
-                        const int gxp = 32 * t + 2 * lr;     // even pixel of this lane in the plane-group row
-                        const int g = gxp / WIN, x = gxp % WIN;
-                        const int pln = pg * NG + g;
-                        const bool okp = pln < a.planes && hi < Hin;
-                        const T* src = a0p + ((i64)(pln < a.planes ? pln : 0) * Hin + (hi < Hin ? hi : Hin - 1)) * Win * (i64)a0ld +
-                                       (unsigned)x * a0ld + 8 * lg;
-                        uint4 bE[KB], bO[KB];
-#pragma unroll
-                        for (int kb = 0; kb < KB; ++kb) {
-                            bE[kb] = *reinterpret_cast<const uint4*>(src + 32 * kb);
-                            bO[kb] = *reinterpret_cast<const uint4*>(src + a0ld + 32 * kb);
-                        }
-                        unsigned* dst = tile + ((g * RQ + sl) * NPC + (x >> 1)) * PS + 4 * lg;
-                        const bool lo_shift = x != 0;                              // pair (x-1, x): x = 0 pairs with the halo
-                        const bool hi_only = TP == 2 && lr == 0 && x != 0;         // the odd neighbour sits in the previous tile's lane 15
-                        const bool extra = x == WIN - 2 || lr == 15;              // this lane's odd pixel opens the next pair
-#pragma unroll
-                        for (int n = 0; n < 4; ++n) {
-                            wf_f32x4_t aE = {0.f, 0.f, 0.f, 0.f}, aO = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                            for (int kb = 0; kb < KB; ++kb) { aE = wf_mfma(wfr[n][kb], bE[kb], aE); aO = wf_mfma(wfr[n][kb], bO[kb], aO); }
-                            const float4 s4 = *reinterpret_cast<const float4*>(&lcoef[16 * n + 4 * lg]);
-                            const float4 t4 = *reinterpret_cast<const float4*>(&lcoef[CS + 16 * n + 4 * lg]);
-                            // Packed math over CHANNEL pairs (j, j + 1) with their own coefficient pairs, written out as float2.  Left to
-                            // itself hipcc's SLP pass packs (even pixel, odd pixel) of ONE channel and broadcasts that channel's scale /
-                            // shift with  v_pk_fma_f32 ... op_sel:[0,1,1]  (the low lane reads the HIGH register of the coefficient
-                            // pair) — and that instruction returned, about once in 10^4 executions on gfx950, a wrong low-lane result in
-                            // lanes 48-63 (tools/dbg_fcr2.py: the odd pixels of channel 16 n + 13 of a whole row read SiLU(0)).  Not a
-                            // wait-state problem (s_nop padding, tied MFMA accumulators, asm-fenced DPP moves changed nothing); gone with
-                            // -fno-slp-vectorize and gone in this form, whose ISA has no op_sel on a low lane.
-                            const wf_f2_t sc2[2] = {wf_f2_t{s4.x, s4.y}, wf_f2_t{s4.z, s4.w}}, sh2[2] = {wf_f2_t{t4.x, t4.y}, wf_f2_t{t4.z, t4.w}};
-                            unsigned d[4], e[4], dd[4];
-#ifdef WF_REPRO_PK_OPSEL      // the scalar form that SLP turns into the op_sel:[0,1,1] instruction (reproducer: tools/dbg_fcr2.py)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float scj = j == 0 ? s4.x : j == 1 ? s4.y : j == 2 ? s4.z : s4.w, shj = j == 0 ? t4.x : j == 1 ? t4.y : j == 2 ? t4.z : t4.w;
-                                const unsigned pk = pk_bf16(aE[j], aO[j]);
-                                const float hE = fmaf(__uint_as_float(pk << 16), scj, shj), hO = fmaf(__uint_as_float(pk & 0xffff0000u), scj, shj);
-                                dd[j] = pk_bf16(hO * sigmoidf_(hO), hE * sigmoidf_(hE));
-                            }
-#else
-#pragma unroll
-                            for (int jp = 0; jp < 2; ++jp) {
-                                const unsigned pk0 = pk_bf16(aE[2 * jp], aO[2 * jp]), pk1 = pk_bf16(aE[2 * jp + 1], aO[2 * jp + 1]);   // y1 as stored
-                                const wf_f2_t yE = wf_f2_t{__uint_as_float(pk0 << 16), __uint_as_float(pk1 << 16)};
-                                const wf_f2_t yO = wf_f2_t{__uint_as_float(pk0 & 0xffff0000u), __uint_as_float(pk1 & 0xffff0000u)};
-                                const wf_f2_t hE = yE * sc2[jp] + sh2[jp], hO = yO * sc2[jp] + sh2[jp];
-                                const wf_f2_t zE = hE * wf_f2_t{sigmoidf_(hE.x), sigmoidf_(hE.y)};
-                                const wf_f2_t zO = hO * wf_f2_t{sigmoidf_(hO.x), sigmoidf_(hO.y)};
-                                dd[2 * jp] = pk_bf16(zO.x, zE.x);                    // (odd x, even x)
-                                dd[2 * jp + 1] = pk_bf16(zO.y, zE.y);
-                            }
-#endif
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                // lane - 1's dword (row_shr:1; lane 0 of a 16-lane row gets 0): its low half is this pair's odd pixel
-                                const unsigned prev = (unsigned)__builtin_amdgcn_update_dpp(0, (int)dd[j], 0x111, 0xf, 0xf, false);
-                                d[j] = okp ? ((dd[j] & 0xffff0000u) | (lo_shift ? (prev & 0xffffu) : 0u)) : 0u;
-                                e[j] = okp ? (dd[j] & 0xffffu) : 0u;
-                            }
-                            if (hi_only) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) reinterpret_cast<unsigned short*>(dst + 16 * n + j)[1] = (unsigned short)(d[j] >> 16);
-                            } else {
-                                *reinterpret_cast<uint4*>(dst + 16 * n) = make_uint4(d[0], d[1], d[2], d[3]);
-                            }
-                            if (extra) *reinterpret_cast<uint4*>(dst + PS + 16 * n) = make_uint4(e[0], e[1], e[2], e[3]);
-                        }
+                if constexpr (NR == 4) {
+                    rebuild_row(pg, hi_s + wave, slot_s + wave, pf);                   // fragments fetched one chunk ahead
+                    if (chunk + 1 < nchunks) load_row(pg, hi_s + NR + wave, pf);       // in flight under the walk below
+                } else {
+                    for (int u = wave; u < NR; u += 4) {
+                        load_row(pg, hi_s + u, pf);
+                        rebuild_row(pg, hi_s + u, slot_s + u, pf);
                     }
                 }
             } else if constexpr (ST == 1) {
