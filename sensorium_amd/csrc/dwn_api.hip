@@ -180,9 +180,16 @@ struct BlockWs {
 };
 // conv_pwl forward with the SE gate folded into per-sample weights (plain A loader): needs whole tiles per sample and
 // the k-loop GEMM variant
+// ... and enough rows per sample to pay for writing B weight copies: with 18432 rows (blocks 0-3) the copies are 1.8 MB and the
+// plain-loader GEMM on its LDS-DMA ring wins; at 4608 / 1280 rows (blocks 4-8) the copies are 7-29 MB per block — written, then
+// re-read at 1.35-1.53x the activations' bytes — and the gate in the A loader is faster for the step although the GEMM itself is
+// slower (round 5, same box: pwl_fwd 1.085 -> 1.289 ms, step 24.27 -> 24.12 ms)
+#ifndef PWL_GATED_MIN_ROWS
+#define PWL_GATED_MIN_ROWS 8192
+#endif
 static bool pwl_gated_weights(const dwn_block_args& a) {
     const int bk = a.dtype == DWN_BF16 ? 64 : 32;
-    return ((a.T * a.Hout * a.Wout) % 128) == 0 && a.Cmid > bk;
+    return ((a.T * a.Hout * a.Wout) % 128) == 0 && a.Cmid > bk && a.T * a.Hout * a.Wout >= PWL_GATED_MIN_ROWS;
 }
 // conv_pwl backward through per-sample products (k_pwl_bwd_reduce) + the recompute-du GEMM epilogue (EPI_DH3): saves
 // three passes over a [Mout][Cmid] tensor at the price of zeroing / accumulating / reading B [Cout][Cmid] fp32 matrices,
@@ -534,12 +541,13 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
         LoadDesc z3 = ld_bnact(a.y3, a.Cmid, a.bn3.coef, a.Cmid, 1, nullptr, 0, S_out);
         PROF(DWN_FAM_SE_POOL, k_se_pool(z3, a.B, a.Cmid, S_out, w.pooled, a.z3, dt, s));
     }
+    // (z3 * gate_b) @ W2^T == z3 @ (W2 . diag(gate_b))^T: where conv_pwl runs on per-sample weights the SE kernel writes them too
+    int gate_folded = 0;
     TRY(k_se_mlp_fwd(w.pooled, 1.0f / (float)S_out, a.se_wr, a.se_br, a.se_we, a.se_be, a.B, a.Cmid, a.se_r,
-                     a.se_pmean, a.se_hidpre, a.se_gate, s));
+                     a.se_pmean, a.se_hidpre, a.se_gate, pwl_gated_weights(a) ? a.w_pwl : nullptr, w.wgated, a.Cout, dt, &gate_folded, s));
     // conv_pwl (:117-120): y4 = (silu(bn3(y3)) * gate) @ W2^T
     if (pwl_gated_weights(a)) {
-        // (z3 * gate_b) @ W2^T == z3 @ (W2 . diag(gate_b))^T: B small weight matrices instead of a per-element multiply
-        TRY(k_gate_weights(a.w_pwl, a.se_gate, w.wgated, a.B, a.Cout, a.Cmid, dt, s));
+        if (!gate_folded) TRY(k_gate_weights(a.w_pwl, a.se_gate, w.wgated, a.B, a.Cout, a.Cmid, dt, s));
         GemmNN g = nn_base(ld_plain(a.z3, a.Cmid), LD_PLAIN, w.wgated, a.Cmid, a.y4, a.Cout, (int)Mout, a.Cout, a.Cmid, 1);
         g.b_sample_stride = (i64)a.Cout * a.Cmid; g.b_rows_per_sample = S_out;
         g.stats = tr ? w.st4 : nullptr; g.stat_nchan = a.Cout; g.f32_split = f32_split_of(a.f32_products, !tr);

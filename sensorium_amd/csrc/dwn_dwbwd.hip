@@ -311,21 +311,26 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
         *reinterpret_cast<uint4*>(tcol) = make_uint4(0, 0, 0, 0);
         if (jj == 0) *reinterpret_cast<uint4*>(tlast) = make_uint4(0, 0, 0, 0);
         int slot_s = 1;                            // ring slot of gradient row s = chunk * RB   (slot(r) = (r + 1) mod RQ)
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            const int s = chunk * RB;
-            // ---------------- y1 rows s-1 .. s+RB-2 -> LDS (DMA, this wave's pixels only) — or the a0 rows they are rebuilt from
-            uint4 afr[RB / 2][KB];
+        uint4 afr[RB / 2][KB];                     // rebuilt form: a0 fragments of the chunk's rows, two rows per MFMA pixel tile
+        auto load_afr = [&](const int s_) {
             if constexpr (CIN > 0) {
                 const unsigned a0row = (unsigned)W * (unsigned)a.a0_ld;
 #pragma unroll
                 for (int t = 0; t < RB / 2; ++t) {
-                    int row = s - 1 + 2 * t + (lr >> 3);                     // rows outside the plane: any valid address (never read back)
+                    int row = s_ - 1 + 2 * t + (lr >> 3);                    // rows outside the plane: any valid address (never read back)
                     row = row < 0 ? 0 : (row >= Hin ? Hin - 1 : row);
 #pragma unroll
                     for (int kb = 0; kb < KB; ++kb)
                         afr[t][kb] = *reinterpret_cast<const uint4*>(a0src0 + (unsigned)row * a0row + 32 * kb);
                 }
-            } else {
+            }
+        };
+        load_afr(0);
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int s = chunk * RB;
+            // ---------------- y1 rows s-1 .. s+RB-2 -> LDS (DMA, this wave's pixels only) — or the a0 rows they are rebuilt from
+            // (rebuilt form: the fragments of this chunk were fetched under the previous chunk's walk)
+            if constexpr (CIN == 0) {
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     const int row = s - 1 + i;
@@ -399,6 +404,7 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
                         *reinterpret_cast<uint2*>(dst + (((4 * n + lg) ^ lr) << 3)) = make_uint2(pk_bf16(acc[0], acc[1]), pk_bf16(acc[2], acc[3]));
                     }
                 }
+                if (chunk + 1 < nchunks) load_afr(s + RB);      // the next chunk's a0 rows: in flight under the walk below
             } else {
                 wk_wait_vm0();                      // this wave's y1 blocks have landed (it is their only reader)
             }
@@ -642,6 +648,11 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW2_RC : WK_MINW2) void dw_spat
                 a0t = reinterpret_cast<const T*>(a.a0) + ((i64)aplane * Hin * Win + (unsigned)(hi0 * Win + 4 * ajj + (lane & 3))) * a.a0_ld + 8 * (lane >> 4);
             }
             const unsigned a0row = (unsigned)Win * (unsigned)(CIN > 0 ? a.a0_ld : 0);
+            uint4 anext[KB];                              // a0 fragments one row ahead (rebuilt-y1 form)
+            if constexpr (CIN > 0) {
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) anext[kb] = *reinterpret_cast<const uint4*>(a0t + 32 * kb);
+            }
             uint4 gA[2], gB[2];                          // gradient rows in use: pairs jj, jj+1
             gA[0] = *reinterpret_cast<const uint4*>(tcol); gA[1] = *reinterpret_cast<const uint4*>(tcol + CS);
             // one input row: NTAP tap rows (dy, gradient row) — even rows (dy 1, gcur), odd rows (dy 0, gnext) and (dy 2, gcur)
@@ -650,8 +661,14 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW2_RC : WK_MINW2) void dw_spat
                 uint2 ry[4];
                 uint4 afr[KB];
                 if constexpr (CIN > 0) {
+                    // this row's a0 fragments were fetched during the previous row step; the next row's go out now (rows past the band:
+                    // the clamped address of the last row again — never used)
+                    const int iyn = iy + 1 < nri ? iy + 1 : iy;
 #pragma unroll
-                    for (int kb = 0; kb < KB; ++kb) afr[kb] = *reinterpret_cast<const uint4*>(a0t + (unsigned)iy * a0row + 32 * kb);
+                    for (int kb = 0; kb < KB; ++kb) {
+                        afr[kb] = anext[kb];
+                        anext[kb] = *reinterpret_cast<const uint4*>(a0t + (unsigned)iyn * a0row + 32 * kb);
+                    }
                 } else {
                     const T* yn = y10 + (unsigned)iy * y1row;
 #pragma unroll
@@ -901,7 +918,6 @@ static int launch_s1c_rb(const DwSpatialBwd& a, hipStream_t s) {
     const int rb = a.rows_band > 0 ? a.rows_band : (LPW == 16 ? 4 : 2);
     if (rb <= 2) return launch_s1c<LPW, 2, CIN>(a, s);
     if (rb <= 4) return launch_s1c<LPW, 4, CIN>(a, s);
-    if constexpr (CIN > 0) return launch_s1c<LPW, 4, CIN>(a, s);     // (the rebuilt-y1 form is built for 2 / 4 rows per chunk)
     if (rb <= 6) return launch_s1c<LPW, 6, CIN>(a, s);
     return launch_s1c<LPW, 8, CIN>(a, s);
 }

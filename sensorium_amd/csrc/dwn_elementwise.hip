@@ -1175,12 +1175,17 @@ __device__ __forceinline__ float wave_sum(float v) {
 // the channels with 16-byte loads (lane -> 4 consecutive channels, 256 channels per wave step): every load independent,
 // one xor-shuffle sum per owned unit and NO LDS atomics (a hidden unit has exactly one owner wave — nothing to order in the deterministic build either).
 // Requires C % 4 == 0 (16-byte rows of `wr`).
+// w2 != NULL: the kernel also writes the gate folded into conv_pwl's weight for its sample and channel range,
+// wg[b][n][c] = w2[n][c] * gate[b][c] in the compute type (dwiseneuro.py:40-43,117-120; what k_gate_weights did in a launch of its
+// own, 9 launches per step)
 template <int RP>
 __global__ __launch_bounds__(256) void se_mlp_fwd_rows_kernel(const long long* pooled_sum, float inv_s, const float* wr,
                                                               const float* br, const float* we, const float* be, int C,
-                                                              int R, float* pmean, float* hid_pre, float* gate) {
+                                                              int R, float* pmean, float* hid_pre, float* gate,
+                                                              const float* __restrict__ w2, void* __restrict__ wg, int N2, int wg_bf16) {
     constexpr int RPW = RP / 4;
     __shared__ float hid[RP];
+    __shared__ float gl[256];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int split = gridDim.y, part = blockIdx.y;
     const int C4 = C >> 2;                                  // float4 per row
@@ -1240,7 +1245,23 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_rows_kernel(const long long* p
 #pragma unroll
             for (int r = 0; r < 16; ++r) a = fmaf(wv[r], r0 + r < R ? hid[r0 + r] : 0.f, a);
         }
-        gate[(i64)b * C + c] = sigmoidf_(a);
+        const float gv = sigmoidf_(a);
+        gate[(i64)b * C + c] = gv;
+        if (w2 && c - part * per < 256) gl[c - part * per] = gv;
+    }
+    if (w2) {                                   // (uniform: per <= 256 is checked by the launcher)
+        __syncthreads();
+        const int c0 = part * per, nc = c_end - c0;
+        if (nc > 0) {
+            const int tot = N2 * nc;
+            for (int i = tid; i < tot; i += 256) {
+                const int n = i / nc, cc = i - n * nc;
+                const float v = w2[(i64)n * C + c0 + cc] * gl[cc];
+                const i64 o = ((i64)b * N2 + n) * C + c0 + cc;
+                if (wg_bf16) reinterpret_cast<bf16_t*>(wg)[o] = f2bf(v);
+                else reinterpret_cast<float*>(wg)[o] = v;
+            }
+        }
     }
 }
 
@@ -1372,18 +1393,25 @@ __global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const float* dgp, con
     }
 }
 
+// w2 / wg / N2 (optional): fold the gate into conv_pwl's weight in the same launch (rows kernel only; returns 1 in *folded)
 int k_se_mlp_fwd(const long long* pooled_sum, float inv_s, const float* wr, const float* br, const float* we,
-                 const float* be, int B, int C, int R, float* pmean, float* hid_pre, float* gate, hipStream_t s) {
+                 const float* be, int B, int C, int R, float* pmean, float* hid_pre, float* gate, const float* w2, void* wg, int N2,
+                 int dtype, int* folded, hipStream_t s) {
+    if (folded) *folded = 0;
     if ((C & 3) == 0 && R <= SE_RT && !(((size_t)pooled_sum | (size_t)wr | (size_t)pmean) & 15)) {
+        const bool fold = w2 && wg && (C + 7) / 8 <= 256;
+        const float* w2f = fold ? w2 : nullptr;
+        const int bf = dtype == DWN_BF16 ? 1 : 0;
         if (R <= 16)
             hipLaunchKernelGGL(se_mlp_fwd_rows_kernel<16>, dim3(B, 8), dim3(256), 0, s, pooled_sum, inv_s, wr, br, we, be, C, R,
-                               pmean, hid_pre, gate);
+                               pmean, hid_pre, gate, w2f, wg, N2, bf);
         else if (R <= 32)
             hipLaunchKernelGGL(se_mlp_fwd_rows_kernel<32>, dim3(B, 8), dim3(256), 0, s, pooled_sum, inv_s, wr, br, we, be, C, R,
-                               pmean, hid_pre, gate);
+                               pmean, hid_pre, gate, w2f, wg, N2, bf);
         else
             hipLaunchKernelGGL(se_mlp_fwd_rows_kernel<SE_RT>, dim3(B, 8), dim3(256), 0, s, pooled_sum, inv_s, wr, br, we, be, C,
-                               R, pmean, hid_pre, gate);
+                               R, pmean, hid_pre, gate, w2f, wg, N2, bf);
+        if (folded && fold) *folded = 1;
     } else {
         hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(B, 8), dim3(256), (C + R) * sizeof(float), s, pooled_sum, inv_s, wr, br,
                            we, be, C, R, pmean, hid_pre, gate);

@@ -56,7 +56,8 @@ int k_residual_bwd_dx(const LoadDesc& xin, const void* da0, const void* dout, co
                       void* dx, int dtype, hipStream_t s);
 int k_se_pool(const LoadDesc& z3, int B, int C, int rows_per_sample, long long* pooled, void* z3out, int dtype, hipStream_t s);
 int k_se_mlp_fwd(const long long* pooled_sum, float inv_s, const float* wr, const float* br, const float* we,
-                 const float* be, int B, int C, int R, float* pmean, float* hid_pre, float* gate, hipStream_t s);
+                 const float* be, int B, int C, int R, float* pmean, float* hid_pre, float* gate, const float* w2, void* wg, int N2,
+                 int dtype, int* folded, hipStream_t s);
 int k_se_mlp_bwd(const float* dg, const float* gate, const float* hid_pre, const float* pmean, const float* wr,
                  const float* we, int B, int C, int R, float inv_s, float* dgp, float* dhp, float* dps, float* dwr,
                  float* dbr, float* dwe, float* dbe, hipStream_t s);

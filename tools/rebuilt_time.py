@@ -38,7 +38,7 @@ def timeit(fn, n=8, reps=3):
     return best
 
 
-def run(planes, Hin, Win, Cc, stride, which, cin=64):
+def run(planes, Hin, Win, Cc, stride, which, cin=64, rows_band=0):
     g = torch.Generator(device=dev); g.manual_seed(0)
     Hout, Wout = (Hin - 1) // stride + 1, (Win - 1) // stride + 1
     a0 = torch.randn(planes * Hin * Win, cin, device=dev, generator=g).to(BF)
@@ -55,7 +55,7 @@ def run(planes, Hin, Win, Cc, stride, which, cin=64):
             a = L.DwSpatialFwdArgs()
             di = desc(y1 if mode == "stored" else None, Cc, v1=coef, v2=coef[Cc:]); di.act = 1
             a.inp = di; a.w = w.data_ptr(); a.out = y2.data_ptr(); a.planes = planes; a.Hin = Hin; a.Win = Win; a.Hout = Hout
-            a.Wout = Wout; a.C = Cc; a.stride = stride; a.ks = 3; a.stats = st.data_ptr()
+            a.Wout = Wout; a.C = Cc; a.stride = stride; a.ks = 3; a.stats = st.data_ptr(); a.rows_band = rows_band
             if mode == "rebuilt":
                 a.a0 = a0.data_ptr(); a.a0_ld = cin; a.w1 = w1.data_ptr(); a.Cin = cin
             res[mode] = timeit(lambda: L.check(L.lib.dwn_dw_spatial_fwd(C.byref(a), L.DWN_BF16, 0, s()), "fwd"))
@@ -70,15 +70,17 @@ def run(planes, Hin, Win, Cc, stride, which, cin=64):
             a.dy = desc(dh2, Cc, q=y2, v1=abc, v2=abc[Cc:], v3=abc[2 * Cc:])
             a.y1 = desc(y1 if mode == "stored" else None, Cc, v1=coef, v2=coef[Cc:], v3=coef[2 * Cc:], v4=coef[3 * Cc:])
             a.w = w.data_ptr(); a.dh1 = dh1.data_ptr(); a.dw = dw.data_ptr(); a.planes = planes; a.Hin = Hin; a.Win = Win
-            a.Hout = Hout; a.Wout = Wout; a.C = Cc; a.stride = stride; a.ks = 3; a.stats = st.data_ptr()
+            a.Hout = Hout; a.Wout = Wout; a.C = Cc; a.stride = stride; a.ks = 3; a.stats = st.data_ptr(); a.rows_band = rows_band
             if mode == "rebuilt":
                 a.a0 = a0.data_ptr(); a.a0_ld = cin; a.w1 = w1.data_ptr(); a.Cin = cin
             res[mode] = timeit(lambda: L.check(L.lib.dwn_dw_spatial_bwd(C.byref(a), L.DWN_BF16, 0, s()), "bwd"))
-    print(f"{which} planes={planes} {Hin}x{Win} C={Cc} s={stride}: stored {res['stored']:7.1f} us   rebuilt {res['rebuilt']:7.1f} us", flush=True)
+    print(f"{which} planes={planes} {Hin}x{Win} C={Cc} s={stride} band={rows_band}: stored {res['stored']:7.1f} us   rebuilt {res['rebuilt']:7.1f} us", flush=True)
 
 
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if a in ("fwd", "bwd")] or ["fwd", "bwd"]
+    bands = [int(a) for a in sys.argv[1:] if a.isdigit()] or [0]
     for wh in which:
-        run(1024, 18, 32, 448, 1, wh)
-        run(1024, 36, 64, 448, 2, wh)
+        for rb in bands:
+            run(1024, 18, 32, 448, 1, wh, rows_band=rb)
+            run(1024, 36, 64, 448, 2, wh, rows_band=rb)
