@@ -7,6 +7,9 @@
 #include <math.h>
 
 static thread_local char g_err[512] = "";
+#ifndef DWN_EVAL_CHAIN
+#define DWN_EVAL_CHAIN 1      // eval forward: the chained stencil's rebuilt-input form where it is built (0: dwn_dwrc.hip everywhere; A/B builds)
+#endif
 
 // y1-recomputing spatial forward (dwn_dwrc.hip): used by the eval-mode block forward, where neither the BatchNorm-1
 // statistics nor a saved y1 are needed, so conv_pw never runs as a pass of its own
@@ -480,7 +483,23 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     LoadDesc xin = ld_plain(a0, a.Cin);
     const bool identity_sc = a.stride == 1 && a.Hin == a.Hout && a.Win == a.Wout;
     const bool y1_free = tr && block_y1_free(a);
-    if (y1_free) {
+    // eval, 64 input channels, row-walk plane widths: the chained stencil's rebuilt-input form is also the faster way to skip conv_pw
+    // (623 vs 768 us on block 0's shape, 276 vs 308 us on blocks 1-3'; the tile-resident kernel of dwn_dwrc.hip keeps the rest)
+    bool eval_chain = false;
+    if (DWN_EVAL_CHAIN && !tr && dt == DWN_BF16) {
+        DwSpatialFwd f; memset(&f, 0, sizeof(f));
+        f.planes = a.B * a.T; f.Hin = a.Hin; f.Win = a.Win; f.Hout = a.Hout; f.Wout = a.Wout; f.C = a.Cmid; f.stride = a.stride; f.ks = a.ks;
+        f.in.ld = a.Cmid; f.a0_ld = a.Cin; f.Cin = a.Cin;
+        eval_chain = dw_spatial_fwd_rc_walk_supported(f, dt);
+    }
+    if (eval_chain) {
+        DwSpatialFwd d; memset(&d, 0, sizeof(d));
+        d.in = ld_bnact(nullptr, a.Cmid, a.bn1.coef, a.Cmid, 1, nullptr, 0, 1);
+        d.a0 = a0; d.a0_ld = a.Cin; d.w1 = w.wpw; d.Cin = a.Cin;
+        d.w = w.wdws; d.out = a.y2; d.planes = a.B * a.T; d.Hin = a.Hin; d.Win = a.Win; d.Hout = a.Hout;
+        d.Wout = a.Wout; d.C = a.Cmid; d.stride = a.stride; d.ks = a.ks; d.stats = nullptr;
+        PROF(DWN_FAM_DWS_FWD, launch_dw_spatial_fwd(d, dt, s));
+    } else if (y1_free) {
         // y1-free training: BatchNorm-1's batch statistics from the Gram matrix of a0 (one C-wide pass: gemm_tn [a0 | 1]^T a0), then the
         // chained stencil rebuilds the y1 rows it needs from a0 on the matrix cores: conv_pw is no pass, a.y1 is not written
         LoadDesc cat = ld_plain(a0, a.Cin);
@@ -740,7 +759,14 @@ int dwn_block_backward(const dwn_block_args* ap, int device, void* stream) {
 int dwn_block_forward_writes(const dwn_block_args* ap) {
     const dwn_block_args& a = *ap;
     if (a.training) return block_y1_free(a) ? 2 : 3;
-    return block_fwd_rc(a) ? 0 : 1;
+    if (block_fwd_rc(a)) return 0;
+    if (DWN_EVAL_CHAIN && a.dtype == DWN_BF16) {        // the chained stencil's rebuilt-input form (dwn_block_forward, eval_chain)
+        DwSpatialFwd f; memset(&f, 0, sizeof(f));
+        f.planes = a.B * a.T; f.Hin = a.Hin; f.Win = a.Win; f.Hout = a.Hout; f.Wout = a.Wout; f.C = a.Cmid; f.stride = a.stride; f.ks = a.ks;
+        f.in.ld = a.Cmid; f.a0_ld = a.Cin; f.Cin = a.Cin;
+        if (dw_spatial_fwd_rc_walk_supported(f, a.dtype)) return 0;
+    }
+    return 1;
 }
 
 // ------------------------------------------------------------------------------------------------ pool

@@ -670,6 +670,8 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW2_RC : WK_MINW2) void dw_spat
                         anext[kb] = *reinterpret_cast<const uint4*>(a0t + (unsigned)iyn * a0row + 32 * kb);
                     }
                 } else {
+                    // (fetching these one row ahead, as the rebuilt form does with its a0 fragments, changes nothing here — 1047 / 518 / 292
+                    // vs 1044 / 519 / 279 us at two waves per SIMD, 1057 / 540 / 291 at three: this form moves 5 TB/s and is bound by that)
                     const T* yn = y10 + (unsigned)iy * y1row;
 #pragma unroll
                     for (int p = 0; p < 4; ++p) ry[p] = wk_ld8(yn + p * a.y1.ld);       // in flight under the data-gradient taps

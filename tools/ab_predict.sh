@@ -4,7 +4,7 @@
 dtype=$1; shift
 mkdir -p gpurun_out/ab
 for v in "$@"; do
-  if [ "$v" = base ]; then unset DWN_LIB_PATH; else export DWN_LIB_PATH=$PWD/build_var/$v/libdwiseneuro_hip.so; fi
+  if [ "$v" = base ]; then unset DWN_LIB_PATH; else export DWN_LIB_PATH=$PWD/build_ab/$v/libdwiseneuro_hip.so; fi
   python3 - "$dtype" > gpurun_out/ab/predict_${dtype}_$v.json 2> gpurun_out/ab/predict_${dtype}_$v.err <<'P'
 import json, sys
 sys.path.insert(0, "."); sys.path.insert(0, "tools")
