@@ -80,10 +80,13 @@ MFMA_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md: bf16 dense MFMA ~2.5 P
 MFMA_F32_PEAK_TFLOPS = 157.3       # ... fp32-input MFMA = the fp32 vector rate
 
 
-def block_work(batch, frames, height, width, expansion, fused_pw_blocks, esize):
+def block_work(batch, frames, height, width, expansion, fused_pw_blocks, esize, y1_free_blocks=()):
     """Per block: {family: (algorithmic HBM bytes, FLOPs)} of one launch set of that family in that block, plus the block's
     geometry.  Depth-wise families follow SURVEY.md 8d (read input once + write output once; backward = read x + read dy +
-    write dx); GEMM families count every operand / result once (2*M*K*N FLOPs per product)."""
+    write dx); GEMM families count every operand / result once (2*M*K*N FLOPs per product).
+    `y1_free_blocks`: blocks trained without a materialised y1 (round 5): what runs under `pw_fwd` there is the Gram pass over the
+    block input (a0 read once, [a0 | 1]^T a0), not the expand GEMM; the depth-wise families keep SURVEY's byte definition (their
+    kernels then move FEWER bytes than that: y1 is rebuilt from a0 on the matrix cores, see `traffic`)."""
     out = []
     h, w = height, width
     for i, st in enumerate(STRIDES):
@@ -99,6 +102,8 @@ def block_work(batch, frames, height, width, expansion, fused_pw_blocks, esize):
             "pwl_dgrad": (mo * cout + 2 * mo * e_, 2 * mo * e_ * cout),                           # dy4, y3 in; dh3 out
             "pwl_wgrad": (mo * e_ + mo * cout, 2 * mo * e_ * cout),
         }
+        if i in y1_free_blocks:
+            d["pw_fwd"] = (mi * cin, 2 * mi * cin * (cin + 8))
         if i in fused_pw_blocks:
             # one pass over dh1 for both gradients; y1 is not read (its BatchNorm-backward terms fold into Cin x Cin matrices):
             # dh1, a0 in; da0 out — the bytes this algorithm has to move, not the (dh1, y1) pair autograd would read
@@ -112,14 +117,14 @@ def block_work(batch, frames, height, width, expansion, fused_pw_blocks, esize):
     return out
 
 
-def family_work(batch, frames, height, width, expansion, readouts, fused_pw_blocks, esize):
+def family_work(batch, frames, height, width, expansion, readouts, fused_pw_blocks, esize, y1_free_blocks=()):
     """Algorithmic work per *step* of every timed kernel family: (bytes moved through HBM, FLOPs) -- block_work summed over
     the nine blocks, plus the cortex and the readouts.
     `fused_pw_blocks`: blocks whose conv_pw data + weight gradient are one launch (counted under pw_dgrad)."""
     e = {k: 0 for k in ("dws_fwd", "dwt_fwd", "dws_bwd", "dwt_bwd", "pw_fwd", "pwl_fwd", "pwl_dgrad", "pwl_wgrad",
                         "pw_dgrad", "pw_wgrad", "se_pool")}
     f = dict.fromkeys(e, 0)
-    for blk in block_work(batch, frames, height, width, expansion, fused_pw_blocks, esize):
+    for blk in block_work(batch, frames, height, width, expansion, fused_pw_blocks, esize, y1_free_blocks):
         for k, (by, fl) in blk["work"].items():
             e[k] += by
             f[k] += fl
@@ -443,7 +448,19 @@ def main():
         fused = [i for i, c in enumerate(CORE_FEATURES)
                  if L.lib.dwn_pw_bwd_fused_supported(L.DWN_BF16 if args.dtype == "bf16" else L.DWN_F32,
                                                      128, c * expansion, c)]
-        alg, flops = family_work(args.batch, args.frames, args.height, args.width, expansion, num_neurons, fused, esize)
+        # blocks trained without a materialised y1 (asked of the library: dwn_block_forward_writes bit 0 clear)
+        import sensorium_amd.ops as _ops
+        y1_free, hh, ww = [], args.height, args.width
+        for i, (cf, st) in enumerate(zip(CORE_FEATURES, STRIDES)):
+            ba = L.BlockArgs()
+            ba.dtype = L.DWN_BF16 if args.dtype == "bf16" else L.DWN_F32; ba.training = 1; ba.B = args.batch; ba.T = args.frames
+            ba.Hin, ba.Win = hh, ww; ba.Hout, ba.Wout = (hh - 1) // st + 1, (ww - 1) // st + 1
+            ba.Cin = cf; ba.Cmid = cf * expansion; ba.Cout = CORE_FEATURES[min(i + 1, len(CORE_FEATURES) - 1)]
+            ba.stride = st; ba.ks = 3; ba.kt = 5; ba.se_r = max(1, cf * expansion // 32); ba.y1_mode = _ops._Y1_MODE
+            if not (L.lib.dwn_block_forward_writes(C.byref(ba)) & 1):
+                y1_free.append(i)
+            hh, ww = ba.Hout, ba.Wout
+        alg, flops = family_work(args.batch, args.frames, args.height, args.width, expansion, num_neurons, fused, esize, y1_free)
         mfma_peak = MFMA_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
         # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected inside the timed run):
         # profiles/<round>_pmc_traffic.json holds them for the default metric shape together with the hash of the
@@ -512,7 +529,8 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload_name(args),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "frames": args.frames,
-                       "height": args.height, "width": args.width, "parallelism": f"dp{world}"},
+                       "height": args.height, "width": args.width, "parallelism": f"dp{world}",
+                       "y1_free_blocks": y1_free},
             "clips_per_s_per_gpu": round(value / world, 2), "loss": round(loss_value, 3),
             "clips_per_s_fwd_bwd_only": None if fwd_bwd_clips is None else round(fwd_bwd_clips, 2),
             "roofline": roof,

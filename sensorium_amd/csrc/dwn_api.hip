@@ -192,7 +192,8 @@ struct BlockWs {
 #endif
 static bool pwl_gated_weights(const dwn_block_args& a) {
     const int bk = a.dtype == DWN_BF16 ? 64 : 32;
-    return ((a.T * a.Hout * a.Wout) % 128) == 0 && a.Cmid > bk && a.T * a.Hout * a.Wout >= PWL_GATED_MIN_ROWS;
+    // (bf16 only: fp32 keeps the per-sample weights everywhere — its eval-mode split products were validated in that form)
+    return ((a.T * a.Hout * a.Wout) % 128) == 0 && a.Cmid > bk && (a.dtype != DWN_BF16 || a.T * a.Hout * a.Wout >= PWL_GATED_MIN_ROWS);
 }
 // conv_pwl backward through per-sample products (k_pwl_bwd_reduce) + the recompute-du GEMM epilogue (EPI_DH3): saves
 // three passes over a [Mout][Cmid] tensor at the price of zeroing / accumulating / reading B [Cout][Cmid] fp32 matrices,
