@@ -259,7 +259,8 @@ typedef struct dwn_block_args {
     int f32_products;                        /* DWN_F32_AUTO / _NATIVE / _SPLIT3: how dtype f32 multiplies (see below) */
     /* training, bf16: 0 = the library leaves y1 (conv_pw's output, the widest tensor of the block) unmaterialised where both
      * stencils can rebuild it from the block input on the matrix cores (BatchNorm-1 statistics from the Gram matrix of the
-     * input): y1 may then be NULL in forward and backward (dwn_block_forward_writes bit 0 clear); 1 = always materialise y1.
+     * input) AND that is the faster path (64 input channels): y1 may then be NULL in forward and backward
+     * (dwn_block_forward_writes bit 0 clear); 1 = always materialise y1; 2 = y1-free wherever it is built (64 / 128 input channels).
      * Forward and backward of one block must be called with the same value. */
     int y1_mode;
 } dwn_block_args;

@@ -224,7 +224,10 @@ static bool block_y1_free(const dwn_block_args& a) {
     d.planes = a.B * a.T; d.Hin = a.Hin; d.Win = a.Win; d.Hout = a.Hout; d.Wout = a.Wout; d.C = a.Cmid; d.stride = a.stride; d.ks = a.ks;
     d.dy.ld = a.Cmid; d.y1.ld = a.Cmid; d.a0_ld = a.Cin; d.Cin = a.Cin;
     if (!dw_spatial_bwd_rc_supported(d, a.dtype)) return false;
-    return true;
+    // y1_mode 0: where it is also the faster path — 64 input channels (blocks 0-3: -0.4 ms per step); with 128 (blocks 4-6: four k-steps
+    // per MFMA tile, 256 B of a0 per pixel against 128 B of a y1 slice) the rebuilding stencils lose more than conv_pw costs
+    // (stand-alone 508 vs 295 us forward, 614 vs 549 us backward on block 4's shape); y1_mode 2 takes every block that is built
+    return a.y1_mode == 2 || a.Cin == 64;
 }
 // eval-mode forward without conv_pw as its own pass (BatchNorm-1 is known: the tile-resident stencil of dwn_dwrc.hip)
 static bool block_fwd_rc(const dwn_block_args& a) {

@@ -265,18 +265,40 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
     // parity lr >> 3, slot lr & 7), k group lg.  The 8-byte channel chunk c8 of tile pixel lr is stored at chunk c8 ^ lr of its
     // 128-byte slot (conflict-free ds_write_b64; the walk reads its chunk cv at cv ^ key with key = 8 * row parity + slot).
     const int lr = lane & 15, lg = lane >> 4;
-    uint4 wfr[4][KB];
+    // W1 fragments: registers for CIN = 64; for CIN = 128 a swizzled copy of the 64-row slice in LDS behind the y1 rows
+    constexpr bool W1_LDS = CIN > 64;
+    constexpr unsigned W1_OFF = RING_BYTES + (unsigned)RB * 4096u;
+    uint4 wfr[W1_LDS ? 1 : 4][KB];
     const T* a0src0 = nullptr;
     if constexpr (CIN > 0) {
         const T* w1 = reinterpret_cast<const T*>(a.w1);
+        if constexpr (W1_LDS) {
+            constexpr int CH = CIN / 8;
+            for (int i = tid; i < 64 * CH; i += NT) {
+                const int r = i / CH, c = i % CH;
+                const int ch = c0 + r;
+                *reinterpret_cast<uint4*>(wk_smem + W1_OFF + (r * CH + (c ^ (r & 15))) * 16) =
+                    *reinterpret_cast<const uint4*>(w1 + (i64)(ch < a.C ? ch : c0) * CIN + 8 * c);
+            }
+            __syncthreads();
+        } else {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int ch = c0 + 16 * n + lr;
+            for (int n = 0; n < 4; ++n) {
+                const int ch = c0 + 16 * n + lr;
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-                wfr[n][kb] = *reinterpret_cast<const uint4*>(w1 + (i64)(ch < a.C ? ch : c0) * CIN + 8 * lg + 32 * kb);
+                for (int kb = 0; kb < KB; ++kb)
+                    wfr[n][kb] = *reinterpret_cast<const uint4*>(w1 + (i64)(ch < a.C ? ch : c0) * CIN + 8 * lg + 32 * kb);
+            }
         }
     }
+    auto w1frag = [&](const int n, const int kb) -> uint4 {
+        if constexpr (W1_LDS) {
+            const int r = 16 * n + lr;
+            return *reinterpret_cast<const uint4*>(wk_smem + W1_OFF + (r * (CIN / 8) + ((lg + 4 * kb) ^ (r & 15))) * 16);
+        } else {
+            return wfr[n][kb];
+        }
+    };
     // the walk's chunk offsets inside a slot: [row parity][h]
     const int s0w = (jq & 1) + ((jq >> 1) << 2);
     const int ykey[2][2] = {{(cv ^ s0w) * 8, (cv ^ (s0w + 2)) * 8}, {(cv ^ (8 + s0w)) * 8, (cv ^ (8 + s0w + 2)) * 8}};
@@ -400,7 +422,7 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
                     for (int n = 0; n < 4; ++n) {
                         wk_f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int kb = 0; kb < KB; ++kb) acc = wk_mfma(wfr[n][kb], afr[t][kb], acc);
+                        for (int kb = 0; kb < KB; ++kb) acc = wk_mfma(w1frag(n, kb), afr[t][kb], acc);
                         *reinterpret_cast<uint2*>(dst + (((4 * n + lg) ^ lr) << 3)) = make_uint2(pk_bf16(acc[0], acc[1]), pk_bf16(acc[2], acc[3]));
                     }
                 }
@@ -595,18 +617,40 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW2_RC : WK_MINW2) void dw_spat
     }
     __syncthreads();
 
-        uint4 wfr[4][KB];
+        // B operand: column cv of channel tile n = W1 row c0 + 4 cv + n, k group lane >> 4.  Registers for CIN = 64; for CIN = 128 a
+    // swizzled LDS copy of the slice behind the gradient tile (chunk c of row r at c ^ ((r >> 2) & 15))
+    constexpr bool W1_LDS = CIN > 64;
+    const unsigned W1_OFF = (unsigned)rows_qmax * (unsigned)(NG * Wqp * 256);
+    uint4 wfr[W1_LDS ? 1 : 4][KB];
     if constexpr (CIN > 0) {
-        // B operand: column cv of channel tile n = W1 row c0 + 4 cv + n, k group lane >> 4
         const T* w1 = reinterpret_cast<const T*>(a.w1);
+        if constexpr (W1_LDS) {
+            constexpr int CH = CIN / 8;
+            for (int i = tid; i < 64 * CH; i += NT) {
+                const int r = i / CH, c = i % CH;
+                const int ch = c0 + r;
+                *reinterpret_cast<uint4*>(wk_smem + W1_OFF + (r * CH + (c ^ ((r >> 2) & 15))) * 16) =
+                    *reinterpret_cast<const uint4*>(w1 + (i64)(ch < a.C ? ch : c0) * CIN + 8 * c);
+            }
+            __syncthreads();
+        } else {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int ch = chs + n;
+            for (int n = 0; n < 4; ++n) {
+                const int ch = chs + n;
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-                wfr[n][kb] = *reinterpret_cast<const uint4*>(w1 + (i64)(ch < a.C ? ch : chs) * CIN + 8 * (lane >> 4) + 32 * kb);
+                for (int kb = 0; kb < KB; ++kb)
+                    wfr[n][kb] = *reinterpret_cast<const uint4*>(w1 + (i64)(ch < a.C ? ch : chs) * CIN + 8 * (lane >> 4) + 32 * kb);
+            }
         }
     }
+    auto w1frag = [&](const int n, const int kb) -> uint4 {
+        if constexpr (W1_LDS) {
+            const int r = 4 * cv + n;
+            return *reinterpret_cast<const uint4*>(wk_smem + W1_OFF + (r * (CIN / 8) + (((lane >> 4) + 4 * kb) ^ cv)) * 16);
+        } else {
+            return wfr[n][kb];
+        }
+    };
     // A operand: tile pixel lane & 15 = (quad (lane & 15) >> 2 of this wave, pixel (lane & 15) & 3)
     const int apl = (tid >> 6) * 4 + ((lane & 15) >> 2);
     const int agrp = apl / LPW, ajj = apl % LPW;
@@ -704,7 +748,7 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW2_RC : WK_MINW2) void dw_spat
                     for (int n = 0; n < 4; ++n) {
                         acc[n] = wk_f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int kb = 0; kb < KB; ++kb) acc[n] = wk_mfma(afr[kb], wfr[n][kb], acc[n]);
+                        for (int kb = 0; kb < KB; ++kb) acc[n] = wk_mfma(afr[kb], w1frag(n, kb), acc[n]);
                     }
 #pragma unroll
                     for (int p = 0; p < 4; ++p) ry[p] = make_uint2(pk_bf16(acc[0][p], acc[1][p]), pk_bf16(acc[2][p], acc[3][p]));
@@ -852,7 +896,7 @@ bool dw_spatial_bwd_walk_supported(const DwSpatialBwd& a, int dtype) {
 // whole 64-channel slices (an MFMA needs every lane of the wave: no channel tail)
 bool dw_spatial_bwd_rc_supported(const DwSpatialBwd& a, int dtype) {
     if (!dw_spatial_bwd_walk_supported(a, dtype)) return false;
-    if (a.Cin != 64 || a.C % 64) return false;
+    if ((a.Cin != 64 && a.Cin != 128) || a.C % 64) return false;
     if (a.a0_ld % 8 || a.a0_ld < a.Cin) return false;
     if ((i64)a.Hin * a.Win * a.a0_ld >= (1ll << 31)) return false;
     return true;
@@ -874,7 +918,7 @@ static int launch_s2(const DwSpatialBwd& a, hipStream_t s) {
     R = (R + 1) & ~1;
     if (R > a.Hin) R = (a.Hin + 1) & ~1;
     const int rows_qmax = R / 2 + 1;
-    size_t lds = (size_t)rows_qmax * rowb;
+    size_t lds = (size_t)rows_qmax * rowb + (CIN > 64 ? (size_t)64 * CIN * 2 : 0);
     if (lds < 9 * 64 * sizeof(float)) lds = 9 * 64 * sizeof(float);
     if (lds > 150 * 1024) return dwn_set_error(-5, "dw_spatial_bwd: rows_band too large for the LDS tile");
     auto kern = dw_spatial_bwd_s2_kernel<LPW, CIN>;
@@ -897,7 +941,7 @@ static int launch_s2(const DwSpatialBwd& a, hipStream_t s) {
 template <int LPW, int RB, int CIN>
 static int launch_s1c(const DwSpatialBwd& a, hipStream_t s) {
     constexpr int NG = 16 / LPW, Wqp = LPW + 1;
-    const size_t lds = (size_t)NG * (RB + 2) * Wqp * 256 + (size_t)RB * 4096;
+    const size_t lds = (size_t)NG * (RB + 2) * Wqp * 256 + (size_t)RB * 4096 + (CIN > 64 ? (size_t)64 * CIN * 2 : 0);
     auto kern = dw_spatial_bwd_s1c_kernel<LPW, RB, CIN>;
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         (void)hipGetLastError();
@@ -942,8 +986,8 @@ static int launch_walk_c(const DwSpatialBwd& a, hipStream_t s) {
 int launch_dw_spatial_bwd_walk(const DwSpatialBwd& a, hipStream_t s) {
     if (a.a0) {
         if (!dw_spatial_bwd_rc_supported(a, DWN_BF16) || !a.w1)
-            return dwn_set_error(-3, "dw_spatial_bwd: rebuilt-y1 mode needs bf16, Cin = 64, C % 64 == 0, w1 and a row-walk plane width");
-        return launch_walk_c<64>(a, s);
+            return dwn_set_error(-3, "dw_spatial_bwd: rebuilt-y1 mode needs bf16, Cin = 64 / 128, C % 64 == 0, w1 and a row-walk plane width");
+        return a.Cin == 64 ? launch_walk_c<64>(a, s) : launch_walk_c<128>(a, s);
     }
     return launch_walk_c<0>(a, s);
 }

@@ -86,7 +86,7 @@ __device__ __forceinline__ void wf_lds_barrier() {
 // of the MFMA layout writes 8 consecutive pairs: 64-dword pairs would all land on the same banks).  y2 is bit-identical to
 // conv_pw + this kernel's CIN = 0 form: same MFMA operand roles and k order as the GEMM, same rounding, same stencil.
 template <int ST, int LPW, int RB, int CIN>
-__global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 ? WF_MINW_RC4 : WF_MINW_RC) : WF_MINW) void dw_spatial_fwd_chain_kernel(const DwSpatialFwd a) {
+__global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW_RC4 : WF_MINW_RC) : WF_MINW) void dw_spatial_fwd_chain_kernel(const DwSpatialFwd a) {
     typedef bf16_t T;
     constexpr int NT = 256, CS = 64, NG = 16 / LPW, NPC = ST * LPW + 1;
     constexpr int PS = CIN > 0 ? 68 : 64;                // dwords between consecutive pairs of a ring row
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 ? WF_MINW_RC4 : WF_MIN
     T* outp = reinterpret_cast<T*>(a.out);
     unsigned* tile = reinterpret_cast<unsigned*>(wf_smem);        // ring: [NG][RQ][NPC][64] dwords
     unsigned* tplane = tile + grp * RQ * rowdw + cv * 4;
-    static_assert(CIN == 0 || CIN == 64, "the y1-rebuilding form is built for 64 input channels");
+    static_assert(CIN == 0 || CIN == 64 || CIN == 128, "the y1-rebuilding form is built for 64 / 128 input channels");
     const unsigned inrow = (unsigned)Win * (unsigned)a.in.ld, outrow = (unsigned)Wout * (unsigned)a.C;
     // staging roles: stride 1 = the walk role (4 channels, own output pair column); stride 2 = 8 channels per lane, one lane
     // per input pair column (16-byte loads)
@@ -162,17 +162,40 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 ? WF_MINW_RC4 : WF_MIN
     // (channel row lr of channel tile n, k group lg) for W1; accumulator register j = channel 16 n + 4 lg + j of pixel lr
     const int lr = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint4 wfr[4][KB];
+    // W1 fragments of this workgroup's 64 channels: registers for CIN = 64 (32 VGPRs); for CIN = 128 a copy of the slice in LDS behind
+    // the ring (16 KB, 16-byte chunk c of row r at chunk c ^ (r & 15): conflict-free ds_read_b128 of a fragment), read per channel tile
+    constexpr bool W1_LDS = CIN > 64;
+    constexpr unsigned RING_BYTES = (unsigned)NG * RQ * rowdw * 4u;
+    uint4 wfr[W1_LDS ? 1 : 4][KB];
     if constexpr (CIN > 0) {
         const T* w1 = reinterpret_cast<const T*>(a.w1);
+        if constexpr (W1_LDS) {
+            constexpr int CH = CIN / 8;
+            for (int i = tid; i < 64 * CH; i += NT) {
+                const int r = i / CH, c = i % CH;
+                const int ch = c0 + r;
+                *reinterpret_cast<uint4*>(wf_smem + RING_BYTES + (r * CH + (c ^ (r & 15))) * 16) =
+                    *reinterpret_cast<const uint4*>(w1 + (i64)(ch < a.C ? ch : c0) * CIN + 8 * c);
+            }
+            __syncthreads();
+        } else {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int ch = c0 + 16 * n + lr;
+            for (int n = 0; n < 4; ++n) {
+                const int ch = c0 + 16 * n + lr;
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-                wfr[n][kb] = *reinterpret_cast<const uint4*>(w1 + (i64)(ch < a.C ? ch : c0) * CIN + 8 * lg + 32 * kb);
+                for (int kb = 0; kb < KB; ++kb)
+                    wfr[n][kb] = *reinterpret_cast<const uint4*>(w1 + (i64)(ch < a.C ? ch : c0) * CIN + 8 * lg + 32 * kb);
+            }
         }
     }
+    auto w1frag = [&](const int n, const int kb) -> uint4 {
+        if constexpr (W1_LDS) {
+            const int r = 16 * n + lr;
+            return *reinterpret_cast<const uint4*>(wf_smem + RING_BYTES + (r * (CIN / 8) + ((lg + 4 * kb) ^ (r & 15))) * 16);
+        } else {
+            return wfr[n][kb];
+        }
+    };
     (void)lr; (void)lg; (void)wave;
 
     // one plane-group row of a0 as MFMA B-operand fragments: [tile pair t][even-x / odd-x pixels][k step]
@@ -221,7 +244,7 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 ? WF_MINW_RC4 : WF_MIN
                         for (int m = n; m < n + NB; ++m) {
                             aE[m] = wf_f32x4_t{0.f, 0.f, 0.f, 0.f}; aO[m] = wf_f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                            for (int kb = 0; kb < KB; ++kb) { aE[m] = wf_mfma(wfr[m][kb], fr[t][0][kb], aE[m]); aO[m] = wf_mfma(wfr[m][kb], fr[t][1][kb], aO[m]); }
+                            for (int kb = 0; kb < KB; ++kb) { const uint4 wa = w1frag(m, kb); aE[m] = wf_mfma(wa, fr[t][0][kb], aE[m]); aO[m] = wf_mfma(wa, fr[t][1][kb], aO[m]); }
                         }
                     }
                     const float4 s4 = *reinterpret_cast<const float4*>(&lcoef[16 * n + 4 * lg]);
@@ -555,10 +578,10 @@ bool dw_spatial_fwd_walk_supported(const DwSpatialFwd& a, int dtype) {
     return true;
 }
 
-// rebuilt-input mode (a.a0 != NULL): bf16, Cin = 64, whole 64-channel slices (an MFMA needs every lane of the wave)
+// rebuilt-input mode (a.a0 != NULL): bf16, Cin = 64 / 128, whole 64-channel slices (an MFMA needs every lane of the wave)
 bool dw_spatial_fwd_rc_walk_supported(const DwSpatialFwd& a, int dtype) {
     if (!dw_spatial_fwd_walk_supported(a, dtype)) return false;
-    if (a.Cin != 64 || a.C % 64) return false;
+    if ((a.Cin != 64 && a.Cin != 128) || a.C % 64) return false;
     if (a.a0_ld % 8 || a.a0_ld < a.Cin) return false;
     if ((i64)a.Hin * a.Win * a.a0_ld >= (1ll << 31)) return false;
     return true;
@@ -567,7 +590,7 @@ bool dw_spatial_fwd_rc_walk_supported(const DwSpatialFwd& a, int dtype) {
 template <int ST, int LPW, int RB, int CIN>
 static int launch_fc(const DwSpatialFwd& a, hipStream_t s) {
     constexpr int NG = 16 / LPW, NPC = ST * LPW + 1, RQ = ST == 1 ? RB + 2 : 2 * RB + 1;
-    const size_t lds = (size_t)NG * RQ * NPC * (CIN > 0 ? 272 : 256);
+    const size_t lds = (size_t)NG * RQ * NPC * (CIN > 0 ? 272 : 256) + (CIN > 64 ? (size_t)64 * CIN * 2 : 0);
     auto kern = dw_spatial_fwd_chain_kernel<ST, LPW, RB, CIN>;
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         (void)hipGetLastError();
@@ -627,8 +650,8 @@ static int launch_fwd_walk_c(const DwSpatialFwd& a, hipStream_t s) {
 int launch_dw_spatial_fwd_walk(const DwSpatialFwd& a, hipStream_t s) {
     if (a.a0) {
         if (!dw_spatial_fwd_rc_walk_supported(a, DWN_BF16) || !a.w1)
-            return dwn_set_error(-3, "dw_spatial_fwd: rebuilt-input mode needs bf16, Cin = 64, C % 64 == 0, w1 and a row-walk plane width");
-        return launch_fwd_walk_c<64>(a, s);
+            return dwn_set_error(-3, "dw_spatial_fwd: rebuilt-input mode needs bf16, Cin = 64 / 128, C % 64 == 0, w1 and a row-walk plane width");
+        return a.Cin == 64 ? launch_fwd_walk_c<64>(a, s) : launch_fwd_walk_c<128>(a, s);
     }
     return launch_fwd_walk_c<0>(a, s);
 }

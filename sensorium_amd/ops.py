@@ -78,7 +78,7 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 _PWL_BWD = {"": 0, "new": 1, "old": 2}[os.environ.get("DWN_PWL_BWD", "")]
 # dwn_block_args.y1_mode: "" = the library leaves y1 (conv_pw's output) unmaterialised in bf16 training where both stencils rebuild it
 # from the block input; DWN_Y1=materialise forces the stored-y1 path (the parity tests run both; same-box A/B runs)
-_Y1_MODE = {"": 0, "free": 0, "materialise": 1}[os.environ.get("DWN_Y1", "")]
+_Y1_MODE = {"": 0, "free": 0, "materialise": 1, "all": 2}[os.environ.get("DWN_Y1", "")]
 
 
 def grad_out(param: torch.Tensor, zero: bool = False) -> torch.Tensor:

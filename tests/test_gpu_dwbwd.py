@@ -160,6 +160,17 @@ def test_rebuilt_y1_matches_stored_y1(case):
     assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-5
 
 
+@pytest.mark.parametrize("case", [(3, 18, 32, 128, 1), (5, 9, 16, 128, 1), (7, 5, 8, 64, 1), (130, 9, 16, 896, 1), (33, 18, 32, 192, 1),
+                                  (3, 36, 64, 64, 2), (5, 18, 32, 128, 2), (7, 9, 16, 64, 2), (129, 18, 32, 896, 2), (9, 1, 16, 64, 2)])
+def test_rebuilt_y1_128_channels(case):
+    """Cin = 128 (blocks 4-6): four k-steps per MFMA tile, the W1 slice in LDS instead of registers."""
+    (d0, w0, s0), (d1, w1, s1) = _stored_vs_rebuilt(*case, cin=128)
+    assert not torch.isnan(d1.float()).any()
+    assert torch.equal(d0.view(torch.int16), d1.view(torch.int16)), "dh1 differs"
+    assert float((w0 - w1).norm() / w0.norm()) < 1e-5
+    assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-5
+
+
 @pytest.mark.parametrize("stride,rows_band", [(1, 2), (1, 4), (2, 2), (2, 4), (2, 6), (2, 12)])
 def test_rebuilt_y1_band_heights(stride, rows_band):
     H, W = (18, 32) if stride == 1 else (36, 64)
@@ -173,8 +184,10 @@ def test_rebuilt_y1_is_refused_where_it_is_not_built():
     a.planes, a.Hin, a.Win, a.Hout, a.Wout, a.C, a.stride, a.ks = 2, 18, 32, 18, 32, 72, 1, 3          # a channel tail
     a.dy.ld = 72; a.y1.ld = 72; a.a0_ld = 64; a.Cin = 64
     assert L.lib.dwn_dw_spatial_bwd_rc_supported(C.byref(a), L.DWN_BF16) == 0
-    a.C = 128; a.dy.ld = 128; a.y1.ld = 128; a.Cin = 128; a.a0_ld = 128                                   # Cin 128: not built
+    a.C = 128; a.dy.ld = 128; a.y1.ld = 128; a.Cin = 256; a.a0_ld = 256                                   # Cin 256: not built
     assert L.lib.dwn_dw_spatial_bwd_rc_supported(C.byref(a), L.DWN_BF16) == 0
+    a.Cin = 128; a.a0_ld = 128
+    assert L.lib.dwn_dw_spatial_bwd_rc_supported(C.byref(a), L.DWN_BF16) == 1
     a.Cin = 64; a.a0_ld = 64
     assert L.lib.dwn_dw_spatial_bwd_rc_supported(C.byref(a), L.DWN_BF16) == 1
     assert L.lib.dwn_dw_spatial_bwd_rc_supported(C.byref(a), L.DWN_F32) == 0

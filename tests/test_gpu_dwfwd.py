@@ -114,6 +114,16 @@ def test_rebuilt_input_matches_stored_input(case):
     assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-5
 
 
+@pytest.mark.parametrize("case", [(3, 18, 32, 128, 1), (5, 9, 16, 128, 1), (7, 5, 8, 64, 1), (130, 9, 16, 896, 1), (33, 18, 32, 192, 1),
+                                  (3, 36, 64, 64, 2), (5, 18, 32, 128, 2), (7, 9, 16, 64, 2), (129, 18, 32, 896, 2), (9, 1, 16, 64, 2)])
+def test_rebuilt_input_128_channels(case):
+    """Cin = 128 (blocks 4-6): four k-steps per MFMA tile, the W1 slice in LDS instead of registers."""
+    (y0, s0), (y1, s1) = _stored_vs_rebuilt(*case, cin=128)
+    assert not torch.isnan(y1.float()).any()
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    assert float(((s0 - s1).abs() / (s0.abs() + 1e-2 * s0.abs().mean())).max()) < 1e-5
+
+
 @pytest.mark.parametrize("stride,rows_band", [(1, 4), (1, 8), (2, 2), (2, 4)])
 def test_rebuilt_input_chunk_heights(stride, rows_band):
     H, W = (18, 32) if stride == 1 else (36, 64)

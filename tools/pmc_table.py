@@ -47,6 +47,7 @@ for k, v in per.items():
                        ("SQ_WAIT_INST_LDS", "wait_inst_lds"), ("SQ_ACTIVE_INST_VALU", "active_valu"), ("SQ_ACTIVE_INST_LDS", "active_lds"),
                        ("SQ_ACTIVE_INST_VMEM", "active_vmem"), ("SQ_ACTIVE_INST_FLAT", "active_flat"), ("SQ_ACTIVE_INST_SCA", "active_sca")):
             if c in avg: row[nme + "_frac_of_wave_cycles"] = round(g(c) / wc, 4)
+    if "SQ_INSTS_MFMA" in avg and "SQ_INSTS_VALU" in avg: row["mfma_per_valu"] = round(g("SQ_INSTS_MFMA") / max(g("SQ_INSTS_VALU"), 1), 4)
     if "SQ_LDS_BANK_CONFLICT" in avg and "SQ_LDS_IDX_ACTIVE" in avg: row["lds_conflict_frac"] = round(g("SQ_LDS_BANK_CONFLICT") / max(g("SQ_LDS_IDX_ACTIVE"), 1), 4)
     if "SQ_INSTS_VALU" in avg and "SQ_ACTIVE_INST_VALU" in avg: row["cyc_per_valu"] = round(g("SQ_ACTIVE_INST_VALU") * 4 / max(g("SQ_INSTS_VALU"), 1), 3)
     rows.append(row)

@@ -79,8 +79,11 @@ def run(planes, Hin, Win, Cc, stride, which, cin=64, rows_band=0):
 
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if a in ("fwd", "bwd")] or ["fwd", "bwd"]
-    bands = [int(a) for a in sys.argv[1:] if a.isdigit()] or [0]
+    bands = [int(a) for a in sys.argv[1:] if a.isdigit() and a != '128'] or [0]
     for wh in which:
         for rb in bands:
             run(1024, 18, 32, 448, 1, wh, rows_band=rb)
             run(1024, 36, 64, 448, 2, wh, rows_band=rb)
+            if "128" in sys.argv:
+                run(1024, 18, 32, 896, 2, wh, cin=128, rows_band=rb)
+                run(1024, 9, 16, 896, 1, wh, cin=128, rows_band=rb)
