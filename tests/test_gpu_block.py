@@ -76,23 +76,27 @@ CASES = [
 ]
 
 
-def y1_free_case(case, dtype):
-    """bf16 training leaves y1 (conv_pw's output) unmaterialised where both stencils rebuild it from the block input: 64 / 128 input
-    channels, whole 64-channel slices, the plane widths of the row-walk kernels (dwn_block_args.y1_mode, csrc/dwn_api.hip)."""
+def y1_free_case(case, dtype, mode="auto"):
+    """bf16 training leaves y1 (conv_pw's output) unmaterialised where both stencils rebuild it from the block input — whole
+    64-channel slices, the plane widths of the row-walk kernels — by default on 64-channel inputs (where that is also faster), with
+    y1_mode 2 ("all") on 128-channel inputs too (dwn_block_args.y1_mode, csrc/dwn_api.hip)."""
     cin, cout, stride, exp, ser, B, T, H, W = case
-    return dtype == torch.bfloat16 and cin in (64, 128) and (W in (32, 16, 8) if stride == 1 else W in (64, 32, 16))
+    cins = (64,) if mode == "auto" else (64, 128)
+    return dtype == torch.bfloat16 and mode != "materialise" and cin in cins and (W in (32, 16, 8) if stride == 1 else W in (64, 32, 16))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("drop", [False, True])
-@pytest.mark.parametrize("y1", ["auto", "materialise"])
+@pytest.mark.parametrize("y1", ["auto", "all", "materialise"])
 def test_block_train_forward_backward(case, dtype, drop, y1):
     cin, cout, stride, exp, ser, B, T, H, W = case
     if drop and cin != 8:
         pytest.skip("drop-path variant only on the small cases")
-    if y1 == "materialise" and not y1_free_case(case, dtype):
+    if y1 == "materialise" and not y1_free_case(case, dtype, "all"):
         pytest.skip("y1 is materialised on this case anyway")
+    if y1 == "all" and y1_free_case(case, dtype, "all") == y1_free_case(case, dtype, "auto"):
+        pytest.skip("same path as the default")
     blk, pe = make_block(cin, cout, stride, exp, ser, seed=cin + stride)
     sd = {"blk." + k: v.clone() for k, v in blk.state_dict().items()}
     torch.manual_seed(1)
@@ -113,7 +117,7 @@ def test_block_train_forward_backward(case, dtype, drop, y1):
     blk = blk.to(dev()).train()
     pe = pe.to(dev())
     blk._capture = True
-    blk._dwn_y1_mode = 1 if y1 == "materialise" else 0
+    blk._dwn_y1_mode = {"auto": 0, "materialise": 1, "all": 2}[y1]
     xd = x.to(dev()).to(dtype).requires_grad_(True)
     if drop:
         blk.drop_path.sample = lambda b, d: drop_scale.to(d)
@@ -124,7 +128,7 @@ def test_block_train_forward_backward(case, dtype, drop, y1):
     ft, gt = (1e-3, 1e-3) if dtype == torch.float32 else (4e-2, 8e-2)
     cap = blk._captured
     # the y1-free path is the one that ran where it is built (and only there)
-    assert (cap["y1"] is None) == (y1 == "auto" and y1_free_case(case, dtype)), "y1 materialisation is not what the case expects"
+    assert (cap["y1"] is None) == y1_free_case(case, dtype, y1), "y1 materialisation is not what the case expects"
     for name in ("y1", "y2", "y3", "y4"):
         if cap[name] is None:
             continue
