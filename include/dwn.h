@@ -113,14 +113,16 @@ typedef struct dwn_gemm_nn_args {
      * sums.  coef3 is the [4][coef3_ld] table scale, shift, mean, invstd. */
     const float* gate3; const float* dps3; const float* coef3; int coef3_ld;
     /* kernel variant: DWN_NN_AUTO = chosen by shape; DWN_NN_XL128 / DWN_NN_XL256 = the 256-row LDS-DMA kernel with 128- / 256-column
-     * tiles wherever its argument constraints hold (bf16, plain loader, store epilogue); DWN_NN_TILE128 = never that kernel (the
-     * tests compare the two bit for bit) */
+     * tiles wherever its argument constraints hold (bf16, plain loader, store epilogue); DWN_NN_KD = the A-direct kernel (deep K,
+     * N % 128 == 0, plain / gate loader, store / K-concat epilogue); DWN_NN_TILE128 = never those kernels (the tests compare them
+     * with the 128-row kernel bit for bit) */
     int variant;
 } dwn_gemm_nn_args;
 #define DWN_NN_AUTO 0
 #define DWN_NN_XL128 1
 #define DWN_NN_XL256 2
-#define DWN_NN_TILE128 3   /* never the 256-row kernel: the 128-row persistent kernel (what the tests compare it with) */
+#define DWN_NN_TILE128 3   /* never the 256-row / A-direct kernels: the 128-row persistent kernel (what the tests compare them with) */
+#define DWN_NN_KD 4        /* the A-direct kernel (deep K, N % 128 == 0: only the weights pass through LDS) wherever its constraints hold */
 
 /* dW[R][Cc] += sum_m load(P)[m][r] * load(Q)[m][c]   (fp32 atomics; dW must be zeroed by the caller) */
 typedef struct dwn_gemm_tn_args {

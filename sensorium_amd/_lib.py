@@ -34,7 +34,7 @@ DWN_F32, DWN_BF16 = 0, 1
 DWN_NREP = 32
 LD_PLAIN, LD_PE, LD_BNACT, LD_AFFINE2, LD_DY3, LD_GATE, LD_CAT1 = 0, 1, 2, 3, 4, 5, 6
 EPI_STORE, EPI_READOUT, EPI_DG, EPI_STORE_CAT, EPI_DH3 = 0, 1, 2, 3, 4
-NN_AUTO, NN_XL128, NN_XL256, NN_TILE128 = 0, 1, 2, 3
+NN_AUTO, NN_XL128, NN_XL256, NN_TILE128, NN_KD = 0, 1, 2, 3, 4
 F32_AUTO, F32_NATIVE, F32_SPLIT3 = 0, 1, 2
 FAMILIES = ("pw_fwd", "dws_fwd", "dwt_fwd", "se_pool", "pwl_fwd", "resid_fwd", "resid_bwd", "pwl_dgrad", "pwl_wgrad",
             "bn3_reduce", "dwt_bwd", "dws_bwd", "pw_dgrad", "pw_wgrad", "cortex_fwd", "cortex_bwd", "readout_fwd",
@@ -242,7 +242,7 @@ class DwnError(RuntimeError):
 
 
 # csrc/Makefile HASH_SRCS, in its order
-HASH_SRCS = ("dwn_api.hip", "dwn_gemm.hip", "dwn_gemm_xl.hip", "dwn_dwconv.hip", "dwn_dwrc.hip", "dwn_dwbwd.hip", "dwn_dwfwd.hip",
+HASH_SRCS = ("dwn_api.hip", "dwn_gemm.hip", "dwn_gemm_xl.hip", "dwn_gemm_kd.hip", "dwn_dwconv.hip", "dwn_dwrc.hip", "dwn_dwbwd.hip", "dwn_dwfwd.hip",
              "dwn_elementwise.hip", "dwn_data.hip", "dwn_common.h", "dwn_internal.h", "dwn_kernels.h", "../../include/dwn.h")
 
 

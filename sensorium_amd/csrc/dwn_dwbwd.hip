@@ -46,6 +46,13 @@ typedef unsigned wk_u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float wk_dot2(unsigned a, unsigned b, float c) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wk_bf16x2_t, a), __builtin_bit_cast(wk_bf16x2_t, b), c, false);
 }
+// first tap of an accumulator: the three-operand form with the constant 0 as addend (hipcc selects v_dot2c_f32_bf16, which
+// accumulates in place, for the builtin and spends a v_mov on zeroing every accumulator: 8 - 16 instructions per walk step)
+__device__ __forceinline__ float wk_dot2z(unsigned a, unsigned b) {
+    float r;
+    asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void wk_unpack(const uint2& r, wk_f2_t& lo, wk_f2_t& hi) {
     lo = wk_f2_t{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)};
     hi = wk_f2_t{__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
@@ -473,7 +480,7 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
                     }
                     const unsigned Z[4] = {pk_bf16(z1[0][0].x, z1[1][0].x), pk_bf16(z1[0][0].y, z1[1][0].y),
                                            pk_bf16(z1[0][1].x, z1[1][1].x), pk_bf16(z1[0][1].y, z1[1][1].y)};
-                    float dz0[4] = {0.f, 0.f, 0.f, 0.f}, dz1[4] = {0.f, 0.f, 0.f, 0.f};
+                    float dz0[4] = {0.f, 0.f, 0.f, 0.f}, dz1[4] = {0.f, 0.f, 0.f, 0.f};       // (wk_dot2z here costs 30 spilled registers)
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy) {
                         __builtin_amdgcn_sched_barrier(0);        // one stencil row's weight vectors live at a time (registers)
@@ -722,9 +729,13 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW2_RC : WK_MINW2) void dw_spat
                 }
                 // 1) data-gradient taps (need only the gradient rows): dz of the four pixels
                 float dz[4][4];
+                // first tap in the three-operand form where registers allow (the stored-y1 form already spills at its budget)
+                if constexpr (CIN == 0) {
 #pragma unroll
-                for (int p = 0; p < 4; ++p) dz[p][0] = dz[p][1] = dz[p][2] = dz[p][3] = 0.f;
-                auto tap_dz = [&](const int dy, const uint4 (&g)[2]) {
+                    for (int p = 0; p < 4; ++p) dz[p][0] = dz[p][1] = dz[p][2] = dz[p][3] = 0.f;
+                }
+                auto tap_dz = [&](const int dy, const uint4 (&g)[2], const bool first_) {
+                    const bool first = first_ && CIN > 0;
                     const uint4 W0 = *reinterpret_cast<const uint4*>(&lwp[(dy * 3 + 0) * CS + cv * 4]);
                     const uint4 W1 = *reinterpret_cast<const uint4*>(&lwp[(dy * 3 + 1) * CS + cv * 4]);
                     const uint4 W2 = *reinterpret_cast<const uint4*>(&lwp[(dy * 3 + 2) * CS + cv * 4]);
@@ -733,13 +744,13 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW2_RC : WK_MINW2) void dw_spat
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const unsigned gm = __builtin_amdgcn_alignbit(gb[q], ga[q], 16);      // (g[wo=2m], g[wo=2m+1])
-                        dz[0][q] = wk_dot2(gm, w0[q], dz[0][q]);
-                        dz[1][q] = wk_dot2(gm, w1[q], dz[1][q]);
-                        dz[2][q] = wk_dot2(gm, w2[q], dz[2][q]);
-                        dz[3][q] = wk_dot2(gb[q], w1[q], dz[3][q]);
+                        dz[0][q] = first ? wk_dot2z(gm, w0[q]) : wk_dot2(gm, w0[q], dz[0][q]);
+                        dz[1][q] = first ? wk_dot2z(gm, w1[q]) : wk_dot2(gm, w1[q], dz[1][q]);
+                        dz[2][q] = first ? wk_dot2z(gm, w2[q]) : wk_dot2(gm, w2[q], dz[2][q]);
+                        dz[3][q] = first ? wk_dot2z(gb[q], w1[q]) : wk_dot2(gb[q], w1[q], dz[3][q]);
                     }
                 };
-                if constexpr (ODD) { tap_dz(0, gnext); __builtin_amdgcn_sched_barrier(0); tap_dz(2, gcur); } else { tap_dz(1, gcur); }
+                if constexpr (ODD) { tap_dz(0, gnext, true); __builtin_amdgcn_sched_barrier(0); tap_dz(2, gcur, false); } else { tap_dz(1, gcur, true); }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (CIN > 0) {
                     // y1 of the thread's quad: acc[n][p] = y1[pixel p][channel 4 cv + n], rounded as the stored tensor reads back

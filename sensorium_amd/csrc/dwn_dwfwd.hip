@@ -50,6 +50,13 @@ __device__ __forceinline__ WfBlk wf_block() {
 __device__ __forceinline__ float wf_dot2(unsigned a, unsigned b, float c) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wf_bf16x2_t, a), __builtin_bit_cast(wf_bf16x2_t, b), c, false);
 }
+// first tap of an accumulator: the three-operand form with the constant 0 as addend (hipcc selects v_dot2c_f32_bf16, which
+// accumulates in place, for the builtin and spends a v_mov on zeroing every accumulator first: 8 of a walk step's 79 instructions)
+__device__ __forceinline__ float wf_dot2z(unsigned a, unsigned b) {
+    float r;
+    asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void wf_unpack(const uint2& r, wf_f2_t& lo, wf_f2_t& hi) {
     lo = wf_f2_t{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)};
     hi = wf_f2_t{__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
@@ -232,7 +239,10 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
                 const int pln = pg_ * NG + g;
                 const bool okp = pln < a.planes && hi < a.Hin;
                 unsigned* dst = tile_ + ((g * RQ + sl) * NPC + (x >> 1)) * PS + 4 * lg;
-                const bool lo_shift = x != 0;                              // pair (x-1, x): x = 0 pairs with the halo
+                // pair (x-1, x): x = 0 pairs with the halo (low half 0).  With 32 | WIN that is lane row 0 only, which the DPP move zeroes
+                constexpr bool LO_FREE = WIN % 32 == 0;
+                const unsigned lomask = x != 0 ? 0xffffu : 0u, okmask = okp ? 0xffffffffu : 0u;
+                (void)lomask;
                 const bool hi_only = TP == 2 && lr == 0 && x != 0;         // the odd neighbour sits in the previous tile's lane 15
                 const bool extra = x == WIN - 2 || lr == 15;              // this lane's odd pixel opens the next pair
                 constexpr int NB = ST == 1 ? 4 : 2;                         // channel tiles whose MFMAs are issued together (registers)
@@ -281,10 +291,12 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
 #endif
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        // lane - 1's dword (row_shr:1; lane 0 of a 16-lane row gets 0): its low half is this pair's odd pixel
-                        const unsigned prev = (unsigned)__builtin_amdgcn_update_dpp(0, (int)dd[j], 0x111, 0xf, 0xf, false);
-                        d[j] = okp ? ((dd[j] & 0xffff0000u) | (lo_shift ? (prev & 0xffffu) : 0u)) : 0u;
-                        e[j] = okp ? (dd[j] & 0xffffu) : 0u;
+                        // lane - 1's dword (row_shr:1 with bound_ctrl: lane 0 of a 16-lane row reads 0): its low half is this pair's
+                        // odd pixel.  Four instructions per dword: mask, DPP move, bit-field insert, mask.
+                        const unsigned m = dd[j] & okmask;
+                        const unsigned prev = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x111, 0xf, 0xf, true);
+                        d[j] = __builtin_amdgcn_perm(m, LO_FREE ? prev : (prev & lomask), 0x07060100u);      // (m.hi16, prev.lo16)
+                        e[j] = m & 0xffffu;
                     }
                     if (hi_only) {
 #pragma unroll
@@ -474,7 +486,7 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
                         t2[0] = *reinterpret_cast<const uint4*>(tc + sl2 * rowdw);
                         t2[1] = *reinterpret_cast<const uint4*>(tc + sl2 * rowdw + PS);
                         sl2 = sl2 + 1 == RQ ? 0 : sl2 + 1;
-                        float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
+                        float acc0[4], acc1[4];
 #pragma unroll
                         for (int dy = 0; dy < 3; ++dy) {
                             const uint4 p0 = dy == 0 ? t0[0] : dy == 1 ? t1[0] : t2[0];
@@ -482,9 +494,9 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
                             const unsigned x0[4] = {p0.x, p0.y, p0.z, p0.w}, x1[4] = {p1.x, p1.y, p1.z, p1.w};
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                acc0[q] = wf_dot2(x0[q], wp[dy][0][q], acc0[q]);
+                                acc0[q] = dy == 0 ? wf_dot2z(x0[q], wp[dy][0][q]) : wf_dot2(x0[q], wp[dy][0][q], acc0[q]);
                                 acc0[q] = wf_dot2(x1[q], wp[dy][1][q], acc0[q]);
-                                acc1[q] = wf_dot2(x0[q], wp[dy][NWC - 2][q], acc1[q]);
+                                acc1[q] = dy == 0 ? wf_dot2z(x0[q], wp[dy][NWC - 2][q]) : wf_dot2(x0[q], wp[dy][NWC - 2][q], acc1[q]);
                                 acc1[q] = wf_dot2(x1[q], wp[dy][NWC - 1][q], acc1[q]);
                             }
                         }
@@ -510,7 +522,7 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
                             r2[m] = *reinterpret_cast<const uint4*>(tc + sc * rowdw + m * PS);
                         }
                         sa = sc;
-                        float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
+                        float acc0[4], acc1[4];
 #pragma unroll
                         for (int dy = 0; dy < 3; ++dy) {
                             const uint4 p0 = dy == 0 ? r0[0] : dy == 1 ? r1[0] : r2[0];
@@ -519,9 +531,9 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
                             const unsigned x0[4] = {p0.x, p0.y, p0.z, p0.w}, x1[4] = {p1.x, p1.y, p1.z, p1.w}, x2[4] = {p2.x, p2.y, p2.z, p2.w};
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                acc0[q] = wf_dot2(x0[q], wp[dy][0][q], acc0[q]);
+                                acc0[q] = dy == 0 ? wf_dot2z(x0[q], wp[dy][0][q]) : wf_dot2(x0[q], wp[dy][0][q], acc0[q]);
                                 acc0[q] = wf_dot2(x1[q], wp[dy][1][q], acc0[q]);
-                                acc1[q] = wf_dot2(x1[q], wp[dy][0][q], acc1[q]);
+                                acc1[q] = dy == 0 ? wf_dot2z(x1[q], wp[dy][0][q]) : wf_dot2(x1[q], wp[dy][0][q], acc1[q]);
                                 acc1[q] = wf_dot2(x2[q], wp[dy][1][q], acc1[q]);
                             }
                         }

@@ -873,6 +873,7 @@ int launch_gemm_nn(const GemmNN& g, int dtype, hipStream_t s) {
         if (g.b_rows_per_sample <= 0 || g.b_rows_per_sample % 128 || g.groups != 1 || g.K <= bk)
             return dwn_set_error(-2, "gemm_nn: per-sample weights need b_rows_per_sample % 128 == 0, groups == 1, K > one k-tile");
     }
+    if (gemm_nn_kd_eligible(g, dtype)) return launch_gemm_nn_kd(g, s);
     if (gemm_nn_xl_eligible(g, dtype)) return launch_gemm_nn_xl(g, s);
     return dtype == DWN_BF16 ? launch_nn_d<bf16_t>(g, s) : launch_nn_d<float>(g, s);
 }

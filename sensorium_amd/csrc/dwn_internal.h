@@ -15,6 +15,9 @@ int launch_gemm_tn(const GemmTN& g, int dtype, hipStream_t s);
 // 256-row / 8-wave LDS-DMA variant for the load-path-bound shapes (dwn_gemm_xl.hip)
 bool gemm_nn_xl_eligible(const GemmNN& g, int dtype);
 int launch_gemm_nn_xl(const GemmNN& g, hipStream_t s);
+// A-direct kernel for the deep-K, narrow-N shapes: only the weights pass through LDS (dwn_gemm_kd.hip)
+bool gemm_nn_kd_eligible(const GemmNN& g, int dtype);
+int launch_gemm_nn_kd(const GemmNN& g, hipStream_t s);
 int launch_dw_spatial_fwd(const DwSpatialFwd& a, int dtype, hipStream_t s);
 int launch_dw_spatial_bwd(const DwSpatialBwd& a, int dtype, hipStream_t s);
 int launch_dw_temporal_fwd(const DwTemporalFwd& a, int dtype, hipStream_t s);

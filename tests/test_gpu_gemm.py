@@ -79,6 +79,60 @@ def test_gemm_nn_xl_kernel(L, M, N, K, groups, bn):
     assert rel(s0, cf.sum(0)) < 1e-4 and rel(s1, (cf * cf).sum(0)) < 1e-4
 
 
+@pytest.mark.parametrize("form", ["plain", "gate", "cat"])
+@pytest.mark.parametrize("M,N,K,K2", [(128, 128, 128, 128), (1000, 256, 384, 128), (2560, 128, 896, 128), (5120, 256, 1792, 256),
+                                      (40960, 256, 1792, 256)])
+def test_gemm_nn_a_direct_kernel(L, form, M, N, K, K2):
+    """The A-direct kernel (dwn_gemm_kd.hip: conv_pwl with the SE gate on its input, src/models/dwiseneuro.py:117-120, and
+    conv_pw's K-concatenated data gradient, :90-91 backward, of the 128- / 256-channel blocks) forced onto small and ragged-M
+    shapes and at block 8's shape: equal to the 128-row kernel BIT FOR BIT (same k order, same roundings), BatchNorm sums
+    included, and within the bf16 bound of float64."""
+    torch.manual_seed(M + N + K)
+    dtype = torch.bfloat16
+    rows = 128 if M % 128 == 0 else 0                      # samples of 128 rows (the gate form needs whole tiles per sample)
+    if form == "gate" and not rows:
+        pytest.skip("gate form: rows per sample must be a multiple of 128")
+    a = torch.randn(M, K, device=dev()).to(dtype)
+    Kt = K + (K2 if form == "cat" else 0)
+    b = (torch.randn(N, Kt, device=dev()) / Kt ** 0.5).to(dtype)
+    a2 = torch.randn(M, K2, device=dev()).to(dtype)
+    bias = torch.randn(N, device=dev())
+    gate = torch.rand(M // 128 if rows else 1, K, device=dev()) + 0.25
+    out = {}
+    for variant in (L.NN_KD, L.NN_TILE128):
+        c = torch.full((M, N), float("nan"), dtype=dtype, device=dev())
+        st = stats_buffer(N)
+        g = L.GemmNNArgs()
+        g.a = load_desc(L, a, K)
+        g.a_kind = L.LD_PLAIN
+        if form == "gate":
+            g.a.gate = gate.data_ptr(); g.a.gate_ld = K; g.a.rows_per_sample = 128
+            g.a_kind = L.LD_GATE
+        g.b = b.data_ptr(); g.ldb = Kt; g.c = c.data_ptr(); g.ldc = N
+        g.M, g.N, g.K, g.groups = M, N, Kt, 1
+        g.stats = st.data_ptr(); g.stat_nchan = N; g.epi = L.EPI_STORE
+        if form == "cat":
+            g.epi = L.EPI_STORE_CAT; g.a2 = a2.data_ptr(); g.a2_ld = K2; g.K1 = K; g.bias = bias.data_ptr()
+        g.variant = variant
+        L.check(L.lib.dwn_gemm_nn(C.byref(g), _dt(L, dtype), 0, stream()), "gemm_nn")
+        torch.cuda.synchronize()
+        out[variant] = (c, read_stats(st, N))
+    c, (s0, s1) = out[L.NN_KD]
+    c_ref, (r0, r1) = out[L.NN_TILE128]
+    assert not torch.isnan(c.float()).any()
+    assert torch.equal(c.view(torch.int16), c_ref.view(torch.int16))
+    af = a.double()
+    if form == "gate":
+        af = (a.float() * gate.repeat_interleave(128, 0)).to(dtype).double()      # rounded as the loader rounds
+    ref = af @ b[:, :K].double().t()
+    if form == "cat":
+        ref = ref + a2.double() @ b[:, K:].double().t() + bias.double()
+    assert rel(c, ref) < 6e-3
+    cf = c.double()
+    assert rel(s0, cf.sum(0)) < 1e-4 and rel(s1, (cf * cf).sum(0)) < 1e-4
+    assert rel(s0, r0) < 1e-5 and rel(s1, r1) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_nn_exact_small_integers(L, dtype):
     """A = I-like / asymmetric B with small integers: exact in both dtypes, catches any transposed tile map."""
