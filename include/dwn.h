@@ -281,7 +281,7 @@ typedef struct dwn_cortex_args {
     const float* w;                         /* [C][Cin/groups] */
     dwn_bn bn, bnsc;
     const float* drop_scale;
-    const void* dout; void* dx; float* dw;  /* backward */
+    const void* dout; void* dx; float* dw;  /* backward; dw [C][Cin/groups] fp32 (16-byte aligned) is cleared and written by the call */
     const float* dout_mask; int dout_mask_ld; /* optional [B][C] multiplier on dout (readout Dropout1d backward) */
     void* ws; size_t ws_bytes;
     int f32_products;                         /* DWN_F32_AUTO / _NATIVE / _SPLIT3 */

@@ -854,7 +854,10 @@ int dwn_cortex_backward(const dwn_cortex_args* ap, int device, void* stream) {
         PrepArgs pa;
         bool ok = pa.zero(w.zb, ((size_t)(w.ze - w.zb) + 15) & ~(size_t)15);
         ok = ok && pa.packw(a.w, w.wp, a.groups, Ng, Kg, 1, Kg, Ng);       // per group W^T [Kg][Ng]
-        if (!ok) return dwn_set_error(-2, "cortex_backward: workspace arena must be 16-byte aligned");
+        // dw is accumulated with atomics by the weight-gradient product: cleared here, in the same launch (as dwn_block_backward
+        // clears its dw_*), not by the caller
+        ok = ok && pa.zero(a.dw, (size_t)a.C * Kg * sizeof(float));
+        if (!ok) return dwn_set_error(-2, "cortex_backward: workspace arena and dw must be 16-byte aligned (C * Cin / groups a multiple of 4)");
         TRY(k_prep(pa, dt, s));
     }
     TRY(k_cortex_bwd_reduce(a.y, a.x, a.dout, a.dout_mask, a.dout_mask_ld, a.bn.coef, a.bnsc.coef, a.drop_scale, M, a.T,

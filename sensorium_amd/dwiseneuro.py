@@ -338,20 +338,19 @@ class DwiseNeuro(nn.Module):
         return self
 
     def _draw_drop_paths(self, batch: int, device) -> None:
-        """One uniform draw for every stochastic-depth layer of this forward pass (12 layers: 4 small launches instead
-        of 24).  Same distribution as DropPath.sample: factor = Bernoulli(keep) / keep per sample."""
+        """One draw for every stochastic-depth layer of this forward pass (12 layers: 2 small launches instead of 24).  Same
+        distribution as DropPath.sample: factor = Bernoulli(keep) / keep per sample (0 where keep == 0: no 0/0)."""
         layers = [m for m in self.modules() if isinstance(m, DropPath) and m.drop_prob > 0.0 and m.training]
         if not layers:
             return
-        probs = tuple(m.drop_prob for m in layers)
+        key = (tuple(m.drop_prob for m in layers), batch)
         cache = getattr(self, "_dp_keep", None)
-        if cache is None or cache[0] != probs or cache[1].device != device:      # rebuilt when a drop-path schedule changes a rate
-            cache = (probs, torch.tensor([1.0 - q for q in probs], dtype=torch.float32, device=device).unsqueeze(1))
+        if cache is None or cache[0] != key or cache[1].device != device:      # rebuilt when a drop-path schedule changes a rate
+            keep = torch.tensor([1.0 - q for q in key[0]], dtype=torch.float32)
+            inv = torch.where(keep > 0, 1.0 / keep.clamp_min(1e-30), torch.zeros_like(keep))
+            cache = (key, keep.unsqueeze(1).expand(len(layers), batch).contiguous().to(device), inv.unsqueeze(1).to(device))
             self._dp_keep = cache
-        keep = cache[1]
-        u = torch.rand(len(layers), batch, dtype=torch.float32, device=device)
-        # floor(u + keep) is 1 with probability keep; keep == 0 (drop_prob 1): factor 0, as DropPath.sample (no 0/0)
-        factors = torch.where(keep > 0, torch.floor(u + keep) / keep.clamp_min(1e-30), torch.zeros_like(u))
+        factors = torch.bernoulli(cache[1]).mul_(cache[2])
         for m, row in zip(layers, factors.unbind(0)):
             m._pooled = row
 

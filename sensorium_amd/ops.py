@@ -429,7 +429,7 @@ class CortexFn(torch.autograd.Function):
         bn, bnsc = layer.bn.bn, layer.bn_sc.bn
         f32 = dict(dtype=torch.float32, device=dev)
         dgm, dbm, dgs, dbs = grad_out(bn.weight), grad_out(bn.bias), grad_out(bnsc.weight), grad_out(bnsc.bias)
-        dw = grad_out(layer.conv.weight, zero=True)
+        dw = grad_out(layer.conv.weight)             # cleared by dwn_cortex_backward's prep launch
         dx = torch.empty_like(x)
         a = L.CortexArgs()
         a.dtype = _DT[dtype]; a.training = 1; a.B = B; a.T = T; a.Cin = Cin; a.C = Cc

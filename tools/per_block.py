@@ -71,7 +71,7 @@ def classify(seq):
             elif n.startswith("se_pool"):
                 fam, b = "se_pool", blk
                 after_pool = True
-            elif n.startswith("gemm_nn"):
+            elif (n.startswith("gemm_nn") or n.startswith("gemm_kd")):
                 if after_pool:
                     fam, b = "pwl_fwd", blk
                     after_pool = False
@@ -98,7 +98,7 @@ def classify(seq):
                 after_dws = True
             elif n.startswith("pw_bwd_fused"):
                 fam, b = "pw_dgrad", bblk
-            elif n.startswith("gemm_nn"):
+            elif (n.startswith("gemm_nn") or n.startswith("gemm_kd")):
                 fam, b = ("pw_dgrad" if after_dws else "pwl_dgrad"), bblk
             elif n.startswith("gemm_tn"):
                 fam, b = ("pw_wgrad" if after_dws else "pwl_wgrad"), bblk

@@ -21,7 +21,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 FAMILIES = {
     "dws_bwd": ("dw_spatial_bwd",), "dws_fwd": ("dw_spatial_fwd",), "dwt_bwd": ("dw_temporal_bwd",),
     "dwt_fwd": ("dw_temporal_fwd",), "bn3_reduce": ("bn3_bwd_reduce",), "se_pool": ("se_pool",),
-    "gemm_nn": ("gemm_nn_kernel",), "gemm_tn": ("gemm_tn_kernel",),
+    "gemm_nn": ("gemm_nn_kernel", "gemm_nn_xl_kernel", "gemm_kd_kernel"), "gemm_tn": ("gemm_tn_kernel",),
 }
 
 
