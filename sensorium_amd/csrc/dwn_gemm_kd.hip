@@ -58,16 +58,16 @@ static __device__ __forceinline__ void kd_lds_barrier() {           // LDS hand-
     asm volatile("" ::: "memory");
 }
 
-template <int BN, bool GATE, bool CAT>
-__global__ __launch_bounds__(256, (BN == 256 || KD_NG > 1) ? 2 : KD_MINW128) void gemm_kd_kernel(const KdArgs g) {
-    constexpr int BM = 128;
+template <int BN, int RT, bool GATE, bool CAT>
+__global__ __launch_bounds__(256, (BN * RT >= 512 || KD_NG > 1) ? 2 : KD_MINW128) void gemm_kd_kernel(const KdArgs g) {
+    constexpr int BM = 64 * RT;                     // RT 16-row tiles per wave, four waves
     constexpr int NJ = BN / 16;                     // 16-column accumulator tiles per wave row tile
     constexpr int NCH = BN * 4 / 256;               // 16-byte weight chunks a thread stages per k-step
     constexpr int STG = BN * 64;                    // bytes of one weight stage (BN rows x 32 k)
     constexpr int CROW = BN * 2 + 16;               // epilogue staging row stride (bytes)
     constexpr int CPR = BN / 8;                     // 16-byte chunks per output row
     constexpr int NIT = 64 * CPR / 256;             // read-back iterations per 64-row pass
-    constexpr int FRG = BN == 256 ? KD_FRG256 : KD_FRG;                     // weight fragments read from LDS before their MFMAs are issued
+    constexpr int FRG = (BN == 256 || RT == 4) ? KD_FRG256 : KD_FRG;                     // weight fragments read from LDS before their MFMAs are issued
     extern __shared__ __attribute__((aligned(16))) unsigned char kd_smem[];
     unsigned char* const sB = kd_smem;
     unsigned char* const sC = kd_smem + 2 * STG;
@@ -85,11 +85,11 @@ __global__ __launch_bounds__(256, (BN == 256 || KD_NG > 1) ? 2 : KD_MINW128) voi
     const int nk = g.K >> 5;                        // 32-deep k-steps (a multiple of 4)
 
     // ---- A fragments: rows m0 + 32 wave + 16 i + lr (clamped: rows past M are computed and never stored)
-    const bf16_t* pa[2];
-    [[maybe_unused]] const bf16_t* pa2[2];
+    const bf16_t* pa[RT];
+    [[maybe_unused]] const bf16_t* pa2[RT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int m = m0 + 32 * wave + 16 * i + lr;
+    for (int i = 0; i < RT; ++i) {
+        int m = m0 + 16 * RT * wave + 16 * i + lr;
         m = m < g.M ? m : g.M - 1;
         pa[i] = g.A + (i64)m * g.lda + 8 * lg;
         if constexpr (CAT) pa2[i] = g.A2 + (i64)m * g.a2_ld + 8 * lg;
@@ -97,12 +97,13 @@ __global__ __launch_bounds__(256, (BN == 256 || KD_NG > 1) ? 2 : KD_MINW128) voi
     // A ring: NG groups of four k-steps.  NG = 2 loads a whole group at once (a row's 256 contiguous bytes requested together, four
     // to eight k-steps ahead) at the price of a wave per SIMD: measured slower (pw_dgrad block 4: 369 vs 351 us), so NG = 1
     constexpr int NG = KD_NG;
-    uint4 ar[4 * NG][2];
-    auto load_a = [&](int ks, uint4 (&dst)[2]) {
+    constexpr int AD = RT == 4 ? 2 : 4 * NG;          // ring slots (k-steps of A in flight): 128 accumulator registers leave room for two
+    uint4 ar[AD][RT];
+    auto load_a = [&](int ks, uint4 (&dst)[RT]) {
         ks = ks < nk ? ks : nk - 1;                 // past the end: a valid address, the data is never used
         const int k = ks << 5;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RT; ++i) {
             const bf16_t* src = pa[i] + k;
             if constexpr (CAT) src = k >= g.K1 ? pa2[i] + (k - g.K1) : src;       // a pointer select, not a branch around the load
             dst[i] = *reinterpret_cast<const uint4*>(src);
@@ -128,15 +129,15 @@ __global__ __launch_bounds__(256, (BN == 256 || KD_NG > 1) ? 2 : KD_MINW128) voi
         for (int i = 0; i < NCH; ++i) *reinterpret_cast<uint4*>(sB + stage * STG + sboff[i]) = make_uint4(src[i].x, src[i].y, src[i].z, src[i].w);
     };
 
-    kd_f32x4_t acc[2][NJ];
+    kd_f32x4_t acc[RT][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = kd_f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // ---- prologue: four k-steps of A and two of the weights in flight, the sample's gate row in LDS, weight stage 0 written
 #pragma unroll
-    for (int u = 0; u < 4 * NG; ++u) load_a(u, ar[u]);
+    for (int u = 0; u < AD; ++u) load_a(u, ar[u]);
     load_b(0, bs[0]);
     load_b(1, bs[1]);
     if constexpr (GATE) {
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(256, (BN == 256 || KD_NG > 1) ? 2 : KD_MINW128) voi
     auto step = [&](auto uc, auto gc, const int ks) {
             constexpr int u = decltype(uc)::value;
             constexpr int ao = 4 * decltype(gc)::value;          // first ring slot of this k-step's group
+            constexpr int as = AD == 2 ? (u & 1) : ao + u;        // this k-step's ring slot
             // weights of k-step ks + 1 (loaded two steps ago) into the stage step ks - 1 has released; then k-step ks + 3's loads
             {
                 constexpr int sb = (u + 1) & 1;
@@ -167,13 +169,15 @@ __global__ __launch_bounds__(256, (BN == 256 || KD_NG > 1) ? 2 : KD_MINW128) voi
                     bs[sb][i] = *reinterpret_cast<const uint4*>(pb[i] + kb);
                 }
             }
-            uint4 af[2] = {ar[ao + u][0], ar[ao + u][1]};
+            uint4 af[RT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) af[i] = ar[as][i];
             if constexpr (GATE) {
                 const float4 g0 = *reinterpret_cast<const float4*>(sgate + (ks << 5) + 8 * lg);
                 const float4 g1 = *reinterpret_cast<const float4*>(sgate + (ks << 5) + 8 * lg + 4);
                 const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < RT; ++i) {
                     float v[8];
                     unpack16<bf16_t>(af[i], v);
 #pragma unroll
@@ -194,14 +198,16 @@ __global__ __launch_bounds__(256, (BN == 256 || KD_NG > 1) ? 2 : KD_MINW128) voi
 #pragma unroll
                 for (int j = 0; j < FRG; ++j)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < RT; ++i)
                         acc[i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(kd_bf16x8_t, wf[j]), __builtin_bit_cast(kd_bf16x8_t, af[i]),
                                                                                  acc[i][j0 + j], 0, 0, 0);
             }
             // A rows are 128-byte lines of which a k-step uses 64 bytes: the loads of two consecutive k-steps are issued back to back
             // (after the odd step, into the two slots just consumed), so that the second half of a line is requested while the
             // first is still in flight in the L1 — issued a step apart, every load was an L1 miss of its own
-            if constexpr (NG == 2) {
+            if constexpr (AD == 2) {
+                load_a(ks + 2, ar[as]);
+            } else if constexpr (NG == 2) {
                 if constexpr (u == 3) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) load_a(ks + 5 + q, ar[ao + q]);
@@ -226,11 +232,12 @@ __global__ __launch_bounds__(256, (BN == 256 || KD_NG > 1) ? 2 : KD_MINW128) voi
 #pragma unroll
     for (int e = 0; e < 8; ++e) { st0[e] = 0.f; st1[e] = 0.f; }
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        if ((wave >> 1) == p) {
+    for (int p = 0; p < BM / 64; ++p) {
+        // rows 64 p .. 64 p + 63 of the tile: waves 2p, 2p + 1 (RT = 2) or wave p (RT = 4)
+        if (16 * RT * wave / 64 == p) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = 32 * (wave & 1) + 16 * i + lr;
+            for (int i = 0; i < RT; ++i) {
+                const int row = (16 * RT * wave) % 64 + 16 * i + lr;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int col = 16 * j + 4 * lg;
@@ -306,18 +313,18 @@ bool gemm_nn_kd_eligible(const GemmNN& g, int dtype) {
     return g.K >= 512 && g.M >= 8192 && (g.N == 256 || (g.N == 128 && g.a_kind == LD_GATE));
 }
 
-template <int BN, bool GATE, bool CAT>
+template <int BN, int RT, bool GATE, bool CAT>
 static int launch_kd_t(const KdArgs& a, hipStream_t s) {
     const size_t smem = 2 * (size_t)BN * 64 + 64 * ((size_t)BN * 2 + 16) + 2 * (size_t)BN * 4 + (GATE ? (size_t)a.K * 4 : 0);
     static bool attr_done = false;                         // (idempotent; a benign race at worst sets it twice)
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kd_kernel<BN, GATE, CAT>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kd_kernel<BN, RT, GATE, CAT>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return dwn_set_error((int)e, hipGetErrorString(e));
         attr_done = true;
     }
     const unsigned tiles = (unsigned)a.ntm * (unsigned)a.ntn;
     const unsigned grid = (tiles + 7u) & ~7u;
-    hipLaunchKernelGGL((gemm_kd_kernel<BN, GATE, CAT>), dim3(grid), dim3(256), smem, s, a);
+    hipLaunchKernelGGL((gemm_kd_kernel<BN, RT, GATE, CAT>), dim3(grid), dim3(256), smem, s, a);
     DWN_CHECK_LAUNCH();
     return 0;
 }
@@ -334,14 +341,17 @@ int launch_gemm_nn_kd(const GemmNN& g, hipStream_t s) {
     const bool gate = g.a_kind == LD_GATE;
     a.gate = gate ? g.a.gate : nullptr; a.gate_ld = gate ? g.a.gate_ld : 0; a.rows_per_sample = gate ? g.a.rows_per_sample : 1;
     a.stats = g.stats; a.stat_nchan = g.stat_nchan;
-    a.ntm = (g.M + 127) / 128;
-    // 256-column tiles read A once; they need two resident workgroups per CU's worth of tiles to fill the chip
-    const bool wide = KD_WIDE && g.N % 256 == 0 && (i64)a.ntm * (g.N / 256) >= 512;
+    // 256-column tiles read A once; they need two resident workgroups per CU's worth of tiles to fill the chip.  (256-ROW tiles at
+    // 128 columns — RT = 4, the weights re-read from L2 half as often — measured the same time as 128-row tiles, 360 us at
+    // 589824 x 128 x 1024, against 310 us for the kernel with both operands in LDS: not built.)
+    const int ntm128 = (g.M + 127) / 128;
+    const bool wide = KD_WIDE && g.N % 256 == 0 && (i64)ntm128 * (g.N / 256) >= 512;
+    a.ntm = ntm128;
     a.ntn = wide ? g.N / 256 : g.N / 128;
     if (wide) {
-        if (gate) return launch_kd_t<256, true, false>(a, s);
-        return cat ? launch_kd_t<256, false, true>(a, s) : launch_kd_t<256, false, false>(a, s);
+        if (gate) return launch_kd_t<256, 2, true, false>(a, s);
+        return cat ? launch_kd_t<256, 2, false, true>(a, s) : launch_kd_t<256, 2, false, false>(a, s);
     }
-    if (gate) return launch_kd_t<128, true, false>(a, s);
-    return cat ? launch_kd_t<128, false, true>(a, s) : launch_kd_t<128, false, false>(a, s);
+    if (gate) return launch_kd_t<128, 2, true, false>(a, s);
+    return cat ? launch_kd_t<128, 2, false, true>(a, s) : launch_kd_t<128, 2, false, false>(a, s);
 }

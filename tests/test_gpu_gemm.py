@@ -89,7 +89,7 @@ def test_gemm_nn_a_direct_kernel(L, form, M, N, K, K2):
     included, and within the bf16 bound of float64."""
     torch.manual_seed(M + N + K)
     dtype = torch.bfloat16
-    rows = 128 if M % 128 == 0 else 0                      # samples of 128 rows (the gate form needs whole tiles per sample)
+    rows = 256 if M % 256 == 0 else 128 if M % 128 == 0 else 0        # rows per sample (the gate form needs whole tiles per sample)
     if form == "gate" and not rows:
         pytest.skip("gate form: rows per sample must be a multiple of 128")
     a = torch.randn(M, K, device=dev()).to(dtype)
@@ -97,7 +97,7 @@ def test_gemm_nn_a_direct_kernel(L, form, M, N, K, K2):
     b = (torch.randn(N, Kt, device=dev()) / Kt ** 0.5).to(dtype)
     a2 = torch.randn(M, K2, device=dev()).to(dtype)
     bias = torch.randn(N, device=dev())
-    gate = torch.rand(M // 128 if rows else 1, K, device=dev()) + 0.25
+    gate = torch.rand(M // rows if rows else 1, K, device=dev()) + 0.25
     out = {}
     for variant in (L.NN_KD, L.NN_TILE128):
         c = torch.full((M, N), float("nan"), dtype=dtype, device=dev())
@@ -106,7 +106,7 @@ def test_gemm_nn_a_direct_kernel(L, form, M, N, K, K2):
         g.a = load_desc(L, a, K)
         g.a_kind = L.LD_PLAIN
         if form == "gate":
-            g.a.gate = gate.data_ptr(); g.a.gate_ld = K; g.a.rows_per_sample = 128
+            g.a.gate = gate.data_ptr(); g.a.gate_ld = K; g.a.rows_per_sample = rows
             g.a_kind = L.LD_GATE
         g.b = b.data_ptr(); g.ldb = Kt; g.c = c.data_ptr(); g.ldc = N
         g.M, g.N, g.K, g.groups = M, N, Kt, 1
@@ -123,7 +123,7 @@ def test_gemm_nn_a_direct_kernel(L, form, M, N, K, K2):
     assert torch.equal(c.view(torch.int16), c_ref.view(torch.int16))
     af = a.double()
     if form == "gate":
-        af = (a.float() * gate.repeat_interleave(128, 0)).to(dtype).double()      # rounded as the loader rounds
+        af = (a.float() * gate.repeat_interleave(rows, 0)).to(dtype).double()      # rounded as the loader rounds
     ref = af @ b[:, :K].double().t()
     if form == "cat":
         ref = ref + a2.double() @ b[:, K:].double().t() + bias.double()
