@@ -122,6 +122,24 @@ struct RasterIdx {
 // v_exp_f32 + v_rcp_f32 (1 ulp each): an IEEE fp32 division would cost ~10 VALU instructions per element
 __device__ __forceinline__ float sigmoidf_(float h) { return __builtin_amdgcn_rcpf(1.0f + __expf(-h)); }
 __device__ __forceinline__ float siluf_(float h) { return h * sigmoidf_(h); }
+// two sigmoids with the multiply and the add packed (v_pk_mul_f32 / v_pk_add_f32 are the scalar instructions' arithmetic, two lanes
+// at a time; left to itself hipcc emits them per element: 2 of the 4.5 instructions of a SiLU).  Bit-identical to sigmoidf_:
+// __expf(-h) = exp2(-h * log2(e)) = exp2(h * -log2(e)).
+typedef float dwn_f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ dwn_f2_t sigmoid2f_(dwn_f2_t h) {
+    const dwn_f2_t t = h * dwn_f2_t{-0x1.715476p+0f, -0x1.715476p+0f};
+    const dwn_f2_t d = dwn_f2_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + dwn_f2_t{1.0f, 1.0f};
+    return dwn_f2_t{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+// N sigmoids (N even), pairwise
+template <int N> __device__ __forceinline__ void sigmoid_n(const float* h, float* s) {
+    static_assert(N % 2 == 0, "pairs");
+#pragma unroll
+    for (int i = 0; i < N; i += 2) {
+        const dwn_f2_t r = sigmoid2f_(dwn_f2_t{h[i], h[i + 1]});
+        s[i] = r.x; s[i + 1] = r.y;
+    }
+}
 // SqueezeExcite pooling sums are accumulated as 64-bit fixed point in units of 2^-32: integer addition is associative, so the
 // sums do not depend on the order in which lanes, waves and workgroups add (fp32 atomics made the gate — and through bf16
 // roundings every later activation — differ from run to run).  A float of magnitude >= 2^-8 converts exactly; smaller ones
@@ -132,6 +150,19 @@ __device__ __forceinline__ float pool_unfix(long long s) { return (float)((doubl
 __device__ __forceinline__ float silu_gradf_(float h) {
     float s = sigmoidf_(h);
     return s * (1.0f + h * (1.0f - s));
+}
+// v[i] = silu(v[i]) / g[i] = silu'(h[i]) for N (even) values: the same arithmetic as siluf_ / silu_gradf_, sigmoids in pairs
+template <int N> __device__ __forceinline__ void silu_n(float* v) {
+    float s[N];
+    sigmoid_n<N>(v, s);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] * s[i];
+}
+template <int N> __device__ __forceinline__ void silu_grad_n(const float* h, float* g) {
+    float s[N];
+    sigmoid_n<N>(h, s);
+#pragma unroll
+    for (int i = 0; i < N; ++i) g[i] = s[i] * (1.0f + h[i] * (1.0f - s[i]));
 }
 
 // ---- 4-channel vectors (16 B fp32 / 8 B bf16): the unit of the streaming (stencil / elementwise) kernels.
@@ -206,10 +237,8 @@ __device__ __forceinline__ void load_op(const LoadDesc& d, i64 row, int col, flo
         ld_coef<KC>(d.v1 + col, s);
         ld_coef<KC>(d.v2 + col, t);
 #pragma unroll
-        for (int i = 0; i < KC; ++i) {
-            float h = fmaf(o[i], s[i], t[i]);
-            o[i] = d.act ? siluf_(h) : h;
-        }
+        for (int i = 0; i < KC; ++i) o[i] = fmaf(o[i], s[i], t[i]);
+        if (d.act) silu_n<KC>(o);
         if (d.gate) {
             int b = (int)(r32 / (unsigned)d.rows_per_sample);
             float g[KC];
@@ -243,10 +272,13 @@ __device__ __forceinline__ void load_op(const LoadDesc& d, i64 row, int col, flo
         int b = (int)(r32 / (unsigned)d.rows_per_sample);
         ld_coef<KC>(d.gate + (i64)b * d.gate_ld + col, g);
         ld_coef<KC>(d.gate2 + (i64)b * d.gate_ld + col, g2);
+        float h[KC], sp[KC];
+#pragma unroll
+        for (int i = 0; i < KC; ++i) h[i] = fmaf(y[i], s[i], t[i]);
+        silu_grad_n<KC>(h, sp);
 #pragma unroll
         for (int i = 0; i < KC; ++i) {
-            float h = fmaf(y[i], s[i], t[i]);
-            float dh = fmaf(o[i], g[i], g2[i]) * silu_gradf_(h);
+            float dh = fmaf(o[i], g[i], g2[i]) * sp[i];
             o[i] = fmaf(a1[i], dh, fmaf(a2[i], y[i], a3[i]));
         }
     }
@@ -287,7 +319,8 @@ template <int KIND, typename T> struct ColCoef {
             for (int i = 0; i < KC; ++i) o[i] *= g[i];
         } else if constexpr (KIND == LD_BNACT) {
 #pragma unroll
-            for (int i = 0; i < KC; ++i) { float h = fmaf(o[i], c1[i], c2[i]); o[i] = d.act ? siluf_(h) : h; }
+            for (int i = 0; i < KC; ++i) o[i] = fmaf(o[i], c1[i], c2[i]);
+            if (d.act) silu_n<KC>(o);
             if (d.gate) {
                 gate_for(d, row);
 #pragma unroll
@@ -302,10 +335,13 @@ template <int KIND, typename T> struct ColCoef {
             float y[KC];
             unpack16<T>(q, y);
             gate_for(d, row);
+            float h[KC], sp[KC];
+#pragma unroll
+            for (int i = 0; i < KC; ++i) h[i] = fmaf(y[i], c4[i], c5[i]);
+            silu_grad_n<KC>(h, sp);
 #pragma unroll
             for (int i = 0; i < KC; ++i) {
-                float h = fmaf(y[i], c4[i], c5[i]);
-                float dh = fmaf(o[i], g[i], g2[i]) * silu_gradf_(h);
+                float dh = fmaf(o[i], g[i], g2[i]) * sp[i];
                 o[i] = fmaf(c1[i], dh, fmaf(c2[i], y[i], c3[i]));
             }
         }

@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const wk_f2_t hh = y[h][q] * bs2[q] + bt2[q];
-                            const wk_f2_t sg = wk_f2_t{sigmoidf_(hh.x), sigmoidf_(hh.y)};
+                            const wk_f2_t sg = sigmoid2f_(hh);
                             z1[h][q] = hh * sg;
                             dsl[h][q] = sg * (1.0f + hh * (1.0f - sg));
                         }
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW2_RC : WK_MINW2) void dw_spat
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const wk_f2_t hh = y[q] * bs2[q] + bt2[q];
-                        const wk_f2_t sg = wk_f2_t{sigmoidf_(hh.x), sigmoidf_(hh.y)};
+                        const wk_f2_t sg = sigmoid2f_(hh);
                         z[q] = hh * sg;
                         dsl[q] = sg * (1.0f + hh * (1.0f - sg));
                     }

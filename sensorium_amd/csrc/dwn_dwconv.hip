@@ -93,7 +93,8 @@ template <> __device__ __forceinline__ void unpack_pairs<float>(const uint4& r, 
 
 __device__ __forceinline__ void bn_silu4(float* v, const float* s, const float* t) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = siluf_(fmaf(v[i], s[i], t[i]));
+    for (int i = 0; i < 4; ++i) v[i] = fmaf(v[i], s[i], t[i]);
+    silu_n<4>(v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(NT, 4) void dw_spatial_fwd_kernel(const DwSpatialFw
                         for (int i = 0; i < 4; ++i) {
                             const f2_t y = f2_t{__uint_as_float(rw[i] << 16), __uint_as_float(rw[i] & 0xffff0000u)};
                             const f2_t h = y * s8[i] + t8[i];
-                            const f2_t z = h * f2_t{sigmoidf_(h.x), sigmoidf_(h.y)};
+                            const f2_t z = h * sigmoid2f_(h);
                             o[i] = pk_bf16(z.x, z.y);
                         }
                         tile16[f * SV + scv] = okv[u] ? make_uint4(o[0], o[1], o[2], o[3]) : make_uint4(0, 0, 0, 0);
@@ -365,8 +366,8 @@ __global__ __launch_bounds__(NT, 4) void dw_spatial_fwd_pair_kernel(const DwSpat
                         const f2_t ya = f2_t{__uint_as_float(wa[i] << 16), __uint_as_float(wa[i] & 0xffff0000u)};
                         const f2_t yb = f2_t{__uint_as_float(wb[i] << 16), __uint_as_float(wb[i] & 0xffff0000u)};
                         const f2_t ha = ya * s8[i] + t8[i], hb = yb * s8[i] + t8[i];
-                        const f2_t za = ha * f2_t{sigmoidf_(ha.x), sigmoidf_(ha.y)};
-                        const f2_t zb = hb * f2_t{sigmoidf_(hb.x), sigmoidf_(hb.y)};
+                        const f2_t za = ha * sigmoid2f_(ha);
+                        const f2_t zb = hb * sigmoid2f_(hb);
                         o[2 * i] = pack_bf16x2(za.x, zb.x) & msk[u];
                         o[2 * i + 1] = pack_bf16x2(za.y, zb.y) & msk[u];
                     }
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, (ST == 1 ? DWS_BWD_MINB1 : 3)) voi
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const f2_t h = y[i] * bs2[i] + bt2[i];
-                    const f2_t sg = f2_t{sigmoidf_(h.x), sigmoidf_(h.y)};
+                    const f2_t sg = sigmoid2f_(h);
                     z1[i] = h * sg;
                     dsl[i] = sg * (1.0f + h * (1.0f - sg));
                 }
@@ -850,10 +851,10 @@ __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFw
                     if constexpr (ZOUT) {
                         float z[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            z[i] = siluf_(fmaf(round_t<T>(acc[i]), zs[i], zt[i]));     // BN3 + SiLU of the value a stored y3 holds
-                            ps[i] += round_t<T>(z[i]);
-                        }
+                        for (int i = 0; i < 4; ++i) z[i] = fmaf(round_t<T>(acc[i]), zs[i], zt[i]);     // BN3 + SiLU of the value a stored y3 holds
+                        silu_n<4>(z);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ps[i] += round_t<T>(z[i]);
                         st4<T>(op + t * tstride, z);
                     } else {
                         st4<T>(op + t * tstride, acc);
@@ -926,11 +927,17 @@ __global__ __launch_bounds__(256, TB >= 8 ? 2 : 3) void dw_temporal_bwd_kernel(c
         float p[4], q[4];
         V4<T>::unpack(rp, p);
         V4<T>::unpack(rq, q);
+        [[maybe_unused]] float sp4[4];
+        if constexpr (DYK == LD_DY3) {
+            float h4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h4[i] = fmaf(q[i], s3[i], t3[i]);
+            silu_grad_n<4>(h4, sp4);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if constexpr (DYK == LD_DY3) {
-                float h = fmaf(q[i], s3[i], t3[i]);
-                float dh = fmaf(p[i], g[i], g2[i]) * silu_gradf_(h);
+                float dh = fmaf(p[i], g[i], g2[i]) * sp4[i];
                 o[i] = fmaf(a1[i], dh, fmaf(a2[i], q[i], a3[i]));
             } else {
                 o[i] = fmaf(a1[i], p[i], fmaf(a2[i], q[i], a3[i]));
@@ -973,10 +980,13 @@ __global__ __launch_bounds__(256, TB >= 8 ? 2 : 3) void dw_temporal_bwd_kernel(c
                     else { win[KT - 1][0] = win[KT - 1][1] = win[KT - 1][2] = win[KT - 1][3] = 0.f; }
                     float y[4], dh[4];
                     V4<T>::unpack(ry[u], y);
+                    float h4[4], sg4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) h4[i] = fmaf(y[i], bs[i], bt[i]);
+                    sigmoid_n<4>(h4, sg4);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float h = fmaf(y[i], bs[i], bt[i]);
-                        float sg = sigmoidf_(h);
+                        const float h = h4[i], sg = sg4[i];
                         float z2 = h * sg;
                         float dz = 0.f;
 #pragma unroll
@@ -1241,7 +1251,7 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, DWS_BWD_PAIR_MINW) void dw_spatial
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const f2_t hh = y[h][q] * bs2[q] + bt2[q];
-                            const f2_t sg = f2_t{sigmoidf_(hh.x), sigmoidf_(hh.y)};
+                            const f2_t sg = sigmoid2f_(hh);
                             z1[h][q] = hh * sg;
                             dsl[h][q] = sg * (1.0f + hh * (1.0f - sg));
                         }
@@ -1436,10 +1446,13 @@ __global__ __launch_bounds__(256, DWT_RC_MINW) void dw_temporal_bwd_rc_kernel(co
             for (int k = 0; k < KT; ++k) win[k][0] = win[k][1] = win[k][2] = win[k][3] = 0.f;
             auto activate = [&](const raw_t& raw, float* y, float* z, float* ds) {
                 V4<T>::unpack(raw, y);
+                float h4[4], sg4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h4[i] = fmaf(y[i], bs[i], bt[i]);
+                sigmoid_n<4>(h4, sg4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float h = fmaf(y[i], bs[i], bt[i]);
-                    const float sg = sigmoidf_(h);
+                    const float h = h4[i], sg = sg4[i];
                     z[i] = h * sg;
                     ds[i] = sg * (1.0f + h * (1.0f - sg));
                 }

@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
                         const wf_f2_t yE = wf_f2_t{__uint_as_float(pk0 << 16), __uint_as_float(pk1 << 16)};
                         const wf_f2_t yO = wf_f2_t{__uint_as_float(pk0 & 0xffff0000u), __uint_as_float(pk1 & 0xffff0000u)};
                         const wf_f2_t hE = yE * sc2[jp] + sh2[jp], hO = yO * sc2[jp] + sh2[jp];
-                        const wf_f2_t zE = hE * wf_f2_t{sigmoidf_(hE.x), sigmoidf_(hE.y)};
-                        const wf_f2_t zO = hO * wf_f2_t{sigmoidf_(hO.x), sigmoidf_(hO.y)};
+                        const wf_f2_t zE = hE * sigmoid2f_(hE);
+                        const wf_f2_t zO = hO * sigmoid2f_(hO);
                         dd[2 * jp] = pk_bf16(zO.x, zE.x);                    // (odd x, even x)
                         dd[2 * jp + 1] = pk_bf16(zO.y, zE.y);
                     }
@@ -354,14 +354,14 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
                     wf_unpack(rlo, y0, y1v);
                     {
                         const wf_f2_t h0 = y0 * bs2[0] + bt2[0], h1 = y1v * bs2[1] + bt2[1];
-                        z[0][0] = h0 * wf_f2_t{sigmoidf_(h0.x), sigmoidf_(h0.y)};
-                        z[0][1] = h1 * wf_f2_t{sigmoidf_(h1.x), sigmoidf_(h1.y)};
+                        z[0][0] = h0 * sigmoid2f_(h0);
+                        z[0][1] = h1 * sigmoid2f_(h1);
                     }
                     wf_unpack(rhi, y0, y1v);
                     {
                         const wf_f2_t h0 = y0 * bs2[0] + bt2[0], h1 = y1v * bs2[1] + bt2[1];
-                        z[1][0] = h0 * wf_f2_t{sigmoidf_(h0.x), sigmoidf_(h0.y)};
-                        z[1][1] = h1 * wf_f2_t{sigmoidf_(h1.x), sigmoidf_(h1.y)};
+                        z[1][0] = h0 * sigmoid2f_(h0);
+                        z[1][1] = h1 * sigmoid2f_(h1);
                     }
                     return make_uint4(pk_bf16(z[0][0].x, z[1][0].x), pk_bf16(z[0][0].y, z[1][0].y), pk_bf16(z[0][1].x, z[1][1].x), pk_bf16(z[0][1].y, z[1][1].y));
                 };
@@ -417,8 +417,8 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
                         const wf_f2_t ya = wf_f2_t{__uint_as_float(wa[i] << 16), __uint_as_float(wa[i] & 0xffff0000u)};
                         const wf_f2_t yb = wf_f2_t{__uint_as_float(wb[i] << 16), __uint_as_float(wb[i] & 0xffff0000u)};
                         const wf_f2_t ha = ya * s8[i] + t8[i], hb = yb * s8[i] + t8[i];
-                        const wf_f2_t za = ha * wf_f2_t{sigmoidf_(ha.x), sigmoidf_(ha.y)};
-                        const wf_f2_t zb = hb * wf_f2_t{sigmoidf_(hb.x), sigmoidf_(hb.y)};
+                        const wf_f2_t za = ha * sigmoid2f_(ha);
+                        const wf_f2_t zb = hb * sigmoid2f_(hb);
                         o[2 * i] = pk_bf16(za.x, zb.x) & m;
                         o[2 * i + 1] = pk_bf16(za.y, zb.y) & m;
                     }

@@ -1057,7 +1057,8 @@ __global__ __launch_bounds__(256) void se_pool_kernel(LoadDesc z3, int C, int ro
                 float v[KC];
                 unpack16<T>(raw[u], v);
 #pragma unroll
-                for (int i = 0; i < KC; ++i) v[i] = siluf_(fmaf(v[i], sc[i], sh[i]));
+                for (int i = 0; i < KC; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
+                silu_n<KC>(v);
                 if (z3out) st_vec<T>(z3out + ((i64)b * rows_per_sample + r) * C + chan, v);
 #pragma unroll
                 for (int i = 0; i < KC; ++i) acc[i] += round_t<T>(v[i]);
@@ -1485,8 +1486,12 @@ __global__ __launch_bounds__(256) void bn3_bwd_reduce_kernel(LoadDesc d, const f
                 float du[KC], y[KC], dh[KC];
                 unpack16<T>(rp[u], du);
                 unpack16<T>(ry[u], y);
+                float h[KC], sp[KC];
 #pragma unroll
-                for (int i = 0; i < KC; ++i) dh[i] = fmaf(du[i], g[i], g2[i]) * silu_gradf_(fmaf(y[i], sc[i], sh[i]));
+                for (int i = 0; i < KC; ++i) h[i] = fmaf(y[i], sc[i], sh[i]);
+                silu_grad_n<KC>(h, sp);
+#pragma unroll
+                for (int i = 0; i < KC; ++i) dh[i] = fmaf(du[i], g[i], g2[i]) * sp[i];
                 if (dh_out) st_vec<T>(dh_out + row * d.ld + chan, dh);      // may alias d.p (element-wise in place)
 #pragma unroll
                 for (int i = 0; i < KC; ++i) { float r = round_t<T>(dh[i]); s0[i] += r; s1[i] += r * (y[i] - m3[i]) * i3[i]; }

@@ -604,7 +604,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                             float y[KC], dh[KC];
                             unpack16<T>(zraw[it], y);
 #pragma unroll
-                            for (int i = 0; i < KC; ++i) dh[i] = fmaf(v[i], gt3[i], gp3[i]) * silu_gradf_(fmaf(y[i], sc3[i], sh3[i]));
+                            for (int i = 0; i < KC; ++i) dh[i] = fmaf(y[i], sc3[i], sh3[i]);
+                            silu_grad_n<KC>(dh, dh);
+#pragma unroll
+                            for (int i = 0; i < KC; ++i) dh[i] = fmaf(v[i], gt3[i], gp3[i]) * dh[i];
                             const uint4 packed = pack16<T>(dh);
                             *reinterpret_cast<uint4*>(Cp + (i64)m * g.ldc + ccol0 + ncol_e) = packed;
                             if (g.stats) {
@@ -648,7 +651,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
                             ld_coef<KC>(g.dps3 + (i64)b * g.dg_ld + ncol, gp3);
                         }
 #pragma unroll
-                        for (int i = 0; i < KC; ++i) dh[i] = fmaf(v[i], gt3[i], gp3[i]) * silu_gradf_(fmaf(y[i], sc3[i], sh3[i]));
+                        for (int i = 0; i < KC; ++i) dh[i] = fmaf(y[i], sc3[i], sh3[i]);
+                        silu_grad_n<KC>(dh, dh);
+#pragma unroll
+                        for (int i = 0; i < KC; ++i) dh[i] = fmaf(v[i], gt3[i], gp3[i]) * dh[i];
                         const uint4 packed = pack16<T>(dh);
                         *reinterpret_cast<uint4*>(Cp + (i64)m * g.ldc + ccol0 + ncol) = packed;
                         if (g.stats) {
