@@ -114,7 +114,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const GemmNN g) {
     constexpr int A_CH = BM * 8 / 256;
     constexpr int B_CH = BN * 8 / 256;
     constexpr int CROW = BN * (int)sizeof(T) + ((SINGLE == 3 && NN_DMA_NST >= 4) ? 0 : 16);     // epilogue staging row stride (bytes)
-    constexpr int CROWS = TT<T>::IS_BF16 ? 128 : 32;   // rows staged per epilogue pass (bf16: whole tile, one pass)
+    // rows staged per epilogue pass (bf16: the whole tile in one pass — except the dh3 epilogue at 128 columns, whose per-pass
+    // y3 prefetch (CROWS * CPR / 256 16-byte registers) on top of 64 accumulators spills at 128 rows: 64, or 32 in the k-loop form)
+    constexpr int CROWS = TT<T>::IS_BF16 ? ((EPI == EPI_DH3 && BN == 128) ? (SINGLE == 0 ? 32 : 64) : 128) : 32;
     constexpr int NPASS = BM / CROWS;
     constexpr int CPR = BN / KC;                       // 16-byte chunks per output row
     // resident variants hold NKT k-tiles of both operands (SINGLE == 2: K <= two k-tiles); with 128 columns the
@@ -821,9 +823,11 @@ static bool nn_use_dma(const GemmNN& g, int bn) {
 template <typename T, int ALD, int EPI>
 static int launch_nn_t(const GemmNN& g, hipStream_t s) {
     constexpr int BK = 128 / (int)sizeof(T);
-    // the dh3 epilogue keeps four per-column coefficient vectors live: at 128 columns it spills (88-140 B/lane of
-    // scratch, measured 2.7 TB/s); the 64-column tile fits (224 VGPRs) and the extra A re-reads stay in the XCD's L2
-    const bool n64 = g.N <= 64 || EPI == EPI_DH3;
+    // the dh3 epilogue keeps four per-column coefficient vectors live: with a whole 128 x 128 tile per epilogue pass it spills
+    // (88-140 B/lane of scratch, measured 2.7 TB/s) and ran on 64-column tiles until round 5; staged in passes of 64 (32) rows it
+    // fits, and where the channel count is a multiple of 128 the wider tile halves the A re-reads from L2 (stand-alone
+    // 162 -> 148 us at 147456 x 896 x 128, 270 -> 238 us at K = 256; 448 columns = 3.5 tiles: no gain, stays at 64)
+    const bool n64 = g.N <= 64 || (EPI == EPI_DH3 && !(TT<T>::IS_BF16 && g.N % 128 == 0));
     if constexpr (HasSingle<ALD, EPI>::value) {
         if (g.K <= BK) return n64 ? launch_nn_k<T, ALD, EPI, 64, 1>(g, s) : launch_nn_k<T, ALD, EPI, 128, 1>(g, s);
     }
