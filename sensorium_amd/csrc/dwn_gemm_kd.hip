@@ -22,9 +22,6 @@
 #include "dwn_internal.h"
 #include <type_traits>
 
-#ifndef KD_NG
-#define KD_NG 1
-#endif
 #ifndef KD_FRG
 #define KD_FRG 2
 #endif
@@ -59,7 +56,7 @@ static __device__ __forceinline__ void kd_lds_barrier() {           // LDS hand-
 }
 
 template <int BN, int RT, bool GATE, bool CAT>
-__global__ __launch_bounds__(256, (BN * RT >= 512 || KD_NG > 1) ? 2 : KD_MINW128) void gemm_kd_kernel(const KdArgs g) {
+__global__ __launch_bounds__(256, BN * RT >= 512 ? 2 : KD_MINW128) void gemm_kd_kernel(const KdArgs g) {
     constexpr int BM = 64 * RT;                     // RT 16-row tiles per wave, four waves
     constexpr int NJ = BN / 16;                     // 16-column accumulator tiles per wave row tile
     constexpr int NCH = BN * 4 / 256;               // 16-byte weight chunks a thread stages per k-step
@@ -67,7 +64,7 @@ __global__ __launch_bounds__(256, (BN * RT >= 512 || KD_NG > 1) ? 2 : KD_MINW128
     constexpr int CROW = BN * 2 + 16;               // epilogue staging row stride (bytes)
     constexpr int CPR = BN / 8;                     // 16-byte chunks per output row
     constexpr int NIT = 64 * CPR / 256;             // read-back iterations per 64-row pass
-    constexpr int FRG = (BN == 256 || RT == 4) ? KD_FRG256 : KD_FRG;                     // weight fragments read from LDS before their MFMAs are issued
+    constexpr int FRG = BN == 256 ? KD_FRG256 : KD_FRG;                     // weight fragments read from LDS before their MFMAs are issued
     extern __shared__ __attribute__((aligned(16))) unsigned char kd_smem[];
     unsigned char* const sB = kd_smem;
     unsigned char* const sC = kd_smem + 2 * STG;
@@ -94,11 +91,7 @@ __global__ __launch_bounds__(256, (BN * RT >= 512 || KD_NG > 1) ? 2 : KD_MINW128
         pa[i] = g.A + (i64)m * g.lda + 8 * lg;
         if constexpr (CAT) pa2[i] = g.A2 + (i64)m * g.a2_ld + 8 * lg;
     }
-    // A ring: NG groups of four k-steps.  NG = 2 loads a whole group at once (a row's 256 contiguous bytes requested together, four
-    // to eight k-steps ahead) at the price of a wave per SIMD: measured slower (pw_dgrad block 4: 369 vs 351 us), so NG = 1
-    constexpr int NG = KD_NG;
-    constexpr int AD = RT == 4 ? 2 : 4 * NG;          // ring slots (k-steps of A in flight): 128 accumulator registers leave room for two
-    uint4 ar[AD][RT];
+    uint4 ar[4][RT];                                // A ring: four k-steps in flight
     auto load_a = [&](int ks, uint4 (&dst)[RT]) {
         ks = ks < nk ? ks : nk - 1;                 // past the end: a valid address, the data is never used
         const int k = ks << 5;
@@ -137,7 +130,7 @@ __global__ __launch_bounds__(256, (BN * RT >= 512 || KD_NG > 1) ? 2 : KD_MINW128
 
     // ---- prologue: four k-steps of A and two of the weights in flight, the sample's gate row in LDS, weight stage 0 written
 #pragma unroll
-    for (int u = 0; u < AD; ++u) load_a(u, ar[u]);
+    for (int u = 0; u < 4; ++u) load_a(u, ar[u]);
     load_b(0, bs[0]);
     load_b(1, bs[1]);
     if constexpr (GATE) {
@@ -154,10 +147,8 @@ __global__ __launch_bounds__(256, (BN * RT >= 512 || KD_NG > 1) ? 2 : KD_MINW128
     // whole rows, conflict-free)
     const unsigned char* const fb = sB + lr * 64 + ((lg ^ ((0 - (lr >> 2)) & 3)) * 16);
     // one k-step; u = ks & 3 is a compile-time constant so that every ring index is static (a runtime index sends the rings to scratch)
-    auto step = [&](auto uc, auto gc, const int ks) {
+    auto step = [&](auto uc, const int ks) {
             constexpr int u = decltype(uc)::value;
-            constexpr int ao = 4 * decltype(gc)::value;          // first ring slot of this k-step's group
-            constexpr int as = AD == 2 ? (u & 1) : ao + u;        // this k-step's ring slot
             // weights of k-step ks + 1 (loaded two steps ago) into the stage step ks - 1 has released; then k-step ks + 3's loads
             {
                 constexpr int sb = (u + 1) & 1;
@@ -171,7 +162,7 @@ __global__ __launch_bounds__(256, (BN * RT >= 512 || KD_NG > 1) ? 2 : KD_MINW128
             }
             uint4 af[RT];
 #pragma unroll
-            for (int i = 0; i < RT; ++i) af[i] = ar[as][i];
+            for (int i = 0; i < RT; ++i) af[i] = ar[u][i];
             if constexpr (GATE) {
                 const float4 g0 = *reinterpret_cast<const float4*>(sgate + (ks << 5) + 8 * lg);
                 const float4 g1 = *reinterpret_cast<const float4*>(sgate + (ks << 5) + 8 * lg + 4);
@@ -186,9 +177,8 @@ __global__ __launch_bounds__(256, (BN * RT >= 512 || KD_NG > 1) ? 2 : KD_MINW128
                 }
             }
             const unsigned char* const st = fb + (u & 1) * STG;
-            // weight fragments FRG at a time into registers of their own, then their MFMAs: left to itself the compiler reads every
-            // fragment into ONE register quad and the k-step becomes a chain of NJ dependent LDS round trips (~1000 cycles per
-            // k-step and wave measured: that chain, not memory, set the first version's time)
+            // weight fragments FRG at a time into registers of their own, then their MFMAs (FRG = 1, 2, 4, 8 measured within 1 % of each
+            // other; 2 is what fits three waves per SIMD at 128 columns, 1 at 256 columns where 128 accumulators leave no room)
 #pragma unroll
             for (int j0 = 0; j0 < NJ; j0 += FRG) {
                 uint4 wf[FRG];
@@ -204,26 +194,15 @@ __global__ __launch_bounds__(256, (BN * RT >= 512 || KD_NG > 1) ? 2 : KD_MINW128
             }
             // A rows are 128-byte lines of which a k-step uses 64 bytes: the loads of two consecutive k-steps are issued back to back
             // (after the odd step, into the two slots just consumed), so that the second half of a line is requested while the
-            // first is still in flight in the L1 — issued a step apart, every load was an L1 miss of its own
-            if constexpr (AD == 2) {
-                load_a(ks + 2, ar[as]);
-            } else if constexpr (NG == 2) {
-                if constexpr (u == 3) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) load_a(ks + 5 + q, ar[ao + q]);
-                }
-            } else if constexpr (u & 1) { load_a(ks + 3, ar[u - 1]); load_a(ks + 4, ar[u]); }
+            // first is still in flight in the L1
+            if constexpr (u & 1) { load_a(ks + 3, ar[u - 1]); load_a(ks + 4, ar[u]); }
             kd_lds_barrier();
     };
-    auto group = [&](auto gc, const int ks0) {
-        step(std::integral_constant<int, 0>{}, gc, ks0);
-        step(std::integral_constant<int, 1>{}, gc, ks0 + 1);
-        step(std::integral_constant<int, 2>{}, gc, ks0 + 2);
-        step(std::integral_constant<int, 3>{}, gc, ks0 + 3);
-    };
-    for (int ks0 = 0; ks0 < nk; ks0 += 4 * NG) {
-        group(std::integral_constant<int, 0>{}, ks0);
-        if constexpr (NG == 2) { if (ks0 + 4 < nk) group(std::integral_constant<int, 1>{}, ks0 + 4); }
+    for (int ks0 = 0; ks0 < nk; ks0 += 4) {
+        step(std::integral_constant<int, 0>{}, ks0);
+        step(std::integral_constant<int, 1>{}, ks0 + 1);
+        step(std::integral_constant<int, 2>{}, ks0 + 2);
+        step(std::integral_constant<int, 3>{}, ks0 + 3);
     }
 
     // ---- epilogue: 64 rows per pass through LDS (waves 2p, 2p + 1 own the rows of pass p)
