@@ -14,6 +14,9 @@
 extern __shared__ __attribute__((aligned(16))) unsigned char wf_smem[];
 
 
+#ifndef WF_PRIO
+#define WF_PRIO 1          // issue priority of the staging / rebuild phase (0 = off)
+#endif
 typedef float wf_f2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(2))) __bf16 wf_bf16x2_t;
 typedef unsigned wf_u32x2_t __attribute__((ext_vector_type(2)));
@@ -335,6 +338,9 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
             const int s = chunk * RB;
             const int hi_s = ST * s;                     // first input row staged by this chunk
             // ---------------- stage SiLU(BN1(y1)) rows hi_s .. hi_s + NR - 1, x-pair-packed, into their ring slots
+            // (at raised issue priority: the other workgroups of the CU are mostly in their walk, whose LDS reads and dot products
+            // can wait — this phase ends in the barrier all four waves of this workgroup need; measured -4 ... -7 % on the rebuilt form)
+            __builtin_amdgcn_s_setprio(WF_PRIO);
             if constexpr (CIN > 0) {
                 // ---------------- rebuild SiLU(BN1(y1)) of input rows hi_s .. hi_s + NR - 1 from a0: wave w takes rows w, w + 4, ...
                 if constexpr (NR == 4) {
@@ -456,6 +462,7 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
                     }
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             wf_lds_barrier();
             // ---------------- walk down this chunk's output rows of the thread's output pair column (outputs 2jj, 2jj+1)
             const int o_lo = ST == 1 ? (s > 0 ? s - 1 : 0) : s;
