@@ -79,6 +79,9 @@ __device__ __forceinline__ void block_stats_flush(float* lstat, const float* s0,
     }
 }
 
+#ifndef DWT_PRIO
+#define DWT_PRIO 1         // issue priority while a wave issues its next global loads (0 = off)
+#endif
 typedef float f2_t __attribute__((ext_vector_type(2)));
 // two adjacent channels as one register pair: the compiler emits v_pk_fma_f32 / v_pk_mul_f32 without shuffles
 template <typename T> __device__ __forceinline__ void unpack_pairs(const typename V4<T>::raw_t& r, f2_t& lo, f2_t& hi);
@@ -1463,12 +1466,16 @@ __global__ __launch_bounds__(256, DWT_RC_MINW) void dw_temporal_bwd_rc_kernel(co
                 if (j < a.T) activate(ld4_raw<T>(y2p + e0 + j * tstride), yw[P + j], zw[P + j], dsw[P + j]);
             for (int t0 = -P; t0 < a.T; t0 += TB) {
                 raw_t rp[TB], ry[TB];
+                // load issue at raised priority: a streaming kernel's next loads should leave before the other waves' arithmetic gets
+                // the issue slot (measured: 240 -> 227 us per launch in the step; the forward kernel and se_pool, whose vector ALUs are half as busy, gain nothing)
+                __builtin_amdgcn_s_setprio(DWT_PRIO);
 #pragma unroll
                 for (int u = 0; u < TB; ++u) {
                     const int td = t0 + u + P, ty = t0 + u + 2 * P;          // frames of dh3 / y2 fetched for output frame t0+u
                     rp[u] = ld4_raw<T>(dpp + e0 + (td < a.T ? td : 0) * tstride);
                     ry[u] = ld4_raw<T>(y2p + e0 + (ty < a.T ? ty : 0) * tstride);
                 }
+                __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                 for (int u = 0; u < TB; ++u) {
                     const int t = t0 + u;
