@@ -155,9 +155,11 @@ typedef struct dwn_dw_spatial_fwd_args {
     int impl;           /* 0: the library's choice (chained row-walk kernels where they apply); 1: the pair / generic kernels, the
                          * second implementation the tests compare bit for bit */
     /* rebuilt-input mode (a0 != NULL; dwn_dw_spatial_fwd_rc_supported): in.p is NOT read — the kernel rebuilds the rows of
-     * y1 = a0 . w1^T it needs on the matrix cores, rounded to bf16 as conv_pw's stored output reads back (dwiseneuro.py:90-91),
-     * from the block input a0 [rows][a0_ld] (Cin channels) and w1 = conv_pw's weight [C][Cin] rounded to bf16, row-major;
-     * in.v1 / in.v2 (BatchNorm-1 scale / shift) as usual.  conv_pw + spat_covn_dw in one pass over a 7x narrower input. */
+     * y1 = a0 . w1^T it needs on the matrix cores (dwiseneuro.py:90-91) from the block input a0 [rows][a0_ld] (Cin channels) and
+     * w1 = conv_pw's weight [C][Cin] rounded to bf16, row-major, and applies in.v1 / in.v2 (BatchNorm-1 scale / shift) + SiLU to
+     * the fp32 accumulators (since round 6 the product is not rounded to bf16 first: the result is the reference arithmetic with
+     * one rounding fewer than conv_pw's stored output + the stored-input form).  conv_pw + spat_covn_dw in one pass over a 7x
+     * narrower input. */
     const void* a0; long long a0_ld; const void* w1; int Cin;
 } dwn_dw_spatial_fwd_args;
 
@@ -171,10 +173,10 @@ typedef struct dwn_dw_spatial_bwd_args {
     double* stats;
     int rows_band;
     int impl;           /* as in dwn_dw_spatial_fwd_args */
-    /* rebuilt-y1 mode (a0 != NULL; dwn_dw_spatial_bwd_rc_supported): y1.p is NOT read — the kernel rebuilds the y1 rows it needs as
-     * a0 . w1^T on the matrix cores, rounded to bf16 as conv_pw's stored output reads back (dwiseneuro.py:90-91), from the block
-     * input a0 [rows][a0_ld] (Cin channels, the positional encoding included) and w1 = conv_pw's weight [C][Cin] rounded to
-     * bf16, row-major.  y1.v1..v4 (BatchNorm-1 coefficients) as usual. */
+    /* rebuilt-y1 mode (a0 != NULL; dwn_dw_spatial_bwd_rc_supported): y1.p is NOT read — the kernel rebuilds the y1 values it needs
+     * as a0 . w1^T on the matrix cores (dwiseneuro.py:90-91; the fp32 accumulators, not rounded to bf16: the same values the
+     * rebuilt-input forward activates) from the block input a0 [rows][a0_ld] (Cin channels, the positional encoding included)
+     * and w1 = conv_pw's weight [C][Cin] rounded to bf16, row-major.  y1.v1..v4 (BatchNorm-1 coefficients) as usual. */
     const void* a0; long long a0_ld; const void* w1; int Cin;
 } dwn_dw_spatial_bwd_args;
 
@@ -366,9 +368,9 @@ int dwn_gemm_nn(const dwn_gemm_nn_args* a, int dtype, int device, void* stream);
 int dwn_gemm_tn(const dwn_gemm_tn_args* a, int dtype, int device, void* stream);
 int dwn_dw_spatial_fwd(const dwn_dw_spatial_fwd_args* a, int dtype, int device, void* stream);
 int dwn_dw_spatial_bwd(const dwn_dw_spatial_bwd_args* a, int dtype, int device, void* stream);
-/* 1 when dwn_dw_spatial_fwd can run these arguments in rebuilt-input mode (bf16, Cin 64, C % 64 == 0, the row-walk plane widths) */
+/* 1 when dwn_dw_spatial_fwd can run these arguments in rebuilt-input mode (bf16, Cin 64 or 128, C % 64 == 0, the row-walk plane widths) */
 int dwn_dw_spatial_fwd_rc_supported(const dwn_dw_spatial_fwd_args* a, int dtype);
-/* 1 when dwn_dw_spatial_bwd can run these arguments in rebuilt-y1 mode (bf16, Cin 64, C % 64 == 0, the row-walk plane widths) */
+/* 1 when dwn_dw_spatial_bwd can run these arguments in rebuilt-y1 mode (bf16, Cin 64 or 128, C % 64 == 0, the row-walk plane widths) */
 int dwn_dw_spatial_bwd_rc_supported(const dwn_dw_spatial_bwd_args* a, int dtype);
 int dwn_dw_temporal_fwd(const dwn_dw_temporal_fwd_args* a, int dtype, int device, void* stream);
 int dwn_dw_temporal_bwd(const dwn_dw_temporal_bwd_args* a, int dtype, int device, void* stream);

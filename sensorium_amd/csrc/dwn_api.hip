@@ -487,8 +487,9 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
     LoadDesc xin = ld_plain(a0, a.Cin);
     const bool identity_sc = a.stride == 1 && a.Hin == a.Hout && a.Win == a.Wout;
     const bool y1_free = tr && block_y1_free(a);
-    // eval, 64 input channels, row-walk plane widths: the chained stencil's rebuilt-input form is also the faster way to skip conv_pw
-    // (623 vs 768 us on block 0's shape, 276 vs 308 us on blocks 1-3'; the tile-resident kernel of dwn_dwrc.hip keeps the rest)
+    // eval, 64 or 128 input channels, row-walk plane widths: the chained stencil's rebuilt-input form is also the faster way to skip
+    // conv_pw (623 vs 768 us on block 0's shape, 276 vs 308 us on blocks 1-3'; faster than the tile-resident kernel at 128 channels
+    // too: profiles/r5_predict_bf16_kernel_stats.csv); the tile-resident kernel of dwn_dwrc.hip keeps the other geometries
     bool eval_chain = false;
     if (DWN_EVAL_CHAIN && !tr && dt == DWN_BF16) {
         DwSpatialFwd f; memset(&f, 0, sizeof(f));

@@ -19,10 +19,10 @@
 #include <stdlib.h>
 #include <type_traits>
 
-#ifndef WK_MINW
 #ifndef WK_PRIO
 #define WK_PRIO 1          // issue priority of the staging / rebuild phase (0 = off)
 #endif
+#ifndef WK_MINW
 #define WK_MINW 3          // waves per SIMD the walk kernels are compiled for (three 256-thread workgroups per CU)
 #endif
 #ifndef WK_MINW2
@@ -203,12 +203,15 @@ __device__ __forceinline__ WkBlk wk_block() {
     return r;
 }
 
-// CIN > 0: y1 is NOT read — the chunk's rows of this 64-channel slice are REBUILT from the block input a0 (a.a0, Cin = CIN
-// channels, seven times narrower) with v_mfma_f32_16x16x32_bf16 and W1 (a.w1, as rounded to bf16): a wave fetches the a0 rows of
-// its own 8 pixels straight into B-operand fragments (16 pixels = two rows x 8 pixels per MFMA tile), keeps its W1 fragments
-// in registers for the whole launch, rounds the accumulators to bf16 as the stored tensor would read back (bit-identical to
-// conv_pw's output: same operand roles, same k order) and writes them where the LDS-DMA would have put y1.  The slices of a
-// plane group run on one XCD (wk_block), so a0 crosses the fabric once and the other slices find it in that L2.
+// CIN > 0: y1 is NOT read — a thread's y1 values are REBUILT from the block input a0 (a.a0, Cin = CIN channels, seven times
+// narrower) with v_mfma_f32_16x16x32_bf16 and W1 (a.w1, as rounded to bf16), inside the walk and without an LDS round trip (round 6;
+// the stride-2 kernel's scheme): the MFMA runs with the PIXELS as its A operand — tile row 4 g + j = (pixel pair g of this wave's four,
+// row parity j >> 1, x parity j & 1) of two consecutive rows — and W1 rows as B in the order 4 cv + n, so accumulator register j of
+// channel tile n in lane (cv, g) IS y1[row r + (j >> 1)][x = 2 jj + (j & 1)][channel 4 cv + n]: the thread's own 2 x 4 values of two
+// consecutive walk rows, as fp32 accumulators (not rounded to bf16: the forward stencil activates the same accumulators and the
+// Gram-matrix statistics describe them).  A wave fetches its a0 fragments one chunk ahead (each tile's registers are refilled as
+// soon as its MFMAs are issued) and keeps its W1 fragments in registers for the whole launch.  The slices of a plane group run on
+// one XCD (wk_block), so a0 crosses the fabric once and the other slices find it in that L2.
 template <int LPW, int RB, int CIN>
 __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatial_bwd_s1c_kernel(const DwSpatialBwd a) {
     typedef bf16_t T;
@@ -271,13 +274,13 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
     // ... and where this thread finds its two pixels (2jj, 2jj+1) of a row in that block: slots s0 and s0 + 2
     const int jq = pl & 3;
     const unsigned char* yld = wk_smem + RING_BYTES + wave * 1024 + (((jq & 1) + ((jq >> 1) << 2)) * 128) + cv * 8;
-    // ---- rebuilt y1 (CIN > 0): MFMA tile = this wave's 8 pixels of two consecutive rows; lane (lr, lg): tile pixel lr = (row
-    // parity lr >> 3, slot lr & 7), k group lg.  The 8-byte channel chunk c8 of tile pixel lr is stored at chunk c8 ^ lr of its
-    // 128-byte slot (conflict-free ds_write_b64; the walk reads its chunk cv at cv ^ key with key = 8 * row parity + slot).
+    // ---- rebuilt y1 (CIN > 0): lane (lr, lg): A-operand row lr = (pixel pair lr >> 2 of this wave, row parity (lr >> 1) & 1, x parity
+    // lr & 1), k group lg; B-operand column lr = W1 row c0 + 4 lr + n of channel tile n
     const int lr = lane & 15, lg = lane >> 4;
-    // W1 fragments: registers for CIN = 64; for CIN = 128 a swizzled copy of the 64-row slice in LDS behind the y1 rows
+    // W1 fragments: registers for CIN = 64; for CIN = 128 a swizzled copy of the 64-row slice in LDS behind the ring
+    // (16-byte chunk c of row r at chunk c ^ ((r >> 2) & 15): conflict-free ds_read_b128 of a fragment)
     constexpr bool W1_LDS = CIN > 64;
-    constexpr unsigned W1_OFF = RING_BYTES + (unsigned)RB * 4096u;
+    constexpr unsigned W1_OFF = CIN > 0 ? RING_BYTES : RING_BYTES + (unsigned)RB * 4096u;
     uint4 wfr[W1_LDS ? 1 : 4][KB];
     const T* a0src0 = nullptr;
     if constexpr (CIN > 0) {
@@ -287,14 +290,14 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
             for (int i = tid; i < 64 * CH; i += NT) {
                 const int r = i / CH, c = i % CH;
                 const int ch = c0 + r;
-                *reinterpret_cast<uint4*>(wk_smem + W1_OFF + (r * CH + (c ^ (r & 15))) * 16) =
+                *reinterpret_cast<uint4*>(wk_smem + W1_OFF + (r * CH + (c ^ ((r >> 2) & 15))) * 16) =
                     *reinterpret_cast<const uint4*>(w1 + (i64)(ch < a.C ? ch : c0) * CIN + 8 * c);
             }
             __syncthreads();
         } else {
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                const int ch = c0 + 16 * n + lr;
+                const int ch = c0 + 4 * lr + n;
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)
                     wfr[n][kb] = *reinterpret_cast<const uint4*>(w1 + (i64)(ch < a.C ? ch : c0) * CIN + 8 * lg + 32 * kb);
@@ -303,17 +306,13 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
     }
     auto w1frag = [&](const int n, const int kb) -> uint4 {
         if constexpr (W1_LDS) {
-            const int r = 16 * n + lr;
-            return *reinterpret_cast<const uint4*>(wk_smem + W1_OFF + (r * (CIN / 8) + ((lg + 4 * kb) ^ (r & 15))) * 16);
+            const int r = 4 * lr + n;
+            return *reinterpret_cast<const uint4*>(wk_smem + W1_OFF + (r * (CIN / 8) + ((lg + 4 * kb) ^ lr)) * 16);
         } else {
             return wfr[n][kb];
         }
     };
-    // the walk's chunk offsets inside a slot: [row parity][h]
-    const int s0w = (jq & 1) + ((jq >> 1) << 2);
-    const int ykey[2][2] = {{(cv ^ s0w) * 8, (cv ^ (s0w + 2)) * 8}, {(cv ^ (8 + s0w)) * 8, (cv ^ (8 + s0w + 2)) * 8}};
-    const unsigned char* yslot = wk_smem + RING_BYTES + wave * 1024 + s0w * 128;
-    (void)ykey; (void)yslot; (void)lr; (void)lg;
+    (void)lr; (void)lg;
     // staging constants
     const unsigned cmask = (jj > 0 ? 0x0000ffffu : 0u) | 0xffff0000u;          // pair jj = (wo = 2jj-1, wo = 2jj)
     const unsigned colhi = (unsigned)(2 * jj) * (unsigned)a.dy.ld;
@@ -330,10 +329,9 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
         const int dplane = pg * NG + dgrp < a.planes ? pg * NG + dgrp : 0;
         const T* ysrc0 = y1p + ((i64)dplane * Hin * W + dx) * a.y1.ld + dce;
         if constexpr (CIN > 0) {
-            const int tq = lr & 7;                                                  // slot of this lane's tile pixel
-            const int tpx = wave * 8 + ((tq & 4) | ((tq & 1) << 1) | ((tq >> 1) & 1));   // its pixel of the 32-pixel group row
-            const int tplane = pg * NG + tpx / W < a.planes ? pg * NG + tpx / W : 0;
-            a0src0 = reinterpret_cast<const T*>(a.a0) + ((i64)tplane * Hin * W + tpx % W) * a.a0_ld + 8 * lg;
+            const int tpl = wave * 4 + (lr >> 2);                                   // this lane's tile pixel: pair column of the group row
+            const int tplane = pg * NG + tpl / LPW < a.planes ? pg * NG + tpl / LPW : 0;
+            a0src0 = reinterpret_cast<const T*>(a.a0) + ((i64)tplane * Hin * W + 2 * (tpl % LPW) + (lr & 1)) * a.a0_ld + 8 * lg;
         }
         const i64 prow = (i64)psafe * Hin * W;
         const T* y10 = y1p + prow * a.y1.ld;      // (unused for loads: y1 comes from LDS)
@@ -344,17 +342,20 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
         if (jj == 0) *reinterpret_cast<uint4*>(tlast) = make_uint4(0, 0, 0, 0);
         int slot_s = 1;                            // ring slot of gradient row s = chunk * RB   (slot(r) = (r + 1) mod RQ)
         uint4 afr[RB / 2][KB];                     // rebuilt form: a0 fragments of the chunk's rows, two rows per MFMA pixel tile
-        auto load_afr = [&](const int s_) {
+        auto load_afr_t = [&](const int s_, const int t) {        // tile t of chunk s_: rows s_ - 1 + 2 t, s_ + 2 t
             if constexpr (CIN > 0) {
                 const unsigned a0row = (unsigned)W * (unsigned)a.a0_ld;
+                int row = s_ - 1 + 2 * t + ((lr >> 1) & 1);                 // rows outside the plane: any valid address (never used)
+                row = row < 0 ? 0 : (row >= Hin ? Hin - 1 : row);
 #pragma unroll
-                for (int t = 0; t < RB / 2; ++t) {
-                    int row = s_ - 1 + 2 * t + (lr >> 3);                    // rows outside the plane: any valid address (never read back)
-                    row = row < 0 ? 0 : (row >= Hin ? Hin - 1 : row);
+                for (int kb = 0; kb < KB; ++kb)
+                    afr[t][kb] = *reinterpret_cast<const uint4*>(a0src0 + (unsigned)row * a0row + 32 * kb);
+            }
+        };
+        auto load_afr = [&](const int s_) {
+            if constexpr (CIN > 0) {
 #pragma unroll
-                    for (int kb = 0; kb < KB; ++kb)
-                        afr[t][kb] = *reinterpret_cast<const uint4*>(a0src0 + (unsigned)row * a0row + 32 * kb);
-                }
+                for (int t = 0; t < RB / 2; ++t) load_afr_t(s_, t);
             }
         };
         load_afr(0);
@@ -426,35 +427,108 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
                     }
                 }
             }
-            if constexpr (CIN > 0) {
-                // rebuild this wave's y1 blocks: 4 channel tiles x KB k-steps per pixel tile, rounded as stored
-#pragma unroll
-                for (int t = 0; t < RB / 2; ++t) {
-                    unsigned char* dst = wk_smem + RING_BYTES + (2 * t + (lr >> 3)) * 4096 + wave * 1024 + (lr & 7) * 128;
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) {
-                        wk_f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int kb = 0; kb < KB; ++kb) acc = wk_mfma(w1frag(n, kb), afr[t][kb], acc);
-                        *reinterpret_cast<uint2*>(dst + (((4 * n + lg) ^ lr) << 3)) = make_uint2(pk_bf16(acc[0], acc[1]), pk_bf16(acc[2], acc[3]));
-                    }
-                }
-                if (chunk + 1 < nchunks) load_afr(s + RB);      // the next chunk's a0 rows: in flight under the walk below
-            } else {
-                wk_wait_vm0();                      // this wave's y1 blocks have landed (it is their only reader)
-            }
+            if constexpr (CIN == 0) wk_wait_vm0();  // this wave's y1 blocks have landed (it is their only reader)
             __builtin_amdgcn_s_setprio(0);
             wk_lds_barrier();
             // ---------------- walk rows s-1 .. s+RB-2 of this thread's pixel-pair column
             const int r_lo = s > 0 ? s - 1 : 0;
             const int r_hi = s + RB - 1 < Hin ? s + RB - 1 : Hin;          // exclusive
-            if (pvalid && r_lo < r_hi) {
+            const float4 s4 = *reinterpret_cast<const float4*>(&lcoef[cv * 4]), t4 = *reinterpret_cast<const float4*>(&lcoef[CS + cv * 4]);
+            const wk_f2_t bs2[2] = {wk_f2_t{s4.x, s4.y}, wk_f2_t{s4.z, s4.w}}, bt2[2] = {wk_f2_t{t4.x, t4.y}, wk_f2_t{t4.z, t4.w}};
+            // one row of this thread's pixel pair: y[h][q] = y1 of pixel h, channel pair q (fp32)
+            auto row_math = [&](const int r, const uint4 (&g0)[2], const uint4 (&g1)[2], const uint4 (&g2)[2], const wk_f2_t (&y)[2][2]) {
+                wk_f2_t z1[2][2], dsl[2][2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const wk_f2_t hh = y[h][q] * bs2[q] + bt2[q];
+                        const wk_f2_t sg = sigmoid2f_(hh);
+                        z1[h][q] = hh * sg;
+                        dsl[h][q] = sg * (1.0f + hh * (1.0f - sg));
+                    }
+                }
+                const unsigned Z[4] = {pk_bf16(z1[0][0].x, z1[1][0].x), pk_bf16(z1[0][0].y, z1[1][0].y),
+                                       pk_bf16(z1[0][1].x, z1[1][1].x), pk_bf16(z1[0][1].y, z1[1][1].y)};
+                float dz0[4] = {0.f, 0.f, 0.f, 0.f}, dz1[4] = {0.f, 0.f, 0.f, 0.f};       // (wk_dot2z here costs 30 spilled registers)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    __builtin_amdgcn_sched_barrier(0);        // one stencil row's weight vectors live at a time (registers)
+                    const uint4 G0 = dy == 0 ? g2[0] : dy == 1 ? g1[0] : g0[0];
+                    const uint4 G1 = dy == 0 ? g2[1] : dy == 1 ? g1[1] : g0[1];
+                    const uint4 Wa = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 0) * CS + cv * 4]);
+                    const uint4 Wb = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 1) * CS + cv * 4]);
+                    const uint4 Wc = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 2) * CS + cv * 4]);
+                    const uint4 Wd = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 3) * CS + cv * 4]);
+                    const unsigned ga[4] = {G0.x, G0.y, G0.z, G0.w}, gb[4] = {G1.x, G1.y, G1.z, G1.w};
+                    const unsigned wa[4] = {Wa.x, Wa.y, Wa.z, Wa.w}, wb[4] = {Wb.x, Wb.y, Wb.z, Wb.w};
+                    const unsigned wc[4] = {Wc.x, Wc.y, Wc.z, Wc.w}, wd[4] = {Wd.x, Wd.y, Wd.z, Wd.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        dz0[q] = wk_dot2(ga[q], wa[q], dz0[q]);
+                        dz0[q] = wk_dot2(gb[q], wb[q], dz0[q]);
+                        dz1[q] = wk_dot2(ga[q], wc[q], dz1[q]);
+                        dz1[q] = wk_dot2(gb[q], wd[q], dz1[q]);
+                        const unsigned gm = __builtin_amdgcn_alignbit(gb[q], ga[q], 16);      // (G0.hi, G1.lo)
+                        dwp[dy * 3 + 2][q] = wk_dot2(Z[q], ga[q], dwp[dy * 3 + 2][q]);
+                        dwp[dy * 3 + 1][q] = wk_dot2(Z[q], gm, dwp[dy * 3 + 1][q]);
+                        dwp[dy * 3 + 0][q] = wk_dot2(Z[q], gb[q], dwp[dy * 3 + 0][q]);
+                    }
+                }
+                T* dst = dh0 + (unsigned)r * dhrow;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float* dz = h == 0 ? dz0 : dz1;
+                    const wk_f2_t d0 = wk_f2_t{dz[0], dz[1]} * dsl[h][0], d1 = wk_f2_t{dz[2], dz[3]} * dsl[h][1];
+                    const uint2 packed = make_uint2(pk_bf16(d0.x, d0.y), pk_bf16(d1.x, d1.y));
+                    *reinterpret_cast<uint2*>(dst + h * a.C) = packed;
+                    wk_f2_t r0, r1;
+                    wk_unpack(packed, r0, r1);                    // statistics of the values as stored
+                    sp0[0] += r0; sp0[1] += r1;
+                    sp1[0] += r0 * y[h][0];
+                    sp1[1] += r1 * y[h][1];
+                }
+            };
+            if constexpr (CIN > 0) {
+                // rows ri = 0 .. RB-1 (r = s - 1 + ri), unrolled: the window rotation and the MFMA tile of a row are compile-time; a row
+                // outside [r_lo, r_hi) (row -1 of the first chunk, rows past the plane in the last) skips its math, not its window read
+                int sl = slot_s - 2; sl = sl < 0 ? sl + RQ : sl;                 // ring slot of gradient row s - 2
+                uint4 gw[3][2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    gw[m][0] = *reinterpret_cast<const uint4*>(tcol + sl * rowdw); gw[m][1] = *reinterpret_cast<const uint4*>(tcol + sl * rowdw + CS);
+                    sl = sl + 1 == RQ ? 0 : sl + 1;
+                }
+                wk_f32x4_t acc[4];
+#pragma unroll
+                for (int ri = 0; ri < RB; ++ri) {
+                    const int r = s - 1 + ri;
+                    uint4 (&g0)[2] = gw[ri % 3], (&g1)[2] = gw[(ri + 1) % 3], (&g2)[2] = gw[(ri + 2) % 3];
+                    g2[0] = *reinterpret_cast<const uint4*>(tcol + sl * rowdw);
+                    g2[1] = *reinterpret_cast<const uint4*>(tcol + sl * rowdw + CS);
+                    sl = sl + 1 == RQ ? 0 : sl + 1;
+                    if ((ri & 1) == 0) {
+                        // y1 of rows r, r + 1 for this wave's four pixel pairs: acc[n][2 dr + h] = y1[row r + dr][x = 2 jj + h][channel 4 cv + n]
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            acc[n] = wk_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int kb = 0; kb < KB; ++kb) acc[n] = wk_mfma(afr[ri >> 1][kb], w1frag(n, kb), acc[n]);
+                        }
+                        if (chunk + 1 < nchunks) load_afr_t(s + RB, ri >> 1);      // the next chunk's rows of this tile: in flight under the walk
+                    }
+                    if (pvalid && r >= r_lo && r < r_hi) {
+                        const int d = 2 * (ri & 1);
+                        const wk_f2_t y[2][2] = {{wk_f2_t{acc[0][d], acc[1][d]}, wk_f2_t{acc[2][d], acc[3][d]}},
+                                                 {wk_f2_t{acc[0][d + 1], acc[1][d + 1]}, wk_f2_t{acc[2][d + 1], acc[3][d + 1]}}};
+                        row_math(r, g0, g1, g2, y);
+                    }
+                }
+            } else if (pvalid && r_lo < r_hi) {
                 // ring slots of gradient rows r_lo - 1, r_lo, r_lo + 1
                 int sl0 = slot_s + (r_lo - s) - 1; sl0 = sl0 < 0 ? sl0 + RQ : sl0;
                 int sl1 = sl0 + 1 == RQ ? 0 : sl0 + 1;
                 int sl2 = sl1 + 1 == RQ ? 0 : sl1 + 1;
-                const float4 s4 = *reinterpret_cast<const float4*>(&lcoef[cv * 4]), t4 = *reinterpret_cast<const float4*>(&lcoef[CS + cv * 4]);
-                const wk_f2_t bs2[2] = {wk_f2_t{s4.x, s4.y}, wk_f2_t{s4.z, s4.w}}, bt2[2] = {wk_f2_t{t4.x, t4.y}, wk_f2_t{t4.z, t4.w}};
                 uint4 gw[3][2];
                 gw[0][0] = *reinterpret_cast<const uint4*>(tcol + sl0 * rowdw); gw[0][1] = *reinterpret_cast<const uint4*>(tcol + sl0 * rowdw + CS);
                 gw[1][0] = *reinterpret_cast<const uint4*>(tcol + sl1 * rowdw); gw[1][1] = *reinterpret_cast<const uint4*>(tcol + sl1 * rowdw + CS);
@@ -462,69 +536,12 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
                     g2[0] = *reinterpret_cast<const uint4*>(tcol + sl2 * rowdw);
                     g2[1] = *reinterpret_cast<const uint4*>(tcol + sl2 * rowdw + CS);
                     sl2 = sl2 + 1 == RQ ? 0 : sl2 + 1;
-                    uint2 ry[2];
-                    if constexpr (CIN > 0) {
-                        const int ri = r - (s - 1);
-                        const unsigned char* yr = yslot + ri * 4096;
-                        const int par = ri & 1;
-                        ry[0] = *reinterpret_cast<const uint2*>(yr + (par ? ykey[1][0] : ykey[0][0]));
-                        ry[1] = *reinterpret_cast<const uint2*>(yr + 256 + (par ? ykey[1][1] : ykey[0][1]));
-                    } else {
-                        const unsigned char* yr = yld + (r - (s - 1)) * 4096;
-                        ry[0] = *reinterpret_cast<const uint2*>(yr); ry[1] = *reinterpret_cast<const uint2*>(yr + 256);
-                    }
-                    wk_f2_t y[2][2], z1[2][2], dsl[2][2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        wk_unpack(ry[h], y[h][0], y[h][1]);
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const wk_f2_t hh = y[h][q] * bs2[q] + bt2[q];
-                            const wk_f2_t sg = sigmoid2f_(hh);
-                            z1[h][q] = hh * sg;
-                            dsl[h][q] = sg * (1.0f + hh * (1.0f - sg));
-                        }
-                    }
-                    const unsigned Z[4] = {pk_bf16(z1[0][0].x, z1[1][0].x), pk_bf16(z1[0][0].y, z1[1][0].y),
-                                           pk_bf16(z1[0][1].x, z1[1][1].x), pk_bf16(z1[0][1].y, z1[1][1].y)};
-                    float dz0[4] = {0.f, 0.f, 0.f, 0.f}, dz1[4] = {0.f, 0.f, 0.f, 0.f};       // (wk_dot2z here costs 30 spilled registers)
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        __builtin_amdgcn_sched_barrier(0);        // one stencil row's weight vectors live at a time (registers)
-                        const uint4 G0 = dy == 0 ? g2[0] : dy == 1 ? g1[0] : g0[0];
-                        const uint4 G1 = dy == 0 ? g2[1] : dy == 1 ? g1[1] : g0[1];
-                        const uint4 Wa = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 0) * CS + cv * 4]);
-                        const uint4 Wb = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 1) * CS + cv * 4]);
-                        const uint4 Wc = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 2) * CS + cv * 4]);
-                        const uint4 Wd = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 3) * CS + cv * 4]);
-                        const unsigned ga[4] = {G0.x, G0.y, G0.z, G0.w}, gb[4] = {G1.x, G1.y, G1.z, G1.w};
-                        const unsigned wa[4] = {Wa.x, Wa.y, Wa.z, Wa.w}, wb[4] = {Wb.x, Wb.y, Wb.z, Wb.w};
-                        const unsigned wc[4] = {Wc.x, Wc.y, Wc.z, Wc.w}, wd[4] = {Wd.x, Wd.y, Wd.z, Wd.w};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            dz0[q] = wk_dot2(ga[q], wa[q], dz0[q]);
-                            dz0[q] = wk_dot2(gb[q], wb[q], dz0[q]);
-                            dz1[q] = wk_dot2(ga[q], wc[q], dz1[q]);
-                            dz1[q] = wk_dot2(gb[q], wd[q], dz1[q]);
-                            const unsigned gm = __builtin_amdgcn_alignbit(gb[q], ga[q], 16);      // (G0.hi, G1.lo)
-                            dwp[dy * 3 + 2][q] = wk_dot2(Z[q], ga[q], dwp[dy * 3 + 2][q]);
-                            dwp[dy * 3 + 1][q] = wk_dot2(Z[q], gm, dwp[dy * 3 + 1][q]);
-                            dwp[dy * 3 + 0][q] = wk_dot2(Z[q], gb[q], dwp[dy * 3 + 0][q]);
-                        }
-                    }
-                    T* dst = dh0 + (unsigned)r * dhrow;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const float* dz = h == 0 ? dz0 : dz1;
-                        const wk_f2_t d0 = wk_f2_t{dz[0], dz[1]} * dsl[h][0], d1 = wk_f2_t{dz[2], dz[3]} * dsl[h][1];
-                        const uint2 packed = make_uint2(pk_bf16(d0.x, d0.y), pk_bf16(d1.x, d1.y));
-                        *reinterpret_cast<uint2*>(dst + h * a.C) = packed;
-                        wk_f2_t r0, r1;
-                        wk_unpack(packed, r0, r1);                    // statistics of the values as stored
-                        sp0[0] += r0; sp0[1] += r1;
-                        sp1[0] += r0 * y[h][0];
-                        sp1[1] += r1 * y[h][1];
-                    }
+                    const unsigned char* yr = yld + (r - (s - 1)) * 4096;
+                    const uint2 ry[2] = {*reinterpret_cast<const uint2*>(yr), *reinterpret_cast<const uint2*>(yr + 256)};
+                    wk_f2_t y[2][2];
+                    wk_unpack(ry[0], y[0][0], y[0][1]);
+                    wk_unpack(ry[1], y[1][0], y[1][1]);
+                    row_math(r, g0, g1, g2, y);
                 };
                 for (int r = r_lo; r < r_hi; r += 3) {
                     row_step(r, gw[0], gw[1], gw[2]);
@@ -761,18 +778,18 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW2_RC : WK_MINW2) void dw_spat
                 };
                 if constexpr (ODD) { tap_dz(0, gnext, true); __builtin_amdgcn_sched_barrier(0); tap_dz(2, gcur, false); } else { tap_dz(1, gcur, true); }
                 __builtin_amdgcn_sched_barrier(0);
+                wk_f32x4_t acc[4];
                 if constexpr (CIN > 0) {
-                    // y1 of the thread's quad: acc[n][p] = y1[pixel p][channel 4 cv + n], rounded as the stored tensor reads back
-                    wk_f32x4_t acc[4];
+                    // y1 of the thread's quad: acc[n][p] = y1[pixel p][channel 4 cv + n] — the fp32 accumulators themselves (round 6: not
+                    // rounded to bf16; the forward stencil activates the same accumulators, the Gram statistics describe them)
 #pragma unroll
                     for (int n = 0; n < 4; ++n) {
                         acc[n] = wk_f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int kb = 0; kb < KB; ++kb) acc[n] = wk_mfma(afr[kb], w1frag(n, kb), acc[n]);
                     }
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) ry[p] = make_uint2(pk_bf16(acc[0][p], acc[1][p]), pk_bf16(acc[2][p], acc[3][p]));
                 }
+                (void)acc;
                 // 2) activation, pixel by pixel (order 0, 2, 1, 3 so that (z0, z2) and (z1, z3) pack as soon as possible);
                 //    each pixel is finished at once: dh1 = dz * SiLU', store, BatchNorm-backward sums
                 T* dst = dh0 + (unsigned)iy * dhrow;
@@ -784,7 +801,8 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW2_RC : WK_MINW2) void dw_spat
                 for (int pp = 0; pp < 4; ++pp) {
                     const int p = pp == 0 ? 0 : pp == 1 ? 2 : pp == 2 ? 1 : 3;
                     wk_f2_t y[2], z[2], dsl[2];
-                    wk_unpack(ry[p], y[0], y[1]);
+                    if constexpr (CIN > 0) { y[0] = wk_f2_t{acc[0][p], acc[1][p]}; y[1] = wk_f2_t{acc[2][p], acc[3][p]}; }
+                    else wk_unpack(ry[p], y[0], y[1]);
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const wk_f2_t hh = y[q] * bs2[q] + bt2[q];
@@ -961,7 +979,8 @@ static int launch_s2(const DwSpatialBwd& a, hipStream_t s) {
 template <int LPW, int RB, int CIN>
 static int launch_s1c(const DwSpatialBwd& a, hipStream_t s) {
     constexpr int NG = 16 / LPW, Wqp = LPW + 1;
-    const size_t lds = (size_t)NG * (RB + 2) * Wqp * 256 + (size_t)RB * 4096 + (CIN > 64 ? (size_t)64 * CIN * 2 : 0);
+    // ring + (stored form) the chunk's y1 rows by LDS-DMA / (rebuilt form, 128 input channels) the W1 slice
+    const size_t lds = (size_t)NG * (RB + 2) * Wqp * 256 + (CIN > 0 ? (CIN > 64 ? (size_t)64 * CIN * 2 : 0) : (size_t)RB * 4096);
     auto kern = dw_spatial_bwd_s1c_kernel<LPW, RB, CIN>;
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         (void)hipGetLastError();

@@ -88,18 +88,22 @@ __device__ __forceinline__ void wf_lds_barrier() {
 //   stride 2: chunk c stages input rows 2s .. 2s+2RB-1 and produces output rows s .. s+RB-1;          ring of 2RB+1 rows
 // ring slot of input row r = (r + 1) mod RQ; row -1 (slot 0) is the zero row above the plane.
 // ------------------------------------------------------------------------------------------------
-// CIN > 0 (round 5): the input is NOT read — a.in.p is ignored and the activated rows are REBUILT from the block input a0 (a.a0,
-// CIN channels) as SiLU(BN1(round_bf16(a0 . W1^T))) on the matrix cores: per input row of the plane group a wave runs
-// v_mfma_f32_16x16x32_bf16 on the even-x and on the odd-x pixels (W1 fragments in registers, a0 fragments straight from L2),
-// activates the accumulators (a lane holds 4 consecutive channels of one pixel) and builds the ring's pair dwords
-// (x = 2k-1, x = 2k) with one lane shift of the odd pixel's half.  Pairs are PS = 68 dwords apart in that form (a lane group
-// of the MFMA layout writes 8 consecutive pairs: 64-dword pairs would all land on the same banks).  y2 is bit-identical to
-// conv_pw + this kernel's CIN = 0 form: same MFMA operand roles and k order as the GEMM, same rounding, same stencil.
+// CIN > 0: the input is NOT read — a.in.p is ignored and the activated rows are REBUILT from the block input a0 (a.a0, CIN channels)
+// as SiLU(BN1(a0 . W1^T)) on the matrix cores, BatchNorm-1 applied to the fp32 accumulators (round 6: the product is NOT rounded to
+// bf16 first — these are the values the Gram-matrix statistics describe, and the backward stencils rebuild the same accumulators).
+// The MFMA runs with the PIXELS as its A operand (16 consecutive pixels of the plane-group row) and W1 rows as B in the order
+// 4 col + n, so a lane's accumulators are y1[pixels 4g .. 4g+3][channels 4 col .. 4 col + 3]: two complete x-pairs of four
+// consecutive channels — two ds_write_b128, no lane exchange.  For that the ring holds EVEN-aligned pairs in this form,
+// Q_k = (x = 2k, x = 2k+1) in pair column k + 1, with an all-zero column on either side of a plane (NPC = W/2 + 2); the walk reads
+// three pair columns per row (stride 1: Q_{jj-1}, Q_jj, Q_{jj+1}; stride 2: Q_{2jj-1}, Q_{2jj}, Q_{2jj+1}), four dot products per
+// tap row and channel as before.  Pair columns are 64 dwords apart: a ds_write_b128 group (8 lanes x 16 B) and a ds_read_b128
+// group (16 lanes: 4 + 4 + 8 of two pair columns) each cover distinct banks.
 template <int ST, int LPW, int RB, int CIN>
 __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW_RC4 : WF_MINW_RC) : WF_MINW) void dw_spatial_fwd_chain_kernel(const DwSpatialFwd a) {
     typedef bf16_t T;
-    constexpr int NT = 256, CS = 64, NG = 16 / LPW, NPC = ST * LPW + 1;
-    constexpr int PS = CIN > 0 ? 68 : 64;                // dwords between consecutive pairs of a ring row
+    constexpr bool QL = CIN > 0;                         // even-aligned pairs Q_k = (2k, 2k+1) + a zero column on either side
+    constexpr int NT = 256, CS = 64, NG = 16 / LPW, NPC = ST * LPW + (QL ? 2 : 1);
+    constexpr int PS = 64;                               // dwords between consecutive pairs of a ring row
     constexpr int NWC = ST == 1 ? 4 : 2;
     constexpr int NR = ST * RB;                          // input rows staged per chunk
     constexpr int RQ = ST == 1 ? RB + 2 : 2 * RB + 1;
@@ -107,6 +111,10 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
     constexpr int KB = CIN > 0 ? CIN / 32 : 1;
     __shared__ float lstat[2 * CS];
     __shared__ __attribute__((aligned(16))) float lcoef[2 * CS];             // BatchNorm-1 scale, shift (re-read per phase: registers)
+    // rebuilt form: every coefficient TWICE, (s_c, s_c) — read as the register pairs of the pixel-pair-packed math.  A splat built in
+    // registers is folded by hipcc into v_pk_fma_f32 ... op_sel:[1,0,1] (both lanes read the pair's high register): the instruction
+    // class of the round-5 corruption, refused by tools/check_isa.py
+    __shared__ __attribute__((aligned(16))) float lcoef2[QL ? 4 * CS : 4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int cv = tid & 15, pl = tid >> 4;
     const int grp = pl / LPW, jj = pl % LPW;
@@ -118,7 +126,9 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
     if (tid < 2 * CS) {
         lstat[tid] = 0.f;
         const int c = c0 + (tid & (CS - 1));
-        lcoef[tid] = c < a.C ? (tid < CS ? a.in.v1[c] : a.in.v2[c]) : 0.f;
+        const float v = c < a.C ? (tid < CS ? a.in.v1[c] : a.in.v2[c]) : 0.f;
+        lcoef[tid] = v;
+        if constexpr (QL) { lcoef2[2 * tid] = v; lcoef2[2 * tid + 1] = v; }
     }
     __syncthreads();
 
@@ -134,11 +144,23 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                wp[dy][0][q] = pk_bf16(w[dy * 3 + 0][q], w[dy * 3 + 1][q]);
-                wp[dy][1][q] = pk_bf16(w[dy * 3 + 2][q], 0.f);
-                if constexpr (ST == 1) {
-                    wp[dy][2][q] = pk_bf16(0.f, w[dy * 3 + 0][q]);
-                    wp[dy][3][q] = pk_bf16(w[dy * 3 + 1][q], w[dy * 3 + 2][q]);
+                if constexpr (QL && ST == 1) {
+                    // E = (Qa.hi, Qc.lo), Qb:  out[2jj] = E.(w0,0) + Qb.(w1,w2),  out[2jj+1] = Qb.(w0,w1) + E.(0,w2)
+                    wp[dy][0][q] = pk_bf16(w[dy * 3 + 0][q], 0.f);
+                    wp[dy][1][q] = pk_bf16(w[dy * 3 + 1][q], w[dy * 3 + 2][q]);
+                    wp[dy][2][q] = pk_bf16(w[dy * 3 + 0][q], w[dy * 3 + 1][q]);
+                    wp[dy][3][q] = pk_bf16(0.f, w[dy * 3 + 2][q]);
+                } else if constexpr (QL) {
+                    // pairs Qa, Qb, Qc:  out[2jj] = Qa.(0,w0) + Qb.(w1,w2),  out[2jj+1] = Qb.(0,w0) + Qc.(w1,w2)
+                    wp[dy][0][q] = pk_bf16(0.f, w[dy * 3 + 0][q]);
+                    wp[dy][1][q] = pk_bf16(w[dy * 3 + 1][q], w[dy * 3 + 2][q]);
+                } else {
+                    wp[dy][0][q] = pk_bf16(w[dy * 3 + 0][q], w[dy * 3 + 1][q]);
+                    wp[dy][1][q] = pk_bf16(w[dy * 3 + 2][q], 0.f);
+                    if constexpr (ST == 1) {
+                        wp[dy][2][q] = pk_bf16(0.f, w[dy * 3 + 0][q]);
+                        wp[dy][3][q] = pk_bf16(w[dy * 3 + 1][q], w[dy * 3 + 2][q]);
+                    }
                 }
             }
     }
@@ -168,12 +190,12 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
     constexpr int NLC = ST == 1 ? LPW : SLW;                      // staging lanes per plane row
     constexpr int NEX = (NR + NLC - 1) / NLC;                     // halo-column rows a lane stages per chunk
 
-    // ---- rebuilt input (CIN > 0): lane (lr, lg) of an MFMA = (pixel column lr of the 16-pixel tile, k group lg) for the a0 operand and
-    // (channel row lr of channel tile n, k group lg) for W1; accumulator register j = channel 16 n + 4 lg + j of pixel lr
+    // ---- rebuilt input (CIN > 0): lane (lr, lg) of an MFMA = (pixel lr of the 16-pixel tile, k group lg) for the a0 operand (A),
+    // (W1 row 4 lr + n of channel tile n, k group lg) for W1 (B); accumulator register j of tile n = y1[pixel 4 lg + j][channel 4 lr + n]
     const int lr = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // W1 fragments of this workgroup's 64 channels: registers for CIN = 64 (32 VGPRs); for CIN = 128 a copy of the slice in LDS behind
-    // the ring (16 KB, 16-byte chunk c of row r at chunk c ^ (r & 15): conflict-free ds_read_b128 of a fragment), read per channel tile
+    // the ring (16 KB, 16-byte chunk c of row r at chunk c ^ ((r >> 2) & 15): conflict-free ds_read_b128 of a fragment)
     constexpr bool W1_LDS = CIN > 64;
     constexpr unsigned RING_BYTES = (unsigned)NG * RQ * rowdw * 4u;
     uint4 wfr[W1_LDS ? 1 : 4][KB];
@@ -184,131 +206,90 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
             for (int i = tid; i < 64 * CH; i += NT) {
                 const int r = i / CH, c = i % CH;
                 const int ch = c0 + r;
-                *reinterpret_cast<uint4*>(wf_smem + RING_BYTES + (r * CH + (c ^ (r & 15))) * 16) =
+                *reinterpret_cast<uint4*>(wf_smem + RING_BYTES + (r * CH + (c ^ ((r >> 2) & 15))) * 16) =
                     *reinterpret_cast<const uint4*>(w1 + (i64)(ch < a.C ? ch : c0) * CIN + 8 * c);
             }
             __syncthreads();
         } else {
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                const int ch = c0 + 16 * n + lr;
+                const int ch = c0 + 4 * lr + n;
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)
                     wfr[n][kb] = *reinterpret_cast<const uint4*>(w1 + (i64)(ch < a.C ? ch : c0) * CIN + 8 * lg + 32 * kb);
             }
         }
+        // the zero columns on either side of every plane, all ring slots (never written again)
+        for (int i = tid; i < NG * RQ * 2 * 16; i += NT) {
+            const int c16 = i & 15, side = (i >> 4) & 1, rs = i >> 5;
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned*>(wf_smem) + (rs * NPC + (side ? NPC - 1 : 0)) * PS + 4 * c16) = make_uint4(0, 0, 0, 0);
+        }
     }
     auto w1frag = [&](const int n, const int kb) -> uint4 {
         if constexpr (W1_LDS) {
-            const int r = 16 * n + lr;
-            return *reinterpret_cast<const uint4*>(wf_smem + RING_BYTES + (r * (CIN / 8) + ((lg + 4 * kb) ^ (r & 15))) * 16);
+            const int r = 4 * lr + n;
+            return *reinterpret_cast<const uint4*>(wf_smem + RING_BYTES + (r * (CIN / 8) + ((lg + 4 * kb) ^ lr)) * 16);
         } else {
             return wfr[n][kb];
         }
     };
     (void)lr; (void)lg; (void)wave;
 
-    // one plane-group row of a0 as MFMA B-operand fragments: [tile pair t][even-x / odd-x pixels][k step]
-    constexpr int TP = ST;                       // 32-pixel MFMA tile pairs (even-x, odd-x) per plane-group row
+    // one plane-group row of a0 as MFMA A-operand fragments: [16-pixel tile t][k step]
+    constexpr int NTL = 2 * ST;                  // 16-pixel tiles per plane-group row (32 ST pixels)
     constexpr int WIN = 2 * ST * LPW;            // pixels per plane row
-    uint4 pf[TP][2][KB];
-    auto load_row = [&](const int pg_, const int hi, uint4 (&fr)[TP][2][KB]) {
+    uint4 pf[NTL][KB];
+    auto load_row = [&](const int pg_, const int hi, uint4 (&fr)[NTL][KB]) {
         if constexpr (CIN > 0) {
             const T* a0p = reinterpret_cast<const T*>(a.a0);
             const unsigned a0ld = (unsigned)a.a0_ld;
 #pragma unroll
-            for (int t = 0; t < TP; ++t) {
-                const int gxp = 32 * t + 2 * lr;         // even pixel of this lane in the plane-group row
+            for (int t = 0; t < NTL; ++t) {
+                const int gxp = 16 * t + lr;             // this lane's pixel of the plane-group row
                 const int g = gxp / WIN, x = gxp % WIN;
                 const int pln = pg_ * NG + g;
                 const T* src = a0p + ((i64)(pln < a.planes ? pln : 0) * a.Hin + (hi < a.Hin ? hi : a.Hin - 1)) * a.Win * (i64)a0ld +
                                (unsigned)x * a0ld + 8 * lg;     // rows / planes past the end: any valid address (masked below)
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) {
-                    fr[t][0][kb] = *reinterpret_cast<const uint4*>(src + 32 * kb);
-                    fr[t][1][kb] = *reinterpret_cast<const uint4*>(src + a0ld + 32 * kb);
-                }
+                for (int kb = 0; kb < KB; ++kb) fr[t][kb] = *reinterpret_cast<const uint4*>(src + 32 * kb);
             }
         }
     };
-    auto rebuild_row = [&](const int pg_, const int hi, int sl, const uint4 (&fr)[TP][2][KB]) {
+    auto rebuild_row = [&](const int pg_, const int hi, int sl, const uint4 (&fr)[NTL][KB]) {
         if constexpr (CIN > 0) {
             unsigned* tile_ = reinterpret_cast<unsigned*>(wf_smem);
             sl = sl >= RQ ? sl - RQ : sl;
+            // BatchNorm-1 (scale, scale) / (shift, shift) of channels 4 lr + n (re-read per row: registers)
+            const float4 sa = *reinterpret_cast<const float4*>(&lcoef2[8 * lr]), sb = *reinterpret_cast<const float4*>(&lcoef2[8 * lr + 4]);
+            const float4 ta = *reinterpret_cast<const float4*>(&lcoef2[2 * CS + 8 * lr]), tb = *reinterpret_cast<const float4*>(&lcoef2[2 * CS + 8 * lr + 4]);
+            const wf_f2_t bsc[4] = {wf_f2_t{sa.x, sa.y}, wf_f2_t{sa.z, sa.w}, wf_f2_t{sb.x, sb.y}, wf_f2_t{sb.z, sb.w}};
+            const wf_f2_t bsh[4] = {wf_f2_t{ta.x, ta.y}, wf_f2_t{ta.z, ta.w}, wf_f2_t{tb.x, tb.y}, wf_f2_t{tb.z, tb.w}};
 #pragma unroll
-            for (int t = 0; t < TP; ++t) {
-                const int gxp = 32 * t + 2 * lr;
-                const int g = gxp / WIN, x = gxp % WIN;
-                const int pln = pg_ * NG + g;
-                const bool okp = pln < a.planes && hi < a.Hin;
-                unsigned* dst = tile_ + ((g * RQ + sl) * NPC + (x >> 1)) * PS + 4 * lg;
-                // pair (x-1, x): x = 0 pairs with the halo (low half 0).  With 32 | WIN that is lane row 0 only, which the DPP move zeroes
-                constexpr bool LO_FREE = WIN % 32 == 0;
-                const unsigned lomask = x != 0 ? 0xffffu : 0u, okmask = okp ? 0xffffffffu : 0u;
-                (void)lomask;
-                const bool hi_only = TP == 2 && lr == 0 && x != 0;         // the odd neighbour sits in the previous tile's lane 15
-                const bool extra = x == WIN - 2 || lr == 15;              // this lane's odd pixel opens the next pair
-                constexpr int NB = ST == 1 ? 4 : 2;                         // channel tiles whose MFMAs are issued together (registers)
-                wf_f32x4_t aE[4], aO[4];
+            for (int t = 0; t < NTL; ++t) {
+                const int gx0 = 16 * t + 4 * lg;         // first of this lane's four pixels (a quad never straddles planes: 4 | WIN)
+                const int g = gx0 / WIN, x0 = gx0 % WIN;
+                const unsigned okmask = (pg_ * NG + g < a.planes && hi < a.Hin) ? 0xffffffffu : 0u;     // rows below / planes past the end: zeros
+                unsigned* dst = tile_ + ((g * RQ + sl) * NPC + (x0 >> 1) + 1) * PS + 4 * lr;
+                wf_f32x4_t acc[4];
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
-                    if (n % NB == 0) {                                      // NB x 2 x KB MFMAs first: their latency overlaps
+                    acc[n] = wf_f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int m = n; m < n + NB; ++m) {
-                            aE[m] = wf_f32x4_t{0.f, 0.f, 0.f, 0.f}; aO[m] = wf_f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                            for (int kb = 0; kb < KB; ++kb) { const uint4 wa = w1frag(m, kb); aE[m] = wf_mfma(wa, fr[t][0][kb], aE[m]); aO[m] = wf_mfma(wa, fr[t][1][kb], aO[m]); }
-                        }
-                    }
-                    const float4 s4 = *reinterpret_cast<const float4*>(&lcoef[16 * n + 4 * lg]);
-                    const float4 t4 = *reinterpret_cast<const float4*>(&lcoef[CS + 16 * n + 4 * lg]);
-                    // Packed math over CHANNEL pairs (j, j + 1) with their own coefficient pairs, written out as float2.  Left to
-                    // itself hipcc's SLP pass packs (even pixel, odd pixel) of ONE channel and broadcasts that channel's scale /
-                    // shift with  v_pk_fma_f32 ... op_sel:[0,1,1]  (the low lane reads the HIGH register of the coefficient
-                    // pair) — and that instruction returned, about once in 10^4 executions on gfx950, a wrong low-lane result in
-                    // lanes 48-63 (tools/dbg_fcr2.py: the odd pixels of channel 16 n + 13 of a whole row read SiLU(0)).  Not a
-                    // wait-state problem (s_nop padding, tied MFMA accumulators, asm-fenced DPP moves changed nothing); gone with
-                    // -fno-slp-vectorize and gone in this form, whose ISA has no op_sel on a low lane.
-                    const wf_f2_t sc2[2] = {wf_f2_t{s4.x, s4.y}, wf_f2_t{s4.z, s4.w}}, sh2[2] = {wf_f2_t{t4.x, t4.y}, wf_f2_t{t4.z, t4.w}};
-                    unsigned d[4], e[4], dd[4];
-#ifdef WF_REPRO_PK_OPSEL      // the scalar form that SLP turns into the op_sel:[0,1,1] instruction (reproducer: tools/dbg_fcr2.py)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float scj = j == 0 ? s4.x : j == 1 ? s4.y : j == 2 ? s4.z : s4.w, shj = j == 0 ? t4.x : j == 1 ? t4.y : j == 2 ? t4.z : t4.w;
-                        const unsigned pk = pk_bf16(aE[n][j], aO[n][j]);
-                        const float hE = fmaf(__uint_as_float(pk << 16), scj, shj), hO = fmaf(__uint_as_float(pk & 0xffff0000u), scj, shj);
-                        dd[j] = pk_bf16(hO * sigmoidf_(hO), hE * sigmoidf_(hE));
-                    }
-#else
-#pragma unroll
-                    for (int jp = 0; jp < 2; ++jp) {
-                        const unsigned pk0 = pk_bf16(aE[n][2 * jp], aO[n][2 * jp]), pk1 = pk_bf16(aE[n][2 * jp + 1], aO[n][2 * jp + 1]);   // y1 as stored
-                        const wf_f2_t yE = wf_f2_t{__uint_as_float(pk0 << 16), __uint_as_float(pk1 << 16)};
-                        const wf_f2_t yO = wf_f2_t{__uint_as_float(pk0 & 0xffff0000u), __uint_as_float(pk1 & 0xffff0000u)};
-                        const wf_f2_t hE = yE * sc2[jp] + sh2[jp], hO = yO * sc2[jp] + sh2[jp];
-                        const wf_f2_t zE = hE * sigmoid2f_(hE);
-                        const wf_f2_t zO = hO * sigmoid2f_(hO);
-                        dd[2 * jp] = pk_bf16(zO.x, zE.x);                    // (odd x, even x)
-                        dd[2 * jp + 1] = pk_bf16(zO.y, zE.y);
-                    }
-#endif
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        // lane - 1's dword (row_shr:1 with bound_ctrl: lane 0 of a 16-lane row reads 0): its low half is this pair's
-                        // odd pixel.  Four instructions per dword: mask, DPP move, bit-field insert, mask.
-                        const unsigned m = dd[j] & okmask;
-                        const unsigned prev = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x111, 0xf, 0xf, true);
-                        d[j] = __builtin_amdgcn_perm(m, LO_FREE ? prev : (prev & lomask), 0x07060100u);      // (m.hi16, prev.lo16)
-                        e[j] = m & 0xffffu;
-                    }
-                    if (hi_only) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) reinterpret_cast<unsigned short*>(dst + 16 * n + j)[1] = (unsigned short)(d[j] >> 16);
-                    } else {
-                        *reinterpret_cast<uint4*>(dst + 16 * n) = make_uint4(d[0], d[1], d[2], d[3]);
-                    }
-                    if (extra) *reinterpret_cast<uint4*>(dst + PS + 16 * n) = make_uint4(e[0], e[1], e[2], e[3]);
+                    for (int kb = 0; kb < KB; ++kb) acc[n] = wf_mfma(fr[t][kb], w1frag(n, kb), acc[n]);
                 }
+                // BatchNorm-1 + SiLU on the accumulators, packed over PIXEL pairs (registers j, j + 1 of one channel) with the channel's
+                // scale / shift duplicated in a register pair read from LDS: no op_sel on a low lane (tools/check_isa.py gates this object)
+                unsigned q0[4], q1[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const wf_f2_t s2 = bsc[n], t2 = bsh[n];
+                    const wf_f2_t h0 = wf_f2_t{acc[n][0], acc[n][1]} * s2 + t2, h1 = wf_f2_t{acc[n][2], acc[n][3]} * s2 + t2;
+                    const wf_f2_t z0 = h0 * sigmoid2f_(h0), z1 = h1 * sigmoid2f_(h1);
+                    q0[n] = pk_bf16(z0.x, z0.y) & okmask;                    // Q pair (x0, x0 + 1)
+                    q1[n] = pk_bf16(z1.x, z1.y) & okmask;                    // Q pair (x0 + 2, x0 + 3)
+                }
+                *reinterpret_cast<uint4*>(dst) = make_uint4(q0[0], q0[1], q0[2], q0[3]);
+                *reinterpret_cast<uint4*>(dst + PS) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
             }
         }
     };
@@ -322,7 +303,12 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
         const T* in0 = inp + (i64)(splane < a.planes ? splane : 0) * Hin * Win * a.in.ld + schs;
         T* out0 = outp + (i64)(plane < a.planes ? plane : 0) * Hout * Wout * a.C + chan + (unsigned)(2 * jj) * (unsigned)a.C;
         // row -1 of the ring (slot 0): zeros
-        {
+        if constexpr (QL) {
+            for (int i = tid; i < NG * NPC * 16; i += NT) {
+                const int c16 = i & 15, col = (i >> 4) % NPC, gq = (i >> 4) / NPC;
+                *reinterpret_cast<uint4*>(tile + (gq * RQ * NPC + col) * PS + 4 * c16) = make_uint4(0, 0, 0, 0);
+            }
+        } else {
             unsigned* z = splane_t + kc * PS;
             if constexpr (ST == 1) *reinterpret_cast<uint4*>(z) = make_uint4(0, 0, 0, 0);
             else { reinterpret_cast<uint4*>(z)[0] = make_uint4(0, 0, 0, 0); reinterpret_cast<uint4*>(z)[1] = make_uint4(0, 0, 0, 0); }
@@ -481,7 +467,7 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
                     wf_unpack(pk1, r0, r1);
                     st0[0] += r0; st0[1] += r1; st1[0] += r0 * r0; st1[1] += r1 * r1;
                 };
-                if constexpr (ST == 1) {
+                if constexpr (ST == 1 && !QL) {
                     // ring slots of input rows o_lo - 1, o_lo, o_lo + 1
                     int sl0 = slot_s + (o_lo - s) - 1; sl0 = sl0 < 0 ? sl0 + RQ : sl0;
                     const int sl1 = sl0 + 1 == RQ ? 0 : sl0 + 1;
@@ -505,6 +491,46 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
                                 acc0[q] = wf_dot2(x1[q], wp[dy][1][q], acc0[q]);
                                 acc1[q] = dy == 0 ? wf_dot2z(x0[q], wp[dy][NWC - 2][q]) : wf_dot2(x0[q], wp[dy][NWC - 2][q], acc1[q]);
                                 acc1[q] = wf_dot2(x1[q], wp[dy][NWC - 1][q], acc1[q]);
+                            }
+                        }
+                        finish(oy, acc0, acc1);
+                    };
+                    for (int oy = o_lo; oy < o_hi; oy += 3) {
+                        row_step(oy, tw[0], tw[1], tw[2]);
+                        if (oy + 1 < o_hi) row_step(oy + 1, tw[1], tw[2], tw[0]);
+                        if (oy + 2 < o_hi) row_step(oy + 2, tw[2], tw[0], tw[1]);
+                    }
+                } else if constexpr (ST == 1) {
+                    // even-aligned pairs (rebuilt input): a row needs Q_{jj-1}.hi, Q_jj, Q_{jj+1}.lo — the two outer halves are kept as ONE
+                    // dword per channel, E = (Q_{jj-1}.hi, Q_{jj+1}.lo) (one v_perm per channel and row; 8 instead of 12 window registers
+                    // per row):  out[2jj] = E.(w0,0) + Q_jj.(w1,w2),  out[2jj+1] = Q_jj.(w0,w1) + E.(0,w2)
+                    int sl0 = slot_s + (o_lo - s) - 1; sl0 = sl0 < 0 ? sl0 + RQ : sl0;
+                    const int sl1 = sl0 + 1 == RQ ? 0 : sl0 + 1;
+                    int sl2 = sl1 + 1 == RQ ? 0 : sl1 + 1;
+                    uint4 tw[3][2];                            // [row][E, Q_jj]
+                    auto ld_row = [&](const int sl, uint4 (&t)[2]) {
+                        const uint4 qa = *reinterpret_cast<const uint4*>(tc + sl * rowdw);
+                        t[1] = *reinterpret_cast<const uint4*>(tc + sl * rowdw + PS);
+                        const uint4 qc = *reinterpret_cast<const uint4*>(tc + sl * rowdw + 2 * PS);
+                        t[0] = make_uint4(__builtin_amdgcn_perm(qc.x, qa.x, 0x05040302u), __builtin_amdgcn_perm(qc.y, qa.y, 0x05040302u),
+                                          __builtin_amdgcn_perm(qc.z, qa.z, 0x05040302u), __builtin_amdgcn_perm(qc.w, qa.w, 0x05040302u));
+                    };
+                    ld_row(sl0, tw[0]); ld_row(sl1, tw[1]);
+                    auto row_step = [&](const int oy, const uint4 (&t0)[2], const uint4 (&t1)[2], uint4 (&t2)[2]) {
+                        ld_row(sl2, t2);
+                        sl2 = sl2 + 1 == RQ ? 0 : sl2 + 1;
+                        float acc0[4], acc1[4];
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const uint4 p0 = dy == 0 ? t0[0] : dy == 1 ? t1[0] : t2[0];
+                            const uint4 p1 = dy == 0 ? t0[1] : dy == 1 ? t1[1] : t2[1];
+                            const unsigned x0[4] = {p0.x, p0.y, p0.z, p0.w}, x1[4] = {p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                acc0[q] = dy == 0 ? wf_dot2z(x0[q], wp[dy][0][q]) : wf_dot2(x0[q], wp[dy][0][q], acc0[q]);
+                                acc0[q] = wf_dot2(x1[q], wp[dy][1][q], acc0[q]);
+                                acc1[q] = dy == 0 ? wf_dot2z(x1[q], wp[dy][2][q]) : wf_dot2(x1[q], wp[dy][2][q], acc1[q]);
+                                acc1[q] = wf_dot2(x0[q], wp[dy][3][q], acc1[q]);
                             }
                         }
                         finish(oy, acc0, acc1);
@@ -608,8 +634,8 @@ bool dw_spatial_fwd_rc_walk_supported(const DwSpatialFwd& a, int dtype) {
 
 template <int ST, int LPW, int RB, int CIN>
 static int launch_fc(const DwSpatialFwd& a, hipStream_t s) {
-    constexpr int NG = 16 / LPW, NPC = ST * LPW + 1, RQ = ST == 1 ? RB + 2 : 2 * RB + 1;
-    const size_t lds = (size_t)NG * RQ * NPC * (CIN > 0 ? 272 : 256) + (CIN > 64 ? (size_t)64 * CIN * 2 : 0);
+    constexpr int NG = 16 / LPW, NPC = ST * LPW + (CIN > 0 ? 2 : 1), RQ = ST == 1 ? RB + 2 : 2 * RB + 1;
+    const size_t lds = (size_t)NG * RQ * NPC * 256 + (CIN > 64 ? (size_t)64 * CIN * 2 : 0);
     auto kern = dw_spatial_fwd_chain_kernel<ST, LPW, RB, CIN>;
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         (void)hipGetLastError();

@@ -295,11 +295,11 @@ bool gemm_nn_kd_eligible(const GemmNN& g, int dtype) {
 template <int BN, int RT, bool GATE, bool CAT>
 static int launch_kd_t(const KdArgs& a, hipStream_t s) {
     const size_t smem = 2 * (size_t)BN * 64 + 64 * ((size_t)BN * 2 + 16) + 2 * (size_t)BN * 4 + (GATE ? (size_t)a.K * 4 : 0);
-    static bool attr_done = false;                         // (idempotent; a benign race at worst sets it twice)
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kd_kernel<BN, RT, GATE, CAT>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    // per launch: the attribute belongs to the (function, device) pair and the API takes a device argument (a process-wide flag left
+    // a second device without it); the call is a host-side table write
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kd_kernel<BN, RT, GATE, CAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return dwn_set_error((int)e, hipGetErrorString(e));
-        attr_done = true;
     }
     const unsigned tiles = (unsigned)a.ntm * (unsigned)a.ntn;
     const unsigned grid = (tiles + 7u) & ~7u;

@@ -75,10 +75,17 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 
 # conv_pwl backward implementation forced for a process (the block / model parity tests are re-run under both): "new" =
 # per-sample products + recompute epilogue, "old" = materialised du; unset = the library chooses by shape
-_PWL_BWD = {"": 0, "new": 1, "old": 2}[os.environ.get("DWN_PWL_BWD", "")]
+def _env_choice(name: str, table: dict) -> int:
+    v = os.environ.get(name, "")
+    if v not in table:
+        raise ValueError(f"{name}={v!r}: expected one of {sorted(k for k in table if k)} (or unset)")
+    return table[v]
+
+
+_PWL_BWD = _env_choice("DWN_PWL_BWD", {"": 0, "new": 1, "old": 2})
 # dwn_block_args.y1_mode: "" = the library leaves y1 (conv_pw's output) unmaterialised in bf16 training where both stencils rebuild it
 # from the block input; DWN_Y1=materialise forces the stored-y1 path (the parity tests run both; same-box A/B runs)
-_Y1_MODE = {"": 0, "free": 0, "materialise": 1, "all": 2}[os.environ.get("DWN_Y1", "")]
+_Y1_MODE = _env_choice("DWN_Y1", {"": 0, "free": 0, "materialise": 1, "all": 2})
 
 
 def grad_out(param: torch.Tensor, zero: bool = False) -> torch.Tensor:
