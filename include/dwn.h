@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DWN_ABI_VERSION 6
+#define DWN_ABI_VERSION 7
 #define DWN_F32 0
 #define DWN_BF16 1
 /* How the dtype-f32 GEMMs of a block / cortex layer / readout multiply.  NATIVE: v_mfma_f32_16x16x4_f32.  SPLIT3: each operand
@@ -142,6 +142,10 @@ typedef struct dwn_gemm_tn_args {
      * readout) and dW need not be zeroed; when it needs more, the library zeroes dW itself first.  Needs lddw == Cc and
      * rows_per_sample == 0 (the [groups * R][Cc] matrix is one contiguous block). */
     int overwrite;
+    /* 1 (ABI 7): dw points to DOUBLE [groups * R][lddw] and the M-split partial tiles are added with fp64 atomics — for products
+     * that are later differenced (the Gram pass of dwn_conv_pw_bn_stats: var = w^T (G / n - mu mu^T) w cancels mean^2 against
+     * E[y^2], and several hundred fp32 atomic adds per element carry 1e-6 of the SUM).  Not with overwrite / per-sample mode. */
+    int dw_f64;
 } dwn_gemm_tn_args;
 
 /* depth-wise (1,k,k) conv, stride (1,s,s), pad k/2 — dwiseneuro.py:96-100 */
@@ -386,7 +390,7 @@ int dwn_pack_weight(const float* src, void* dst, int groups, int R, int C, int t
  * weights the matrix cores multiply with).  Writes bn->coef [4][E] = scale, shift, mean, invstd and updates the running statistics
  * and num_batches_tracked like nn.BatchNorm3d.  sc_stats (optional, double[DWN_NREP][2][Cin], zeroed by the caller): receives the
  * shortcut BatchNorm's sums of an identity-map block (sum a0, sum a0^2 per channel) in replica 0.  ws: caller-owned scratch. */
-size_t dwn_conv_pw_bn_stats_workspace_bytes(int Cin);
+size_t dwn_conv_pw_bn_stats_workspace_bytes(int Cin);    /* (Cin + 8) * Cin doubles + alignment */
 int dwn_conv_pw_bn_stats(const void* a0, long long a0_ld, long long M, const float* w_pw, int E, int Cin, const dwn_bn* bn,
                          float momentum, float eps, double* sc_stats, void* ws, size_t ws_bytes, int dtype, int device,
                          void* stream);

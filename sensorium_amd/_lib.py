@@ -62,7 +62,7 @@ class GemmTNArgs(C.Structure):
     _fields_ = [("p", LoadDesc), ("p_kind", c_i), ("q", LoadDesc), ("q_kind", c_i), ("M", c_i), ("R", c_i),
                 ("Cc", c_i), ("dw", c_p), ("lddw", c_ll), ("groups", c_i), ("rows_per_split", c_i),
                 ("nsplit", c_i), ("R_load", c_i), ("rows_per_sample", c_i), ("splits_per_sample", c_i),
-                ("dw_sample_stride", c_ll), ("overwrite", c_i)]
+                ("dw_sample_stride", c_ll), ("overwrite", c_i), ("dw_f64", c_i)]
 
 
 class DwSpatialFwdArgs(C.Structure):
@@ -264,7 +264,8 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.dwn_abi_version() != 6:
+    ab = bool(os.environ.get("DWN_LIB_PATH"))      # an explicitly chosen other build: a same-box A/B run of an older library
+    if lib.dwn_abi_version() != 7 and not (ab and lib.dwn_abi_version() == 6):
         raise ImportError("libdwiseneuro_hip.so ABI version mismatch")
     built, have = lib.dwn_source_hash().decode(), source_hash()
     if built != have and not os.environ.get("DWN_LIB_PATH"):        # (an explicitly chosen other build is an A/B run)
@@ -272,7 +273,7 @@ def _load():
                           f"`make -C {LIB_PATH.parent}` — binaries are not in git, so what runs must be what is committed")
     for cname, struct in _STRUCTS.items():
         n = lib.dwn_sizeof(cname.encode())
-        if n != C.sizeof(struct):
+        if n != C.sizeof(struct) and not (ab and 0 < n < C.sizeof(struct)):      # (A/B: ABI 7 only appended a field)
             raise ImportError(f"struct layout mismatch for {cname}: C {n} bytes vs ctypes {C.sizeof(struct)}")
     return lib
 

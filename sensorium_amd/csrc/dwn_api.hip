@@ -176,7 +176,7 @@ struct BlockWs {
     float* tacc;                                           // conv_pw weight gradient: raw products T1 / Ga / s (k_pw_wgrad_fold)
     void* wgated;                                          // [B][Cout][Cmid] W2 . diag(gate_b) (forward only)
     void* rcblob;                                          // forward: slice images of the y1-recomputing stencil
-    float* gram;                                           // y1-free training forward: [(Cin + 8)][Cin] raw products a0^T a0, 1^T a0
+    double* gram;                                          // y1-free training forward: [(Cin + 8)][Cin] raw products a0^T a0, 1^T a0 (fp64 atomics)
     float* pb;                                             // [B][Cout][Cmid] per-sample dy4^T z3 (backward, see pwl_bwd_per_sample)
     char* zero_beg; char* zero_end;
     size_t bytes;
@@ -253,7 +253,7 @@ BlockWs carve_block(const dwn_block_args& a, int backward, void* base, size_t ca
     w.st4 = c.take<double>(nstat(a.Cout));
     w.stsc = c.take<double>(nstat(backward ? a.Cout : a.Cin));
     w.pooled = c.take<long long>((size_t)a.B * a.Cmid);
-    if (!backward && block_y1_free(a)) w.gram = c.take<float>((size_t)(a.Cin + 8) * a.Cin);
+    if (!backward && block_y1_free(a)) w.gram = c.take<double>((size_t)(a.Cin + 8) * a.Cin);
     size_t z1 = c.off;
     if (backward) {
         w.abc1 = c.take<float>(3 * (size_t)a.Cmid);
@@ -379,7 +379,7 @@ int dwn_bn_bwd_finalize(const double* stats, double count, const dwn_bn* bn, flo
     return k_bn_bwd_finalize(stats, count, bn->coef, bn->dgamma, bn->dbeta, abc, C, (hipStream_t)stream);
 }
 // BatchNorm-1 of conv_pw WITHOUT conv_pw's output (dwn.h): raw products [a0 | 1]^T a0 by one gemm_tn pass, then k_bn1_gram_finalize
-size_t dwn_conv_pw_bn_stats_workspace_bytes(int Cin) { return (size_t)(Cin + 8) * Cin * sizeof(float) + 256; }
+size_t dwn_conv_pw_bn_stats_workspace_bytes(int Cin) { return (size_t)(Cin + 8) * Cin * sizeof(double) + 256; }
 int dwn_conv_pw_bn_stats(const void* a0, long long a0_ld, long long M, const float* w_pw, int E, int Cin, const dwn_bn* bn,
                          float momentum, float eps, double* sc_stats, void* ws, size_t ws_bytes, int dtype, int device, void* stream) {
     ENTER(device);
@@ -387,11 +387,12 @@ int dwn_conv_pw_bn_stats(const void* a0, long long a0_ld, long long M, const flo
     if (!a0 || !w_pw || !bn || !bn->coef || !ws) return dwn_set_error(-1, "conv_pw_bn_stats: null pointer");
     if (Cin % 8 || E <= 0 || M <= 0 || M >= (1ll << 31)) return dwn_set_error(-2, "conv_pw_bn_stats: Cin % 8 == 0, 0 < M < 2^31");
     if (ws_bytes < dwn_conv_pw_bn_stats_workspace_bytes(Cin)) return dwn_set_error(-6, "conv_pw_bn_stats: workspace too small");
-    float* gram = reinterpret_cast<float*>(((size_t)ws + 255) & ~(size_t)255);
-    TRY(k_zero(gram, (size_t)(Cin + 8) * Cin * sizeof(float), s));
+    double* gram = reinterpret_cast<double*>(((size_t)ws + 255) & ~(size_t)255);
+    TRY(k_zero(gram, (size_t)(Cin + 8) * Cin * sizeof(double), s));
     LoadDesc cat = ld_plain(a0, a0_ld);
     cat.cat_c1 = Cin; cat.cat_c2 = 0;
-    GemmTN g = tn_base(cat, LD_CAT1, ld_plain(a0, a0_ld), LD_PLAIN, (int)M, Cin + 8, Cin, gram, Cin, 1);
+    GemmTN g = tn_base(cat, LD_CAT1, ld_plain(a0, a0_ld), LD_PLAIN, (int)M, Cin + 8, Cin, reinterpret_cast<float*>(gram), Cin, 1);
+    g.dw_f64 = 1;
     TRY(launch_gemm_tn(g, dtype, s));
     return k_bn1_gram_finalize(gram, w_pw, E, Cin, (double)M, bn->gamma, bn->beta, bn->running_mean, bn->running_var,
                                bn->num_batches_tracked, momentum, eps, bn->coef, sc_stats, dtype, s);
@@ -509,7 +510,8 @@ int dwn_block_forward(const dwn_block_args* ap, int device, void* stream) {
         // chained stencil rebuilds the y1 rows it needs from a0 on the matrix cores: conv_pw is no pass, a.y1 is not written
         LoadDesc cat = ld_plain(a0, a.Cin);
         cat.cat_c1 = a.Cin; cat.cat_c2 = 0;
-        GemmTN g = tn_base(cat, LD_CAT1, ld_plain(a0, a.Cin), LD_PLAIN, (int)Min, a.Cin + 8, a.Cin, w.gram, a.Cin, 1);
+        GemmTN g = tn_base(cat, LD_CAT1, ld_plain(a0, a.Cin), LD_PLAIN, (int)Min, a.Cin + 8, a.Cin, reinterpret_cast<float*>(w.gram), a.Cin, 1);
+        g.dw_f64 = 1;                                 // fp64 atomics: the variance is a difference of these sums
         PROF(DWN_FAM_PW_FWD, launch_gemm_tn(g, dt, s));
         PROF(DWN_FAM_PW_FWD, k_bn1_gram_finalize(w.gram, a.w_pw, a.Cmid, a.Cin, (double)Min, a.bn1.gamma, a.bn1.beta, a.bn1.running_mean,
                                                  a.bn1.running_var, a.bn1.num_batches_tracked, a.momentum, a.eps, a.bn1.coef,

@@ -214,15 +214,17 @@ int k_bn_bwd_finalize(const double* stats, double count, const float* coef, floa
 // ------------------------------------------------------------------------------------------------
 // BatchNorm-1 batch statistics WITHOUT y1 (round 5).  y1 = a0 . W1^T is linear in the block input, so over the n rows
 //   mean_e = w_e . mu,   var_e = w_e^T (G / n - mu mu^T) w_e     with G = a0^T a0, mu = (1^T a0) / n
-// (gram = [(Cin + 8)][Cin] fp32: rows 0 .. Cin-1 = G, row Cin = 1^T a0 — the raw products a gemm_tn pass over a0 with the
-// [a0 | 1] loader accumulates; W1 as rounded to the compute type, i.e. the weights the MFMAs that rebuild y1 multiply with).
+// (gram = [(Cin + 8)][Cin] fp64: rows 0 .. Cin-1 = G, row Cin = 1^T a0 — the raw products a gemm_tn pass over a0 with the
+// [a0 | 1] loader accumulates, per-workgroup fp32 MFMA tiles added with fp64 atomics (round 6: the difference G / n - mu mu^T
+// amplifies the error of the SUM by (mean^2 + var) / var, and some hundred fp32 atomic adds carried 1e-6 of it);
+// W1 as rounded to the compute type, i.e. the weights the MFMAs that rebuild y1 multiply with).
 // These are the statistics of the UNROUNDED product; a stored bf16 y1 carries 2^-9 of unbiased rounding noise per element on
 // top, which moves the mean by nothing and the variance by 3e-6 of itself.  One wave per channel, fp64 from the products on.
 // sc_stats != NULL: the same raw products also are the shortcut BatchNorm's sums on an identity-map block (its input is a0):
 // block 0 writes sum x = 1^T a0 and sum x^2 = diag(G) into replica 0 of that statistics buffer (zeroed by the caller).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void bn1_gram_finalize_kernel(const float* __restrict__ gram, const float* __restrict__ w1,
+__global__ __launch_bounds__(256) void bn1_gram_finalize_kernel(const double* __restrict__ gram, const float* __restrict__ w1,
                                                                 int E, int Cin, double count, const float* gamma, const float* beta,
                                                                 float* running_mean, float* running_var, long long* nbt,
                                                                 float momentum, float eps, float* coef, double* sc_stats) {
@@ -232,8 +234,8 @@ __global__ __launch_bounds__(256) void bn1_gram_finalize_kernel(const float* __r
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
     if (sc_stats && blockIdx.x == 0) {
         for (int c = threadIdx.x; c < Cin; c += 256) {
-            sc_stats[c] = (double)gram[(i64)Cin * Cin + c];
-            sc_stats[Cin + c] = (double)gram[(i64)c * Cin + c];
+            sc_stats[c] = gram[(i64)Cin * Cin + c];
+            sc_stats[Cin + c] = gram[(i64)c * Cin + c];
         }
     }
     if (e >= E) return;
@@ -242,15 +244,14 @@ __global__ __launch_bounds__(256) void bn1_gram_finalize_kernel(const float* __r
     const double inv_n = 1.0 / count;
     double quad = 0.0, lin = 0.0;
     for (int i = lane; i < Cin; i += 64) {
-        const float* grow = gram + (i64)i * Cin;
+        const double* grow = gram + (i64)i * Cin;
         double r = 0.0;
-        for (int j = 0; j < Cin; j += 4) {
-            const float4 g4 = *reinterpret_cast<const float4*>(grow + j);
-            r += (double)g4.x * (double)lw[wv][j] + (double)g4.y * (double)lw[wv][j + 1] + (double)g4.z * (double)lw[wv][j + 2] +
-                 (double)g4.w * (double)lw[wv][j + 3];
+        for (int j = 0; j < Cin; j += 2) {
+            const double2 g2 = *reinterpret_cast<const double2*>(grow + j);
+            r += g2.x * (double)lw[wv][j] + g2.y * (double)lw[wv][j + 1];
         }
         quad += (double)lw[wv][i] * r;
-        lin += (double)lw[wv][i] * (double)gram[(i64)Cin * Cin + i];
+        lin += (double)lw[wv][i] * gram[(i64)Cin * Cin + i];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { quad += __shfl_xor(quad, o); lin += __shfl_xor(lin, o); }
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void bn1_gram_finalize_kernel(const float* __r
         running_var[e] = (1.f - momentum) * running_var[e] + momentum * (float)unbiased;
     }
 }
-int k_bn1_gram_finalize(const float* gram, const float* w1, int E, int Cin, double count, const float* gamma, const float* beta,
+int k_bn1_gram_finalize(const double* gram, const float* w1, int E, int Cin, double count, const float* gamma, const float* beta,
                         float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef, double* sc_stats, int dtype,
                         hipStream_t s) {
     if (Cin > 512 || Cin % 4) return dwn_set_error(-2, "bn1_gram_finalize: Cin must be a multiple of 4, at most 512");

@@ -1101,6 +1101,7 @@ __global__ __launch_bounds__(256, (TnOcc<PLD, QLD>::value)) void gemm_tn_kernel(
                 int cc = c0 + wn * 64 + j * 16 + lr;
                 if (rr < g.R && cc < g.Cc) {
                     if (g.overwrite == 2) dw[(i64)rr * g.lddw + cc] = acc[i][j][r];      // single M-split: this tile has one writer
+                    else if (g.dw_f64) atomicAdd(reinterpret_cast<double*>(g.dw) + (i64)grp * g.R * g.lddw + dw_off + (i64)rr * g.lddw + cc, (double)acc[i][j][r]);
                     else atomicAdd(dw + (i64)rr * g.lddw + cc, acc[i][j][r]);
                 }
             }
@@ -1166,6 +1167,7 @@ static int launch_tn_t(const GemmTN& g_in, hipStream_t s) {
             g.nsplit = (int)((g.M + rows - 1) / rows);
         }
     }
+    if (g.dw_f64 && (g.overwrite || g.rows_per_sample > 0)) return dwn_set_error(-2, "gemm_tn: dw_f64 excludes overwrite and per-sample mode");
     if (g.overwrite) {
         // dW = product: plain stores with one M-split (overwrite = 2 tells the kernel), else zero first and accumulate
         if (g.rows_per_sample > 0 || g.lddw != g.Cc) return dwn_set_error(-2, "gemm_tn: overwrite needs lddw == Cc and no per-sample mode");

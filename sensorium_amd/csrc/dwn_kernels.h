@@ -25,7 +25,7 @@ int k_bn_finalize_eval(const float* gamma, const float* beta, const float* rm, c
 int k_bn_bwd_finalize(const double* stats, double count, const float* coef, float* dgamma, float* dbeta, float* abc,
                       int C, hipStream_t s);
 // BatchNorm-1 statistics from the Gram matrix of the block input (y1 never materialised; dwn_elementwise.hip)
-int k_bn1_gram_finalize(const float* gram, const float* w1, int E, int Cin, double count, const float* gamma, const float* beta,
+int k_bn1_gram_finalize(const double* gram, const float* w1, int E, int Cin, double count, const float* gamma, const float* beta,
                         float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef, double* sc_stats, int dtype,
                         hipStream_t s);
 int k_ew_apply(const LoadDesc& d, int kind, void* out, i64 ldo, i64 rows, int C, int dtype, hipStream_t s);

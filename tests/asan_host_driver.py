@@ -11,7 +11,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import sensorium_amd._lib as L
 
 lib = L.lib
-assert lib.dwn_abi_version() == 6
+assert lib.dwn_abi_version() == 7
 for cname, struct in L._STRUCTS.items():
     assert lib.dwn_sizeof(cname.encode()) == C.sizeof(struct), cname
 

@@ -153,3 +153,96 @@ def test_fullsize_backward_is_linear_in_loss_scale():
             assert lin <= 3.0 * noise + 1e-3, (k, lin, noise)
         if k.startswith("core.blocks.17."):
             assert err(grads[0], grads[2], k) < 1e-3, k
+
+
+# ---- depth-wise stencils at the metric batch, exact-integer data (round-5 verdict, item 7a) ------------------------------------------
+# spat_covn_dw forward / backward (src/models/dwiseneuro.py:96-102) of blocks 0, 1 and 4 at B = 32, T = 32, stored-y1 AND rebuilt-y1
+# forms, on data chosen so that every intermediate is a small integer that bf16 holds exactly:
+#   a0 in {0, 1}; W1 rows with exactly 16 ones  ->  y1 = a0 . W1^T in 0 .. 16 (integers; the rebuilt forms compute them by MFMA)
+#   BatchNorm-1 scale 1, shift 17  ->  h = y1 + 17 >= 17, where the fp32 SiLU is the identity to the last bit that bf16 keeps
+#     (exp2(-17 log2 e) < 2^-24: sigmoid = 1 within an ulp) and SiLU' = 1  ->  z1 = h in 17 .. 33
+#   three non-zero taps of +-1 per channel  ->  |y2| <= 99; gradient rows g = dh2 in {-1, 0, 1} (A1 = 1, A2 = A3 = 0)  ->  |dh1| <= 3
+# so y2, dh1, the 9-tap weight gradient and the BatchNorm-1 backward sums must EQUAL float64 arithmetic on the same integers.
+def _exact_stencil_case(L, planes, Hin, Win, cin, E, stride):
+    from tests.dw_reference import _dw3x3
+    d = dev()
+    s = stream()
+    BF = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(planes + Hin + cin + stride)
+    Hout, Wout = (Hin - 1) // stride + 1, (Win - 1) // stride + 1
+    Min, Mout = planes * Hin * Win, planes * Hout * Wout
+    a0 = torch.randint(0, 2, (Min, cin), generator=g, device=d, dtype=torch.int8).to(BF)
+    w1 = torch.zeros(E, cin, device=d)
+    w1.scatter_(1, torch.rand(E, cin, generator=g, device=d).argsort(1)[:, :16], 1.0)
+    w1 = w1.to(BF)
+    taps = torch.zeros(E, 9, device=d)
+    taps.scatter_(1, torch.rand(E, 9, generator=g, device=d).argsort(1)[:, :3], 1.0)
+    taps = (taps * (torch.randint(0, 2, (E, 9), generator=g, device=d) * 2 - 1)).t().contiguous()          # [9][E], +-1 / 0
+    dh2 = torch.randint(-1, 2, (Mout, E), generator=g, device=d, dtype=torch.int8).to(BF)
+    y2in = torch.zeros(Mout, E, dtype=BF, device=d)                                                      # weighted with A2 = 0
+    y1 = (a0.float() @ w1.float().t()).to(BF)                                                           # exact: integers 0 .. 16
+    ones, zeros = torch.ones(E, device=d), torch.zeros(E, device=d)
+    shift = torch.full((E,), 17.0, device=d)
+    # float64 reference on the integers (linear activation: z1 = h, SiLU' = 1)
+    h = (y1.double().view(planes, Hin, Win, E) + 17.0).requires_grad_(True)
+    wd = taps.double().clone().requires_grad_(True)
+    y2_ref = _dw3x3(h, wd, stride)
+    y2_ref.backward(dh2.double().view(planes, Hout, Wout, E))
+    y2_ref = y2_ref.detach().reshape(Mout, E)
+    dh1_ref = h.grad.reshape(Min, E)
+    dw_ref = wd.grad.t().contiguous()                                                                   # [E][9]
+    sum_dh1 = dh1_ref.sum(0)
+    sum_dh1_y1 = (dh1_ref * y1.double()).sum(0)
+    del h
+    for mode in ("stored", "rebuilt"):
+        # ---- forward
+        y2 = torch.full((Mout, E), float("nan"), dtype=BF, device=d)
+        st = torch.zeros(32 * 2 * E, dtype=torch.float64, device=d)
+        f = L.DwSpatialFwdArgs()
+        di = L.LoadDesc()
+        di.p = y1.data_ptr() if mode == "stored" else None
+        di.ld = E; di.rows_per_sample = 1; di.v1 = ones.data_ptr(); di.v2 = shift.data_ptr(); di.act = 1
+        f.inp = di
+        f.w = taps.data_ptr(); f.out = y2.data_ptr(); f.planes = planes; f.Hin = Hin; f.Win = Win; f.Hout = Hout; f.Wout = Wout
+        f.C = E; f.stride = stride; f.ks = 3; f.stats = st.data_ptr()
+        if mode == "rebuilt":
+            f.a0 = a0.data_ptr(); f.a0_ld = cin; f.w1 = w1.data_ptr(); f.Cin = cin
+            assert L.lib.dwn_dw_spatial_fwd_rc_supported(C.byref(f), L.DWN_BF16) == 1
+        L.check(L.lib.dwn_dw_spatial_fwd(C.byref(f), L.DWN_BF16, 0, s), "dwn_dw_spatial_fwd")
+        torch.cuda.synchronize()
+        assert torch.equal(y2.double(), y2_ref), (mode, "y2")
+        s0, s1 = read_stats(st, E)
+        assert torch.equal(s0, y2_ref.sum(0)), (mode, "sum y2")                        # integers below 2^24 in every partial sum
+        assert rel(s1, (y2_ref ** 2).sum(0)) < 1e-6, (mode, "sum y2^2")                 # fp32 partial sums beyond 2^24: rounded
+        del y2
+        # ---- backward
+        dh1 = torch.full((Min, E), float("nan"), dtype=BF, device=d)
+        dw = torch.zeros(E, 9, device=d)
+        st = torch.zeros(32 * 2 * E, dtype=torch.float64, device=d)
+        b = L.DwSpatialBwdArgs()
+        b.dy = load_desc(L, dh2, E, q=y2in, v1=ones, v2=zeros, v3=zeros)
+        b.y1 = load_desc(L, y1, E, v1=ones, v2=shift, v3=zeros, v4=ones)                # mean 0, invstd 1: yhat1 = y1
+        b.w = taps.data_ptr(); b.dh1 = dh1.data_ptr(); b.dw = dw.data_ptr(); b.planes = planes; b.Hin = Hin; b.Win = Win
+        b.Hout = Hout; b.Wout = Wout; b.C = E; b.stride = stride; b.ks = 3; b.stats = st.data_ptr()
+        if mode == "rebuilt":
+            b.y1.p = None
+            b.a0 = a0.data_ptr(); b.a0_ld = cin; b.w1 = w1.data_ptr(); b.Cin = cin
+            assert L.lib.dwn_dw_spatial_bwd_rc_supported(C.byref(b), L.DWN_BF16) == 1
+        L.check(L.lib.dwn_dw_spatial_bwd(C.byref(b), L.DWN_BF16, 0, s), "dwn_dw_spatial_bwd")
+        torch.cuda.synchronize()
+        assert torch.equal(dh1.double(), dh1_ref), (mode, "dh1")
+        assert torch.equal(dw.double(), dw_ref), (mode, "dW")
+        s0, s1 = read_stats(st, E)
+        assert torch.equal(s0, sum_dh1) and torch.equal(s1, sum_dh1_y1), (mode, "BatchNorm-1 backward sums")
+        del dh1
+
+
+@pytest.mark.parametrize("geom", [(36, 64, 64, 448, 2), (18, 32, 64, 448, 1), (18, 32, 128, 896, 2)], ids=["block0", "block1", "block4"])
+def test_fullsize_depthwise_stencils_exact(L, geom):
+    _exact_stencil_case(L, B * T, *geom)
+
+
+@pytest.mark.parametrize("geom", [(9, 16, 128, 896, 1), (5, 8, 64, 448, 1), (9, 16, 64, 448, 2)], ids=["block5", "w8", "w16s2"])
+def test_depthwise_stencils_exact_other_plane_widths(L, geom):
+    """The narrower plane widths (several planes side by side in one tile) with a ragged plane count."""
+    _exact_stencil_case(L, 131, *geom)

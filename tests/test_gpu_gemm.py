@@ -537,3 +537,51 @@ def test_conv_pw_batchnorm_statistics_from_the_gram_matrix(L):
         assert int(nbt) == 1
         s0, s1 = read_stats(sc, Cin)
         assert rel(s0, a0.double().sum(0)) < 1e-6 and rel(s1, (a0.double() ** 2).sum(0)) < 1e-6
+
+
+def test_conv_pw_batchnorm_statistics_from_the_gram_matrix_at_the_metric_batch(L):
+    """Round-5 advisor: the Gram route to BatchNorm-1's statistics obtains the variance by cancellation, w^T (G / n - mu mu^T) w, and
+    was only tested to M = 40000 with independent channels.  Here: the row count of block 0 at the metric batch (M = 32 * 32 * 36 * 64
+    = 2 359 296) and of blocks 1-3 (589 824), CORRELATED channels (a random mixing of 8 latent factors + noise) with LARGE means
+    (offsets of three standard deviations: (mean^2 + var) / var ~ 10 amplifies the relative error of the raw sums) — against float64
+    statistics of the product of the same rounded operands.  Mean to 1e-6 sigma, invstd to 3e-6: the raw products are added with
+    fp64 atomics since round 6 (fp32 atomics measured 1e-5 here)."""
+    import ctypes as C
+    torch.manual_seed(11)
+    for M, E, Cin in ((2359296, 448, 64), (589824, 448, 64), (147456, 896, 128)):
+        lat = torch.randn(M, 8, device=dev())
+        mix = torch.randn(8, Cin, device=dev())
+        scale = 0.5 + torch.rand(Cin, device=dev())
+        a0 = ((lat @ mix) * 0.6 + torch.randn(M, Cin, device=dev()) * 0.5) * scale + 3.0 * scale * torch.sign(torch.randn(Cin, device=dev()))
+        a0 = a0.to(torch.bfloat16)
+        del lat
+        w = torch.randn(E, Cin, device=dev()) / Cin ** 0.5
+        gamma = torch.rand(E, device=dev()) + 0.5
+        beta = torch.randn(E, device=dev()) * 0.2
+        rm, rv = torch.zeros(E, device=dev()), torch.ones(E, device=dev())
+        nbt = torch.zeros(1, dtype=torch.int64, device=dev())
+        coef = torch.empty(4 * E, device=dev())
+        sc = torch.zeros(32 * 2 * Cin, dtype=torch.float64, device=dev())
+        ws = torch.empty(L.lib.dwn_conv_pw_bn_stats_workspace_bytes(Cin), dtype=torch.uint8, device=dev())
+        bn = L.BN()
+        bn.gamma = gamma.data_ptr(); bn.beta = beta.data_ptr(); bn.running_mean = rm.data_ptr(); bn.running_var = rv.data_ptr()
+        bn.num_batches_tracked = nbt.data_ptr(); bn.coef = coef.data_ptr()
+        L.check(L.lib.dwn_conv_pw_bn_stats(a0.data_ptr(), Cin, M, w.data_ptr(), E, Cin, C.byref(bn), 0.1, 1e-5, sc.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), L.DWN_BF16, 0, stream()), "conv_pw_bn_stats")
+        torch.cuda.synchronize()
+        # float64 statistics of the product, in row chunks (the product of the largest case is 8.5 GB in float64)
+        wd = w.to(torch.bfloat16).double()
+        s1 = torch.zeros(E, dtype=torch.float64, device=dev())
+        for r0 in range(0, M, 262144):
+            s1 += (a0[r0:r0 + 262144].double() @ wd.t()).sum(0)
+        mean = s1 / M
+        s2 = torch.zeros(E, dtype=torch.float64, device=dev())
+        for r0 in range(0, M, 262144):
+            s2 += ((a0[r0:r0 + 262144].double() @ wd.t() - mean) ** 2).sum(0)
+        var = s2 / M
+        c = coef.view(4, E).double()
+        assert float((mean ** 2 / var).max()) > 5.0                    # the case does amplify
+        assert float(((c[2] - mean).abs() / var.sqrt()).max()) < 1e-6, (M, float(((c[2] - mean).abs() / var.sqrt()).max()))
+        invstd = 1.0 / (var + 1e-5).sqrt()
+        assert float(((c[3] - invstd).abs() / invstd).max()) < 3e-6, (M, float(((c[3] - invstd).abs() / invstd).max()))
+        assert rel(rv, 0.9 + 0.1 * var * M / (M - 1)) < 3e-6

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L.lib, n), f"{n} declared in include/dwn.h but not exported"
         assert n in L.SYMBOLS, f"{n} has no ctypes prototype in sensorium_amd/_lib.py"
-    assert L.lib.dwn_abi_version() == 6
+    assert L.lib.dwn_abi_version() == 7
 
 
 def test_struct_layouts_match():
