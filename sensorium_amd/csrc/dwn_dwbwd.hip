@@ -34,6 +34,17 @@
 #ifndef WK_MINW2_RC
 #define WK_MINW2_RC 2      // ... its y1-rebuilding form (W1 fragments + accumulators on top)
 #endif
+#ifndef WK_S1C_PIPE
+#define WK_S1C_PIPE 0      // stride-1 y1-rebuilding form: 1 = tap weights read from LDS one stencil row ahead (needs WK_S1C_W1LDS for the registers)
+#endif
+#ifndef WK_S1C_W1LDS
+#define WK_S1C_W1LDS 0     // stride-1 y1-rebuilding form: W1 fragments in LDS at 64 input channels too (their 32 registers hold the second
+                           // set of tap weights: the walk reads them one stencil row ahead)
+#endif
+#ifndef WK_S1C_PF
+#define WK_S1C_PF 0        // stride-1 y1-rebuilding form: 1 = the next chunk's gradient rows are fetched under the current chunk's walk (measured:
+                           // no gain at 64 input channels, 430 vs 429 us; -11 % on the 128-channel / 16-pixel-wide form, which the default path does not take)
+#endif
 
 extern __shared__ __attribute__((aligned(16))) unsigned char wk_smem[];
 
@@ -278,8 +289,14 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
     // lr & 1), k group lg; B-operand column lr = W1 row c0 + 4 lr + n of channel tile n
     const int lr = lane & 15, lg = lane >> 4;
     // W1 fragments: registers for CIN = 64; for CIN = 128 a swizzled copy of the 64-row slice in LDS behind the ring
-    // (16-byte chunk c of row r at chunk c ^ ((r >> 2) & 15): conflict-free ds_read_b128 of a fragment)
-    constexpr bool W1_LDS = CIN > 64;
+    // (16-byte chunk c of row r at chunk c ^ ((r >> 2) & (chunks per row - 1)): conflict-free ds_read_b128 of a fragment at 128
+    // input channels, two-way at 64 — eight reads per two walk rows)
+    // PF (rebuilt form): the NEXT chunk's gradient rows are loaded before the current chunk's walk and stay in registers under it —
+    // the kernel runs two workgroups per CU and was latency-bound (vector ALUs 52 % busy, a third of the wave cycles waiting): with
+    // the loads a chunk ahead a workgroup never waits for HBM at the top of a chunk.  The 36 registers come from the W1 fragments,
+    // which then live in LDS for 64 input channels too
+    constexpr bool PF = CIN > 0 && WK_S1C_PF != 0;
+    constexpr bool W1_LDS = CIN > 64 || PF || WK_S1C_W1LDS != 0;
     constexpr unsigned W1_OFF = CIN > 0 ? RING_BYTES : RING_BYTES + (unsigned)RB * 4096u;
     uint4 wfr[W1_LDS ? 1 : 4][KB];
     const T* a0src0 = nullptr;
@@ -290,7 +307,7 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
             for (int i = tid; i < 64 * CH; i += NT) {
                 const int r = i / CH, c = i % CH;
                 const int ch = c0 + r;
-                *reinterpret_cast<uint4*>(wk_smem + W1_OFF + (r * CH + (c ^ ((r >> 2) & 15))) * 16) =
+                *reinterpret_cast<uint4*>(wk_smem + W1_OFF + (r * CH + (c ^ ((r >> 2) & (CH - 1)))) * 16) =
                     *reinterpret_cast<const uint4*>(w1 + (i64)(ch < a.C ? ch : c0) * CIN + 8 * c);
             }
             __syncthreads();
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
     auto w1frag = [&](const int n, const int kb) -> uint4 {
         if constexpr (W1_LDS) {
             const int r = 4 * lr + n;
-            return *reinterpret_cast<const uint4*>(wk_smem + W1_OFF + (r * (CIN / 8) + ((lg + 4 * kb) ^ lr)) * 16);
+            return *reinterpret_cast<const uint4*>(wk_smem + W1_OFF + (r * (CIN / 8) + ((lg + 4 * kb) ^ (lr & (CIN / 8 - 1)))) * 16);
         } else {
             return wfr[n][kb];
         }
@@ -319,6 +336,23 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
     const unsigned lodelta = jj > 0 ? (unsigned)a.dy.ld : 0u;          // jj == 0: the low pixel is the halo (masked)
     const unsigned collast = (unsigned)(W - 1) * (unsigned)a.dy.ld;
 
+    // the staged rows of one chunk, raw: RB rows x (low, high) pixel of the thread's pair column + the halo column's rows
+    uint2 st_rp[RB][2], st_rq[RB][2], st_ep[NEX], st_eq[NEX];
+    auto stage_issue = [&](const T* dp0_, const T* dq0_, const int s_, const bool pv) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int ho = s_ + u;
+            const unsigned off = (pv && ho < Hin) ? (unsigned)ho * dyrow + colhi : lodelta;      // rows past the plane: any valid address (masked)
+            st_rp[u][1] = wk_ld8(dp0_ + off); st_rq[u][1] = wk_ld8(dq0_ + off);
+            st_rp[u][0] = wk_ld8(dp0_ + off - lodelta); st_rq[u][0] = wk_ld8(dq0_ + off - lodelta);
+        }
+#pragma unroll
+        for (int e = 0; e < NEX; ++e) {
+            const int ho = s_ + jj + e * LPW;
+            const unsigned off = (pv && jj + e * LPW < RB && ho < Hin) ? (unsigned)ho * dyrow + collast : 0u;
+            st_ep[e] = wk_ld8(dp0_ + off); st_eq[e] = wk_ld8(dq0_ + off);
+        }
+    };
     for (int pg = blk.x; pg < ngroups; pg += gridDim.x) {
         const int plane = pg * NG + grp;
         const bool pvalid = plane < a.planes && chan_ok;
@@ -326,6 +360,10 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
         const i64 pbase = (i64)psafe * Hin * W * a.dy.ld + chs;
         const T* dp0 = reinterpret_cast<const T*>(a.dy.p) + pbase;
         const T* dq0 = reinterpret_cast<const T*>(a.dy.q) + pbase;
+        // the group this workgroup takes next (prefetch target of this group's last chunk)
+        const int pgn = pg + (int)gridDim.x < ngroups ? pg + (int)gridDim.x : pg;
+        const bool pvalid_n = pgn * NG + grp < a.planes && chan_ok;
+        const i64 pbase_n = (i64)(pgn * NG + grp < a.planes ? pgn * NG + grp : 0) * Hin * W * a.dy.ld + chs;
         const int dplane = pg * NG + dgrp < a.planes ? pg * NG + dgrp : 0;
         const T* ysrc0 = y1p + ((i64)dplane * Hin * W + dx) * a.y1.ld + dce;
         if constexpr (CIN > 0) {
@@ -341,6 +379,41 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
         *reinterpret_cast<uint4*>(tcol) = make_uint4(0, 0, 0, 0);
         if (jj == 0) *reinterpret_cast<uint4*>(tlast) = make_uint4(0, 0, 0, 0);
         int slot_s = 1;                            // ring slot of gradient row s = chunk * RB   (slot(r) = (r + 1) mod RQ)
+        auto stage_finish = [&](const int s_, const int slot_, const bool pv) {
+            const float4 c1 = *reinterpret_cast<const float4*>(&lcoef[2 * CS + cv * 4]);
+            const float4 c2 = *reinterpret_cast<const float4*>(&lcoef[3 * CS + cv * 4]);
+            const float4 c3 = *reinterpret_cast<const float4*>(&lcoef[4 * CS + cv * 4]);
+            const wk_f2_t a1v[2] = {wk_f2_t{c1.x, c1.y}, wk_f2_t{c1.z, c1.w}}, a2v[2] = {wk_f2_t{c2.x, c2.y}, wk_f2_t{c2.z, c2.w}};
+            const wk_f2_t a3v[2] = {wk_f2_t{c3.x, c3.y}, wk_f2_t{c3.z, c3.w}};
+            auto affine_pack = [&](const uint2& plo, const uint2& qlo, const uint2& phi, const uint2& qhi) {
+                wk_f2_t p0, p1, q0, q1, gl0, gl1, gh0, gh1;
+                wk_unpack(plo, p0, p1); wk_unpack(qlo, q0, q1);
+                gl0 = a1v[0] * p0 + (a2v[0] * q0 + a3v[0]); gl1 = a1v[1] * p1 + (a2v[1] * q1 + a3v[1]);
+                wk_unpack(phi, p0, p1); wk_unpack(qhi, q0, q1);
+                gh0 = a1v[0] * p0 + (a2v[0] * q0 + a3v[0]); gh1 = a1v[1] * p1 + (a2v[1] * q1 + a3v[1]);
+                return make_uint4(pk_bf16(gl0.x, gh0.x), pk_bf16(gl0.y, gh0.y), pk_bf16(gl1.x, gh1.x), pk_bf16(gl1.y, gh1.y));
+            };
+            int sl = slot_;
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                uint4 o = affine_pack(st_rp[u][0], st_rq[u][0], st_rp[u][1], st_rq[u][1]);
+                const unsigned m = (pv && s_ + u < Hin) ? cmask : 0u;
+                o.x &= m; o.y &= m; o.z &= m; o.w &= m;
+                *reinterpret_cast<uint4*>(tcol + sl * rowdw) = o;
+                sl = sl + 1 == RQ ? 0 : sl + 1;
+            }
+#pragma unroll
+            for (int e = 0; e < NEX; ++e) {
+                const int u = jj + e * LPW;
+                if (u < RB) {
+                    uint4 o = affine_pack(st_ep[e], st_eq[e], st_ep[e], st_eq[e]);
+                    const unsigned m = (pv && s_ + u < Hin) ? 0x0000ffffu : 0u;
+                    o.x &= m; o.y &= m; o.z &= m; o.w &= m;
+                    int se = slot_ + u; se = se >= RQ ? se - RQ : se;
+                    *reinterpret_cast<uint4*>(tlast + se * rowdw) = o;
+                }
+            }
+        };
         uint4 afr[RB / 2][KB];                     // rebuilt form: a0 fragments of the chunk's rows, two rows per MFMA pixel tile
         auto load_afr_t = [&](const int s_, const int t) {        // tile t of chunk s_: rows s_ - 1 + 2 t, s_ + 2 t
             if constexpr (CIN > 0) {
@@ -359,6 +432,7 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
             }
         };
         load_afr(0);
+        if constexpr (PF) { if (pg == blk.x) stage_issue(dp0, dq0, 0, pvalid); }      // (later groups: issued under the previous group's last walk)
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             const int s = chunk * RB;
             // staging + rebuild at raised issue priority: the CU's other workgroups are mostly in their walk, which can wait; this
@@ -375,61 +449,18 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
                 }
             }
             // ---------------- stage dL/dy2 rows s .. s+RB-1 (BatchNorm-backward affine), x-pair-packed, into their ring slots
-            {
-                uint2 rp[RB][2], rq[RB][2], ep[NEX], eq[NEX];
-                bool ok[RB], eok[NEX];
-                const float4 c1 = *reinterpret_cast<const float4*>(&lcoef[2 * CS + cv * 4]);
-                const float4 c2 = *reinterpret_cast<const float4*>(&lcoef[3 * CS + cv * 4]);
-                const float4 c3 = *reinterpret_cast<const float4*>(&lcoef[4 * CS + cv * 4]);
-                const wk_f2_t a1v[2] = {wk_f2_t{c1.x, c1.y}, wk_f2_t{c1.z, c1.w}}, a2v[2] = {wk_f2_t{c2.x, c2.y}, wk_f2_t{c2.z, c2.w}};
-                const wk_f2_t a3v[2] = {wk_f2_t{c3.x, c3.y}, wk_f2_t{c3.z, c3.w}};
-                auto affine_pack = [&](const uint2& plo, const uint2& qlo, const uint2& phi, const uint2& qhi) {
-                    wk_f2_t p0, p1, q0, q1, gl0, gl1, gh0, gh1;
-                    wk_unpack(plo, p0, p1); wk_unpack(qlo, q0, q1);
-                    gl0 = a1v[0] * p0 + (a2v[0] * q0 + a3v[0]); gl1 = a1v[1] * p1 + (a2v[1] * q1 + a3v[1]);
-                    wk_unpack(phi, p0, p1); wk_unpack(qhi, q0, q1);
-                    gh0 = a1v[0] * p0 + (a2v[0] * q0 + a3v[0]); gh1 = a1v[1] * p1 + (a2v[1] * q1 + a3v[1]);
-                    return make_uint4(pk_bf16(gl0.x, gh0.x), pk_bf16(gl0.y, gh0.y), pk_bf16(gl1.x, gh1.x), pk_bf16(gl1.y, gh1.y));
-                };
-#pragma unroll
-                for (int u = 0; u < RB; ++u) {
-                    const int ho = s + u;
-                    ok[u] = pvalid && ho < Hin;
-                    const unsigned off = ok[u] ? (unsigned)ho * dyrow + colhi : lodelta;
-                    rp[u][1] = wk_ld8(dp0 + off); rq[u][1] = wk_ld8(dq0 + off);
-                    rp[u][0] = wk_ld8(dp0 + off - lodelta); rq[u][0] = wk_ld8(dq0 + off - lodelta);
-                }
-#pragma unroll
-                for (int e = 0; e < NEX; ++e) {
-                    const int ho = s + jj + e * LPW;
-                    eok[e] = pvalid && jj + e * LPW < RB && ho < Hin;
-                    const unsigned off = eok[e] ? (unsigned)ho * dyrow + collast : 0u;
-                    ep[e] = wk_ld8(dp0 + off); eq[e] = wk_ld8(dq0 + off);
-                }
-                int sl = slot_s;
-#pragma unroll
-                for (int u = 0; u < RB; ++u) {
-                    uint4 o = affine_pack(rp[u][0], rq[u][0], rp[u][1], rq[u][1]);
-                    const unsigned m = ok[u] ? cmask : 0u;
-                    o.x &= m; o.y &= m; o.z &= m; o.w &= m;
-                    *reinterpret_cast<uint4*>(tcol + sl * rowdw) = o;
-                    sl = sl + 1 == RQ ? 0 : sl + 1;
-                }
-#pragma unroll
-                for (int e = 0; e < NEX; ++e) {
-                    const int u = jj + e * LPW;
-                    if (u < RB) {
-                        uint4 o = affine_pack(ep[e], eq[e], ep[e], eq[e]);
-                        const unsigned m = eok[e] ? 0x0000ffffu : 0u;
-                        o.x &= m; o.y &= m; o.z &= m; o.w &= m;
-                        int se = slot_s + u; se = se >= RQ ? se - RQ : se;
-                        *reinterpret_cast<uint4*>(tlast + se * rowdw) = o;
-                    }
-                }
-            }
+            if constexpr (!PF) stage_issue(dp0, dq0, s, pvalid);
+            stage_finish(s, slot_s, pvalid);
             if constexpr (CIN == 0) wk_wait_vm0();  // this wave's y1 blocks have landed (it is their only reader)
             __builtin_amdgcn_s_setprio(0);
             wk_lds_barrier();
+            if constexpr (PF) {
+                // the next chunk's gradient rows (this group's, or the first chunk of the group this workgroup takes next; after the last
+                // chunk of its last group: the same addresses again, unused) — in flight under the walk below
+                const bool last = chunk + 1 == nchunks;
+                stage_issue(reinterpret_cast<const T*>(a.dy.p) + (last ? pbase_n : pbase), reinterpret_cast<const T*>(a.dy.q) + (last ? pbase_n : pbase),
+                            last ? 0 : s + RB, last ? pvalid_n : pvalid);
+            }
             // ---------------- walk rows s-1 .. s+RB-2 of this thread's pixel-pair column
             const int r_lo = s > 0 ? s - 1 : 0;
             const int r_hi = s + RB - 1 < Hin ? s + RB - 1 : Hin;          // exclusive
@@ -437,6 +468,17 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
             const wk_f2_t bs2[2] = {wk_f2_t{s4.x, s4.y}, wk_f2_t{s4.z, s4.w}}, bt2[2] = {wk_f2_t{t4.x, t4.y}, wk_f2_t{t4.z, t4.w}};
             // one row of this thread's pixel pair: y[h][q] = y1 of pixel h, channel pair q (fp32)
             auto row_math = [&](const int r, const uint4 (&g0)[2], const uint4 (&g1)[2], const uint4 (&g2)[2], const wk_f2_t (&y)[2][2]) {
+                // PIPE (rebuilt form, 256 registers): the packed tap weights of a stencil row are read from LDS one stencil row AHEAD of
+                // their use — the first set before the activation math — and the stencil rows run oldest gradient row first (the newest,
+                // read from the ring at the top of this row step, last).  With one set live at a time every row step exposed three
+                // dependent LDS round trips (vector ALUs 52 % busy at two waves per SIMD).
+                constexpr bool PIPE = CIN > 0 && WK_S1C_PIPE != 0;
+                auto ldw = [&](const int dy, uint4 (&Wv)[4]) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) Wv[k] = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + k) * CS + cv * 4]);
+                };
+                uint4 Wcur[4], Wnxt[4];
+                if constexpr (PIPE) { ldw(2, Wcur); __builtin_amdgcn_sched_barrier(0); }
                 wk_f2_t z1[2][2], dsl[2][2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -452,17 +494,16 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
                                        pk_bf16(z1[0][1].x, z1[1][1].x), pk_bf16(z1[0][1].y, z1[1][1].y)};
                 float dz0[4] = {0.f, 0.f, 0.f, 0.f}, dz1[4] = {0.f, 0.f, 0.f, 0.f};       // (wk_dot2z here costs 30 spilled registers)
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    __builtin_amdgcn_sched_barrier(0);        // one stencil row's weight vectors live at a time (registers)
+                for (int step = 0; step < 3; ++step) {
+                    const int dy = PIPE ? 2 - step : step;
+                    if constexpr (PIPE) { if (step < 2) ldw(dy - 1, Wnxt); }
+                    __builtin_amdgcn_sched_barrier(0);        // one (PIPE: two) stencil row's weight vectors live at a time (registers)
+                    if constexpr (!PIPE) ldw(dy, Wcur);
                     const uint4 G0 = dy == 0 ? g2[0] : dy == 1 ? g1[0] : g0[0];
                     const uint4 G1 = dy == 0 ? g2[1] : dy == 1 ? g1[1] : g0[1];
-                    const uint4 Wa = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 0) * CS + cv * 4]);
-                    const uint4 Wb = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 1) * CS + cv * 4]);
-                    const uint4 Wc = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 2) * CS + cv * 4]);
-                    const uint4 Wd = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 3) * CS + cv * 4]);
                     const unsigned ga[4] = {G0.x, G0.y, G0.z, G0.w}, gb[4] = {G1.x, G1.y, G1.z, G1.w};
-                    const unsigned wa[4] = {Wa.x, Wa.y, Wa.z, Wa.w}, wb[4] = {Wb.x, Wb.y, Wb.z, Wb.w};
-                    const unsigned wc[4] = {Wc.x, Wc.y, Wc.z, Wc.w}, wd[4] = {Wd.x, Wd.y, Wd.z, Wd.w};
+                    const unsigned wa[4] = {Wcur[0].x, Wcur[0].y, Wcur[0].z, Wcur[0].w}, wb[4] = {Wcur[1].x, Wcur[1].y, Wcur[1].z, Wcur[1].w};
+                    const unsigned wc[4] = {Wcur[2].x, Wcur[2].y, Wcur[2].z, Wcur[2].w}, wd[4] = {Wcur[3].x, Wcur[3].y, Wcur[3].z, Wcur[3].w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         dz0[q] = wk_dot2(ga[q], wa[q], dz0[q]);
@@ -473,6 +514,10 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
                         dwp[dy * 3 + 2][q] = wk_dot2(Z[q], ga[q], dwp[dy * 3 + 2][q]);
                         dwp[dy * 3 + 1][q] = wk_dot2(Z[q], gm, dwp[dy * 3 + 1][q]);
                         dwp[dy * 3 + 0][q] = wk_dot2(Z[q], gb[q], dwp[dy * 3 + 0][q]);
+                    }
+                    if constexpr (PIPE) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) Wcur[k] = Wnxt[k];
                     }
                 }
                 T* dst = dh0 + (unsigned)r * dhrow;
@@ -980,7 +1025,7 @@ template <int LPW, int RB, int CIN>
 static int launch_s1c(const DwSpatialBwd& a, hipStream_t s) {
     constexpr int NG = 16 / LPW, Wqp = LPW + 1;
     // ring + (stored form) the chunk's y1 rows by LDS-DMA / (rebuilt form, 128 input channels) the W1 slice
-    const size_t lds = (size_t)NG * (RB + 2) * Wqp * 256 + (CIN > 0 ? (CIN > 64 ? (size_t)64 * CIN * 2 : 0) : (size_t)RB * 4096);
+    const size_t lds = (size_t)NG * (RB + 2) * Wqp * 256 + (CIN > 0 ? ((CIN > 64 || WK_S1C_PF || WK_S1C_W1LDS) ? (size_t)64 * CIN * 2 : 0) : (size_t)RB * 4096);
     auto kern = dw_spatial_bwd_s1c_kernel<LPW, RB, CIN>;
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         (void)hipGetLastError();

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
                 }
             }
     }
-    wf_f2_t st0[2] = {wf_f2_t{0.f, 0.f}, wf_f2_t{0.f, 0.f}}, st1[2] = {wf_f2_t{0.f, 0.f}, wf_f2_t{0.f, 0.f}};
+    float st0[4] = {0.f, 0.f, 0.f, 0.f}, st1[4] = {0.f, 0.f, 0.f, 0.f};            // BatchNorm-2 sums of this thread's 4 channels
 
     const int Hin = a.Hin, Win = a.Win, Hout = a.Hout, Wout = a.Wout;
     const int ngroups = (a.planes + NG - 1) / NG;
@@ -457,15 +457,21 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
                 const unsigned* tc = tplane + (ST == 1 ? jj : 2 * jj) * PS;       // first ring pair of this output pair
                 auto finish = [&](const int oy, const float* acc0, const float* acc1) {
                     T* dst = out0 + (unsigned)oy * outrow;
-                    const uint2 pk0 = make_uint2(pk_bf16(acc0[0], acc0[1]), pk_bf16(acc0[2], acc0[3]));
-                    const uint2 pk1 = make_uint2(pk_bf16(acc1[0], acc1[1]), pk_bf16(acc1[2], acc1[3]));
+                    // round per channel as a PIXEL pair (x = 2jj, 2jj+1): the BatchNorm-2 sums of the values as stored are then two dot
+                    // products per channel (pair . (1, 1) and pair . pair) instead of unpack + packed add + packed fma, and the stores'
+                    // channel-paired dwords are one v_perm each (round 6: 16 single-rate instructions where there were 20, 8 of them packed)
+                    unsigned q[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) q[i] = pk_bf16(acc0[i], acc1[i]);
+                    const uint2 pk0 = make_uint2(__builtin_amdgcn_perm(q[1], q[0], 0x05040100u), __builtin_amdgcn_perm(q[3], q[2], 0x05040100u));
+                    const uint2 pk1 = make_uint2(__builtin_amdgcn_perm(q[1], q[0], 0x07060302u), __builtin_amdgcn_perm(q[3], q[2], 0x07060302u));
                     *reinterpret_cast<uint2*>(dst) = pk0;
                     *reinterpret_cast<uint2*>(dst + a.C) = pk1;
-                    wf_f2_t r0, r1;
-                    wf_unpack(pk0, r0, r1);
-                    st0[0] += r0; st0[1] += r1; st1[0] += r0 * r0; st1[1] += r1 * r1;
-                    wf_unpack(pk1, r0, r1);
-                    st0[0] += r0; st0[1] += r1; st1[0] += r0 * r0; st1[1] += r1 * r1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        st0[i] = wf_dot2(q[i], 0x3f803f80u, st0[i]);
+                        st1[i] = wf_dot2(q[i], q[i], st1[i]);
+                    }
                 };
                 if constexpr (ST == 1 && !QL) {
                     // ring slots of input rows o_lo - 1, o_lo, o_lo + 1
@@ -583,8 +589,8 @@ __global__ __launch_bounds__(256, CIN > 0 ? (ST * RB <= 4 && CIN <= 64 ? WF_MINW
         }
     }
     if (a.stats) {
-        const unsigned v[8] = {__float_as_uint(st0[0].x), __float_as_uint(st0[0].y), __float_as_uint(st0[1].x), __float_as_uint(st0[1].y),
-                               __float_as_uint(st1[0].x), __float_as_uint(st1[0].y), __float_as_uint(st1[1].x), __float_as_uint(st1[1].y)};
+        const unsigned v[8] = {__float_as_uint(st0[0]), __float_as_uint(st0[1]), __float_as_uint(st0[2]), __float_as_uint(st0[3]),
+                               __float_as_uint(st1[0]), __float_as_uint(st1[1]), __float_as_uint(st1[2]), __float_as_uint(st1[3])};
         float c4[4], d2[2];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

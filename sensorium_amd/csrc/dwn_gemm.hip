@@ -1115,6 +1115,9 @@ __global__ __launch_bounds__(256, (TnOcc<PLD, QLD>::value)) void gemm_tn_kernel(
 #ifndef TN_SLOTS
 #define TN_SLOTS 2
 #endif
+#ifndef TN_F64_SLOTS
+#define TN_F64_SLOTS 2
+#endif
 template <typename T, int PLD, int QLD>
 static int launch_tn_t(const GemmTN& g_in, hipStream_t s) {
     GemmTN g = g_in;
@@ -1146,6 +1149,7 @@ static int launch_tn_t(const GemmTN& g_in, hipStream_t s) {
             bpc = 1;
         }
         if (bpc > TN_SLOTS) bpc = TN_SLOTS;
+        if (g.dw_f64 && bpc > TN_F64_SLOTS) bpc = TN_F64_SLOTS;      // every split adds one fp64 atomic per output element, all to the same addresses
         const int tiles = ((g.R + 127) / 128) * ((g.Cc + 127) / 128) * g.groups;
         int want = (256 * bpc) / tiles;
         const int maxsplit = (int)((g.M + 511) / 512);
