@@ -59,8 +59,9 @@ CONFIGS = [
     ("plain", 505, 71, 11, 0.0, 0.0, 1e-2, 2e-3, 5e-3),
     # round-5 verdict item 7c: a second seed WITH the reference's regularisation on (Dropout1d 0.4 in the readout, DropPath 0.1 in core
     # and cortex: dwiseneuro.py:256,317,382; true_batch_001.py:36-37).  Both modes draw the same masks (the torch generator is
-    # re-seeded before each run and both make the same draws per step).  Bounds: twice what was measured (profiles/r6_bf16_convergence_drop.json)
-    ("drop", 606, 72, 12, 0.4, 0.1, 2e-2, 4e-3, 1e-2),
+    # re-seeded before each run and both make the same draws per step).  Same bounds as the plain run; measured: epoch-mean loss gap
+    # 4e-4 of the drop, held-out correlation of the EMA network 0.71015 (fp32) vs 0.71024 (bf16): profiles/r6_bf16_convergence_drop.json
+    ("drop", 606, 72, 12, 0.4, 0.1, 1e-2, 2e-3, 5e-3),
 ]
 
 
