@@ -755,15 +755,8 @@ __global__ __launch_bounds__(DWS_BWD_THREADS, (ST == 1 ? DWS_BWD_MINB1 : 3)) voi
 // temporal forward: y3[t] = sum_k w[k] z2[t + k - P]
 // ------------------------------------------------------------------------------------------------
 // ZOUT (eval mode): the output is z3 = SiLU(BN3(y3)) and the SqueezeExcite pooling sums ride along (see dwn.h)
-// RS = ring slots = frames per unrolled batch (>= KT).  RS == KT: any T, but a clip of T frames costs ceil(T / KT) * KT load slots
-// (T = 16: 20, T = 32: 35); RS = 8 for T % 8 == 0 (the training clip of 32 frames, the inference window of 16): no wasted slot,
-// eight loads in flight per batch.  Same arithmetic, same order: the results are bit-identical.
-#ifndef DWT_FWD_RS8
-#define DWT_FWD_RS8 1
-#endif
-template <typename T, int KT, bool ZOUT = false, int RS = KT>
+template <typename T, int KT, bool ZOUT = false>
 __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFwd a) {
-    static_assert(RS >= KT, "the ring holds a whole window");
     constexpr int NCV = SL<T>::NCV, CS = SL<T>::CS, LP = SL<T>::LP, P = KT / 2;
     typedef typename SL<T>::raw_t raw_t;
     __shared__ float lstat[2 * CS];
@@ -829,9 +822,9 @@ __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFw
             const i64 b = pos / a.HW, hw = pos % a.HW;
             const T* ip = inp + (b * a.T * a.HW + hw) * a.C + chan;      // element (t = 0)
             T* op = outp + (b * a.T * a.HW + hw) * a.C + chan;
-            // ring of RS slots, RS frames per unrolled batch: at step u of a batch z2(t + k - P) lives in slot (u + k) % RS — compile-time
+            // ring of KT slots, KT frames per unrolled batch: at step u of a batch z2(t + k - P) lives in slot (u + k) % KT — compile-time
             // indices, no register shifting (the shifting version spent 52 moves per 16 outputs)
-            float win[RS][4];
+            float win[KT][4];
             [[maybe_unused]] float ps[4] = {0.f, 0.f, 0.f, 0.f};         // ZOUT: this position's sums over t of the stored z3
 #pragma unroll
             for (int k = 0; k < KT - 1; ++k) {
@@ -839,25 +832,25 @@ __global__ __launch_bounds__(256) void dw_temporal_fwd_kernel(const DwTemporalFw
                 if (t >= 0 && t < a.T) { ld4<T>(ip + t * tstride, win[k]); bn_silu4(win[k], bs, bt); }
                 else { win[k][0] = win[k][1] = win[k][2] = win[k][3] = 0.f; }
             }
-            for (int t0 = 0; t0 < a.T; t0 += RS) {
-                raw_t raw[RS];
+            for (int t0 = 0; t0 < a.T; t0 += KT) {
+                raw_t raw[KT];
 #pragma unroll
-                for (int u = 0; u < RS; ++u) {
+                for (int u = 0; u < KT; ++u) {
                     int tl = t0 + u + P;
                     raw[u] = ld4_raw<T>(ip + (tl < a.T ? tl : 0) * tstride);
                 }
 #pragma unroll
-                for (int u = 0; u < RS; ++u) {
+                for (int u = 0; u < KT; ++u) {
                     int t = t0 + u;
                     if (t >= a.T) break;
-                    const int sn = (u + KT - 1) % RS;                   // newest slot: frame t + P
+                    const int sn = (u + KT - 1) % KT;                   // newest slot: frame t + P
                     if (t + P < a.T) { V4<T>::unpack(raw[u], win[sn]); bn_silu4(win[sn], bs, bt); }
                     else { win[sn][0] = win[sn][1] = win[sn][2] = win[sn][3] = 0.f; }
                     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int k = 0; k < KT; ++k)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[k][i], win[(u + k) % RS][i], acc[i]);
+                        for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[k][i], win[(u + k) % KT][i], acc[i]);
                     if constexpr (ZOUT) {
                         float z[4];
 #pragma unroll
@@ -1385,15 +1378,13 @@ static int temporal_fwd_t(const DwTemporalFwd& a, hipStream_t s) {
     const i64 work = (npos + LP - 1) / LP;
     if (a.z_scale) {
         if (!a.z_shift || a.stats) return dwn_set_error(-2, "dw_temporal: the z3 epilogue needs z_shift and no statistics (eval mode)");
-        if (a.kt == 5 && a.T % 8 == 0 && DWT_FWD_RS8) { dim3 grid(resident_grid_x(dw_temporal_fwd_kernel<T, 5, true, 8>, 0, slices, work), slices); hipLaunchKernelGGL((dw_temporal_fwd_kernel<T, 5, true, 8>), grid, dim3(256), 0, s, a); }
-        else if (a.kt == 5) { dim3 grid(resident_grid_x(dw_temporal_fwd_kernel<T, 5, true>, 0, slices, work), slices); hipLaunchKernelGGL((dw_temporal_fwd_kernel<T, 5, true>), grid, dim3(256), 0, s, a); }
+        if (a.kt == 5) { dim3 grid(resident_grid_x(dw_temporal_fwd_kernel<T, 5, true>, 0, slices, work), slices); hipLaunchKernelGGL((dw_temporal_fwd_kernel<T, 5, true>), grid, dim3(256), 0, s, a); }
         else if (a.kt == 3) { dim3 grid(resident_grid_x(dw_temporal_fwd_kernel<T, 3, true>, 0, slices, work), slices); hipLaunchKernelGGL((dw_temporal_fwd_kernel<T, 3, true>), grid, dim3(256), 0, s, a); }
         else return dwn_set_error(-4, "dw_temporal: only temporal_kernel 3 or 5 is built");
         DWN_CHECK_LAUNCH();
         return 0;
     }
-    if (a.kt == 5 && a.T % 8 == 0 && DWT_FWD_RS8) { dim3 grid(resident_grid_x(dw_temporal_fwd_kernel<T, 5, false, 8>, 0, slices, work), slices); hipLaunchKernelGGL((dw_temporal_fwd_kernel<T, 5, false, 8>), grid, dim3(256), 0, s, a); }
-    else if (a.kt == 5) { dim3 grid(resident_grid_x(dw_temporal_fwd_kernel<T, 5>, 0, slices, work), slices); hipLaunchKernelGGL((dw_temporal_fwd_kernel<T, 5>), grid, dim3(256), 0, s, a); }
+    if (a.kt == 5) { dim3 grid(resident_grid_x(dw_temporal_fwd_kernel<T, 5>, 0, slices, work), slices); hipLaunchKernelGGL((dw_temporal_fwd_kernel<T, 5>), grid, dim3(256), 0, s, a); }
     else if (a.kt == 3) { dim3 grid(resident_grid_x(dw_temporal_fwd_kernel<T, 3>, 0, slices, work), slices); hipLaunchKernelGGL((dw_temporal_fwd_kernel<T, 3>), grid, dim3(256), 0, s, a); }
     else return dwn_set_error(-4, "dw_temporal: only temporal_kernel 3 or 5 is built");
     DWN_CHECK_LAUNCH();

@@ -146,10 +146,12 @@ def test_bf16_gradient_gain_at_the_metric_batch():
         gain = float((g16[k] * g32[k]).sum()) / n32 ** 2
         cos = float((g16[k] * g32[k]).sum()) / (n32 * float(g16[k].norm()))
         if k == "core.stem.0.weight":
-            # 320 elements, a small correlation of two large tensors at the far end of the bf16 chain: its gain moves 0.92 ... 1.03
-            # with the DATA (four input seeds, stored and unmaterialised y1 alike: profiles/r5_stem_gain_seeds.txt; the seed used
-            # here gave 0.98-1.00 in round 4 and gives 0.96-0.98 with BatchNorm-1's statistics from the Gram matrix: one other draw)
-            assert abs(gain - 1.0) <= 0.1 and cos >= 0.95, (k, gain, cos)
+            # 320 elements, a small correlation of two large tensors at the far end of the bf16 chain.  On THIS data seed it measures
+            # 0.984 / 0.998 with y1 unmaterialised and 0.979 / 0.992 with y1 stored (round 6, profiles/r6_stem_gain_seeds.txt): the same
+            # in both modes since the rebuilt y1 is no longer rounded and the Gram sums are fp64 (round 5: 0.96-0.98 vs 0.987-1.006).
+            # Bound: 5e-2 in either mode (2.5 x the largest deviation seen on this seed).  Across DATA seeds the gain of this one
+            # parameter scatters 0.93 ... 1.02, stored and unmaterialised alike — a property of the gradient, not of a mode.
+            assert abs(gain - 1.0) <= 5e-2 and cos >= 0.95, (k, gain, cos)
         elif n32 >= 1e-2 * tot32:
             assert abs(gain - 1.0) <= 2e-2, (k, gain)
         else:
