@@ -34,16 +34,10 @@
 #ifndef WK_MINW2_RC
 #define WK_MINW2_RC 2      // ... its y1-rebuilding form (W1 fragments + accumulators on top)
 #endif
-#ifndef WK_S1C_PIPE
-#define WK_S1C_PIPE 0      // stride-1 y1-rebuilding form: 1 = tap weights read from LDS one stencil row ahead (needs WK_S1C_W1LDS for the registers)
-#endif
-#ifndef WK_S1C_W1LDS
-#define WK_S1C_W1LDS 0     // stride-1 y1-rebuilding form: W1 fragments in LDS at 64 input channels too (their 32 registers hold the second
-                           // set of tap weights: the walk reads them one stencil row ahead)
-#endif
 #ifndef WK_S1C_PF
-#define WK_S1C_PF 0        // stride-1 y1-rebuilding form: 1 = the next chunk's gradient rows are fetched under the current chunk's walk (measured:
-                           // no gain at 64 input channels, 430 vs 429 us; -11 % on the 128-channel / 16-pixel-wide form, which the default path does not take)
+#define WK_S1C_PF 1        // stride-1 y1-rebuilding form, gradient rows of the NEXT chunk fetched under the current chunk's walk: 0 = never,
+                           // 1 = at 128 input channels (measured -11 %: 284 -> 252 us at 1024 planes of 9 x 16, E = 896), 2 = always
+                           // (64 input channels: 430 vs 429 us — that form is not waiting for these loads)
 #endif
 
 extern __shared__ __attribute__((aligned(16))) unsigned char wk_smem[];
@@ -295,8 +289,8 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
     // the kernel runs two workgroups per CU and was latency-bound (vector ALUs 52 % busy, a third of the wave cycles waiting): with
     // the loads a chunk ahead a workgroup never waits for HBM at the top of a chunk.  The 36 registers come from the W1 fragments,
     // which then live in LDS for 64 input channels too
-    constexpr bool PF = CIN > 0 && WK_S1C_PF != 0;
-    constexpr bool W1_LDS = CIN > 64 || PF || WK_S1C_W1LDS != 0;
+    constexpr bool PF = (CIN > 64 && WK_S1C_PF >= 1) || (CIN > 0 && WK_S1C_PF >= 2);
+    constexpr bool W1_LDS = CIN > 64 || PF;
     constexpr unsigned W1_OFF = CIN > 0 ? RING_BYTES : RING_BYTES + (unsigned)RB * 4096u;
     uint4 wfr[W1_LDS ? 1 : 4][KB];
     const T* a0src0 = nullptr;
@@ -468,17 +462,6 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
             const wk_f2_t bs2[2] = {wk_f2_t{s4.x, s4.y}, wk_f2_t{s4.z, s4.w}}, bt2[2] = {wk_f2_t{t4.x, t4.y}, wk_f2_t{t4.z, t4.w}};
             // one row of this thread's pixel pair: y[h][q] = y1 of pixel h, channel pair q (fp32)
             auto row_math = [&](const int r, const uint4 (&g0)[2], const uint4 (&g1)[2], const uint4 (&g2)[2], const wk_f2_t (&y)[2][2]) {
-                // PIPE (rebuilt form, 256 registers): the packed tap weights of a stencil row are read from LDS one stencil row AHEAD of
-                // their use — the first set before the activation math — and the stencil rows run oldest gradient row first (the newest,
-                // read from the ring at the top of this row step, last).  With one set live at a time every row step exposed three
-                // dependent LDS round trips (vector ALUs 52 % busy at two waves per SIMD).
-                constexpr bool PIPE = CIN > 0 && WK_S1C_PIPE != 0;
-                auto ldw = [&](const int dy, uint4 (&Wv)[4]) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) Wv[k] = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + k) * CS + cv * 4]);
-                };
-                uint4 Wcur[4], Wnxt[4];
-                if constexpr (PIPE) { ldw(2, Wcur); __builtin_amdgcn_sched_barrier(0); }
                 wk_f2_t z1[2][2], dsl[2][2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -494,16 +477,19 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
                                        pk_bf16(z1[0][1].x, z1[1][1].x), pk_bf16(z1[0][1].y, z1[1][1].y)};
                 float dz0[4] = {0.f, 0.f, 0.f, 0.f}, dz1[4] = {0.f, 0.f, 0.f, 0.f};       // (wk_dot2z here costs 30 spilled registers)
 #pragma unroll
-                for (int step = 0; step < 3; ++step) {
-                    const int dy = PIPE ? 2 - step : step;
-                    if constexpr (PIPE) { if (step < 2) ldw(dy - 1, Wnxt); }
-                    __builtin_amdgcn_sched_barrier(0);        // one (PIPE: two) stencil row's weight vectors live at a time (registers)
-                    if constexpr (!PIPE) ldw(dy, Wcur);
+                for (int dy = 0; dy < 3; ++dy) {
+                    __builtin_amdgcn_sched_barrier(0);        // one stencil row's weight vectors live at a time (registers)
+                    // (reading the tap weights one stencil row ahead, oldest gradient row first — 16 more registers, W1 moved to LDS for
+                    // them — measured 431 vs 416 us on the rebuilt form: no gain, removed)
                     const uint4 G0 = dy == 0 ? g2[0] : dy == 1 ? g1[0] : g0[0];
                     const uint4 G1 = dy == 0 ? g2[1] : dy == 1 ? g1[1] : g0[1];
+                    const uint4 Wa = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 0) * CS + cv * 4]);
+                    const uint4 Wb = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 1) * CS + cv * 4]);
+                    const uint4 Wc = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 2) * CS + cv * 4]);
+                    const uint4 Wd = *reinterpret_cast<const uint4*>(&lwp[(dy * 4 + 3) * CS + cv * 4]);
                     const unsigned ga[4] = {G0.x, G0.y, G0.z, G0.w}, gb[4] = {G1.x, G1.y, G1.z, G1.w};
-                    const unsigned wa[4] = {Wcur[0].x, Wcur[0].y, Wcur[0].z, Wcur[0].w}, wb[4] = {Wcur[1].x, Wcur[1].y, Wcur[1].z, Wcur[1].w};
-                    const unsigned wc[4] = {Wcur[2].x, Wcur[2].y, Wcur[2].z, Wcur[2].w}, wd[4] = {Wcur[3].x, Wcur[3].y, Wcur[3].z, Wcur[3].w};
+                    const unsigned wa[4] = {Wa.x, Wa.y, Wa.z, Wa.w}, wb[4] = {Wb.x, Wb.y, Wb.z, Wb.w};
+                    const unsigned wc[4] = {Wc.x, Wc.y, Wc.z, Wc.w}, wd[4] = {Wd.x, Wd.y, Wd.z, Wd.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         dz0[q] = wk_dot2(ga[q], wa[q], dz0[q]);
@@ -514,10 +500,6 @@ __global__ __launch_bounds__(256, CIN > 0 ? WK_MINW_RC : WK_MINW) void dw_spatia
                         dwp[dy * 3 + 2][q] = wk_dot2(Z[q], ga[q], dwp[dy * 3 + 2][q]);
                         dwp[dy * 3 + 1][q] = wk_dot2(Z[q], gm, dwp[dy * 3 + 1][q]);
                         dwp[dy * 3 + 0][q] = wk_dot2(Z[q], gb[q], dwp[dy * 3 + 0][q]);
-                    }
-                    if constexpr (PIPE) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) Wcur[k] = Wnxt[k];
                     }
                 }
                 T* dst = dh0 + (unsigned)r * dhrow;
@@ -1025,7 +1007,7 @@ template <int LPW, int RB, int CIN>
 static int launch_s1c(const DwSpatialBwd& a, hipStream_t s) {
     constexpr int NG = 16 / LPW, Wqp = LPW + 1;
     // ring + (stored form) the chunk's y1 rows by LDS-DMA / (rebuilt form, 128 input channels) the W1 slice
-    const size_t lds = (size_t)NG * (RB + 2) * Wqp * 256 + (CIN > 0 ? ((CIN > 64 || WK_S1C_PF || WK_S1C_W1LDS) ? (size_t)64 * CIN * 2 : 0) : (size_t)RB * 4096);
+    const size_t lds = (size_t)NG * (RB + 2) * Wqp * 256 + (CIN > 0 ? ((CIN > 64 || WK_S1C_PF >= 2) ? (size_t)64 * CIN * 2 : 0) : (size_t)RB * 4096);
     auto kern = dw_spatial_bwd_s1c_kernel<LPW, RB, CIN>;
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         (void)hipGetLastError();
