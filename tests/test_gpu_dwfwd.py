@@ -106,10 +106,10 @@ def _stored_and_rebuilt(planes, Hin, Win, Cc, stride, rows_band=0, seed=0, cin=6
     return out["stored"], out["rebuilt"], ref
 
 
-# bf16 bounds of ONE stencil pass on unit-variance data: z1 and y2 are each rounded to bf16 once (2^-9 relative, uniform:
-# 1.1e-3 rms each), the stored form also y1 — measured 1.5e-3 (rebuilt) / 1.9e-3 (stored); single elements within a few bf16 ulps
-# of the tap sum's scale
-FWD_L2, FWD_MAX = 4e-3, 0.02
+# bf16 bounds of ONE stencil pass on unit-variance data: z1 and y2 are each rounded to bf16 once, the stored form also y1.
+# Measured (tools/rebuilt_parity_report.py, profiles/r6_rebuilt_parity.txt): relative L2 2.35e-3 rebuilt / 3.0e-3 stored on every
+# shape; largest single error 3.3-4.5e-3 of the largest |y2| (rebuilt), 4.1-4.6e-3 (stored)
+FWD_L2, FWD_MAX = 3.5e-3, 0.015
 
 
 def _check_fwd(stored, rebuilt, ref):

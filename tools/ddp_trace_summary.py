@@ -23,7 +23,7 @@ def main():
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", ""), r.get("Queue_Id", "")))
     rows.sort()
-    is_comm = lambda n: bool(re.search(r"nccl|rccl", n, re.I))
+    is_comm = lambda n: bool(re.search(r"nccl|rccl|oneRank", n, re.I))
     # steps end with the fused optimizer
     opt = [i for i, r in enumerate(rows) if "adamw_ema_kernel" in r[2]]
     if len(opt) < 3:
