@@ -152,7 +152,7 @@ def _stored_and_rebuilt(planes, Hin, Win, Cc, stride, rows_band=0, seed=0, cin=6
 # bf16 bounds of one backward stencil pass on unit-variance data: the staged gradient and dh1 are each rounded to bf16 once, z1
 # enters the weight gradient rounded to bf16, the stored form also reads a rounded y1.  Measured (tools/rebuilt_parity_report.py,
 # profiles/r6_rebuilt_parity.txt): dh1 relative L2 2.35e-3 rebuilt / 2.42e-3 stored, dW 3.6-7.2e-5 rebuilt / 1.2-1.4e-4 stored
-BWD_L2, BWD_DW = 3.5e-3, 5e-4
+BWD_L2, BWD_DW = 3.5e-3, 2e-3       # (dW: the one-row planes of the small cases average over 72 pixels only)
 
 
 def _check_bwd(stored, rebuilt, ref, yhat):
