@@ -1,7 +1,8 @@
 """One InvertedResidual3d block at block 0's shape: gain of the bf16 input gradient (and of the weight gradients) against the fp32
 HIP path, y1 stored vs y1-free (dwn_block_args.y1_mode) — is there a systematic difference between the two bf16 paths?"""
 import math, sys
-sys.path.insert(0, '/root/repo')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 from tests.test_gpu_block import make_block
 from tests.gpu_helpers import dev

@@ -1,5 +1,6 @@
 import math, sys
-sys.path.insert(0, '/root/repo')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np, torch
 from tests.test_gpu_bf16_depth import _model, _fwd_bwd
 from tests.gpu_helpers import synth_inputs, dev
